@@ -1,0 +1,161 @@
+"""The oracle against outputs of the reference's OWN compiled FK stages + libtorch autograd (tests/golden/*.npz,
+generated in the build container by oracle/gen_golden.py from oracle/_ref)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cpu
+from smplpp_amd import model_io
+
+from conftest import GOLDEN, model_digest
+
+VERT_TOL = 1e-5  # metres (BASELINE.json north_star)
+
+
+def test_synthetic_model_is_reproducible(synth_model, golden_fk_synth):
+    assert model_digest(synth_model) == str(golden_fk_synth["model_sha256"])
+    m = synth_model
+    assert m["vertices_template"].shape == (6890, 3) and m["face_indices"].shape == (13776, 3)
+    assert m["face_indices"].min() == 1 and m["face_indices"].max() == 6890
+    # closed genus-0 manifold: every edge shared by exactly two faces
+    f = m["face_indices"].astype(np.int64)
+    edges = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+    _, cnt = np.unique(edges, axis=0, return_counts=True)
+    assert (cnt == 2).all() and len(cnt) == 3 * 6890 - 6
+
+
+def test_fk_synth_golden(oracle_synth, golden_fk_synth):
+    g = golden_fk_synth
+    o = oracle_synth.fk(g["beta"], g["theta"])
+    ids = g["vertex_ids"]
+    assert np.abs(o["verts"][:, ids] - g["verts"]).max() < 2e-6
+    assert np.abs(o["rest"][:, ids] - g["rest"]).max() < 1e-6
+    assert np.abs(o["joints"] - g["joints"]).max() < 1e-6
+    assert np.abs(o["xforms"] - g["xforms"]).max() < 2e-6
+    assert np.abs(o["poserot"] - g["poserot"]).max() < 1e-6
+    np.testing.assert_allclose(o["verts"].astype(np.float64).sum(axis=1), g["verts_sum"], atol=2e-3)
+    np.testing.assert_allclose(np.abs(o["verts"].astype(np.float64)).sum(axis=1), g["verts_abs_sum"], rtol=1e-6)
+
+
+def test_fk_zero_pose_is_template(oracle_synth, synth_model):
+    """BASELINE config 1: beta = 0, theta = 0 -> vertices == template, G' == identity."""
+    o = oracle_synth.fk(np.zeros((1, 10), np.float32), np.zeros((1, 25, 3), np.float32))
+    assert np.abs(o["verts"][0] - synth_model["vertices_template"]).max() < 1e-6
+    eye = np.tile(np.eye(4, dtype=np.float32), (24, 1, 1))
+    assert np.abs(o["xforms"][0] - eye).max() < 1e-6
+
+
+def test_fk_tiny_golden():
+    g = np.load(os.path.join(GOLDEN, "fk_tiny.npz"))
+    m = model_io.tiny_model(61, seed=7)
+    assert model_digest(m) == str(g["model_sha256"])
+    o = cpu.OracleModel(m).fk(g["beta"], g["theta"])
+    for k in ("verts", "rest", "joints", "xforms", "poserot"):
+        assert np.abs(o[k] - g[k]).max() < 3e-6, k
+
+
+@pytest.mark.parametrize("case", ["plain", "body", "full", "motion", "missing"])
+def test_ik_eval_golden(oracle_synth, golden_ik_synth, case):
+    g = golden_ik_synth
+    pl, no, ob, nw, pw = g[case + "_cfg"]
+    K = len(g["face_idx"])
+    ts = cpu.TaskSet(g["face_idx"], g["target_pos"], g["target_normal"], [pw] * K, [nw] * K, [pl] * K, [no] * K)
+    r = oracle_synth.ik_eval(g["beta"], g["theta"], ts, bool(ob))
+    J = g[case + "_J"]
+    assert r["J"].shape == J.shape
+    # position rows: 1e-6 m.  Normal rows are conditioned by the ~2 cm triangles (2e-7 m of fp32 vertex noise over a
+    # 2e-2 m edge ~ 1e-5 in the unit normal), so they get 5e-5.
+    de = np.abs(r["e"] - g[case + "_e"]).reshape(K, 4)
+    assert de[:, :3].max() < 2e-6 and de[:, 3].max() < 5e-5
+    # fp32 reverse-mode autograd vs analytic fp64: agree to fp32 rounding of the autograd path
+    # (normal rows inherit the same triangle conditioning: observed <= 1.6e-4 relative, uniform along a row)
+    dJ = np.abs(r["J"] - J).reshape(K, 4, -1)
+    assert dJ[:, :3].max() < 2e-5 * max(1.0, np.abs(J).max())
+    assert dJ[:, 3].max() < 4e-4 * max(1.0, np.abs(J).max())
+    assert np.abs(ts.vertex_weights - g[case + "_vertex_weights"]).max() < 2e-5
+    assert np.abs(ts.tangents - g[case + "_tangents"]).max() < 1e-4
+    assert np.abs(r["actual_pos"] - g[case + "_actual_pos"]).max() < 1e-6
+    assert np.abs(r["actual_normal"] - g[case + "_actual_normal"]).max() < 2e-5
+    if pw == 0.0:
+        assert not r["e"].any() and not r["J"].any()  # missing marker -> zero rows (node.cpp:681)
+
+
+def test_ik_step_golden(oracle_synth, golden_ik_synth):
+    """One iteration of node.cpp:704-1001 from each state of the golden trajectory (whose Jacobians came from the
+    reference's autograd path): the joint-angle update agrees within the north_star's 1e-4 rad."""
+    g = golden_ik_synth
+    K = len(g["face_idx"])
+    traj, faces, weights = g["traj_theta"], g["traj_faces"], g["traj_weights"]
+    for it in range(traj.shape[0] - 1):
+        ts = cpu.TaskSet(faces[it], g["target_pos"], g["target_normal"], phi_limit=np.zeros(K), vertex_weights=weights[it])
+        _, theta, e2 = oracle_synth.ik_solve(np.zeros(10, np.float32), traj[it], ts, 1)
+        assert np.abs(theta - traj[it + 1]).max() < 1e-4, it
+        assert abs(e2 - g["traj_e_sqnorm"][it]) < 1e-5 * max(1.0, e2)
+        assert (ts.face_idx == faces[it + 1]).all()
+        assert np.abs(ts.vertex_weights - weights[it + 1]).max() < 2e-3
+
+
+def test_ik_trajectory_golden(oracle_synth, golden_ik_synth):
+    """Free-running 12 iterations.  The problem is under-determined (75 unknowns, 24 rows) and the damping
+    1e-3 + |e|^2 (node.cpp:887-893) shrinks as it converges, so fp32 rounding of the reference's autograd Jacobian is
+    amplified along weakly-observed directions: joint angles track to 1e-4 rad while |e|^2 > 1e-3, to 3e-3 after; the
+    task-space residual converges identically."""
+    g = golden_ik_synth
+    K = len(g["face_idx"])
+    ts = cpu.TaskSet(g["face_idx"], g["target_pos"], g["target_normal"], phi_limit=np.zeros(K))
+    traj = g["traj_theta"]
+    beta = np.zeros(10, np.float32)
+    theta = traj[0].copy()
+    for it in range(1, traj.shape[0]):
+        beta, theta, e2 = oracle_synth.ik_solve(beta, theta, ts, 1)
+        tol = 1e-4 if g["traj_e_sqnorm"][it - 1] > 1e-3 else 3e-3
+        assert np.abs(theta - traj[it]).max() < tol, it
+    assert e2 < 2e-5 and g["traj_e_sqnorm"][-1] < 2e-5
+
+
+def test_box_qp_matches_llt_when_unconstrained_and_clamps():
+    rng = np.random.default_rng(0)
+    J = rng.normal(size=(30, 12))
+    A = J.T @ J + 0.1 * np.eye(12)
+    b = rng.normal(size=12)
+    x = cpu.llt_solve(A, b)
+    np.testing.assert_allclose(A @ x, -b, atol=1e-10)
+    xq = cpu.box_qp(A, b, np.full(12, -1e30), np.full(12, 1e30))
+    np.testing.assert_allclose(xq, x, atol=1e-10)
+    lo, hi = np.full(12, -0.05), np.full(12, 0.05)
+    lo[:4], hi[:4] = 0.0, 0.0  # pinned (phiLimit_ == 0)
+    xq = cpu.box_qp(A, b, lo, hi)
+    assert (xq >= lo - 1e-12).all() and (xq <= hi + 1e-12).all() and not xq[:4].any()
+    # KKT: projected gradient vanishes
+    gkk = A @ xq + b
+    free = (xq > lo + 1e-9) & (xq < hi - 1e-9)
+    assert np.abs(gkk[free]).max(initial=0) < 1e-9
+    assert (gkk[(xq <= lo + 1e-9) & (lo < hi)] >= -1e-9).all() and (gkk[(xq >= hi - 1e-9) & (lo < hi)] <= 1e-9).all()
+    # brute-force check against projected gradient descent
+    y = np.clip(np.zeros(12), lo, hi)
+    L = np.linalg.eigvalsh(A).max()
+    for _ in range(20000):
+        y = np.clip(y - (A @ y + b) / L, lo, hi)
+    np.testing.assert_allclose(xq, y, atol=1e-6)
+
+
+def test_closest_points_and_weights_roundtrip(oracle_synth, synth_model):
+    """calcTriangleVertexWeights round trip as in tests/src/TestGeometryUtils.cpp:68-96 (tol 1e-3 there)."""
+    rng = np.random.default_rng(5)
+    v = synth_model["vertices_template"]
+    f0 = synth_model["face_indices"] - 1
+    faces = rng.integers(0, len(f0), 20)
+    bary = rng.dirichlet(np.ones(3), 20).astype(np.float32)
+    bary[:3] = np.eye(3)  # corner cases
+    pts = np.einsum("ki,kix->kx", bary, v[f0[faces]])
+    face, closest, sq = oracle_synth.closest_points(v, pts)
+    assert sq.max() < 1e-10
+    assert np.abs(closest - pts).max() < 1e-5
+    for k in range(20):
+        w = cpu.triangle_vertex_weights(pts[k], v[f0[faces[k]]])
+        assert abs(w.sum() - 1) < 1e-5
+        assert np.abs(w @ v[f0[faces[k]]] - pts[k]).max() < 1e-3
+    # a point off the surface projects onto the mesh
+    face, closest, sq = oracle_synth.closest_points(v, pts + np.float32(0.01) * np.array([[0, 0, 1.0]], np.float32))
+    assert (sq > 0).all() and (sq <= 1.0001e-4).all()
