@@ -1,0 +1,406 @@
+// SMPL::launch (/root/reference/src/SMPL.cpp:671-737) as two gfx950 kernels.
+//
+//  pose_kernel   one 64-lane wavefront per frame: Rodrigues x24 (src/BlendShape.cpp:803-844), pose coefficients
+//                vec(R)[9:] - vec(I)[9:] (:865-895), joints = J0 + JS.beta (src/JointRegression.cpp:583-598, folded),
+//                FK chain over the kinematic tree and relative transforms (src/WorldTransformation.cpp:421-677).
+//                Writes the K-major A operand AT[220][ldA] and G'[n][24][3x4].
+//  skin_kernel   fused: rest = T + S.beta + P.c as ONE fp32 GEMM [frames x 220] x [220 x 3V] on
+//                v_mfma_f32_32x32x2_f32 (exact fp32; bf16/fp16 operands would break the 1e-5 m bound), then in the
+//                epilogue, on the accumulator registers, linear blend skinning with the frame tile's G' staged in LDS
+//                (src/JointRegression.cpp:551-565, src/LinearBlendSkinning.cpp:445-553).  No [n,V,4,4] intermediate,
+//                no rest-shape round trip through HBM.
+//
+// Tile: a 256-thread workgroup = 4 wavefronts = (32*FT frames) x (4 groups of 32 vertices); each wavefront owns
+// FT x 3 accumulator tiles of 32x32 (frames x {x,y,z} of its 32 vertices), so a lane ends up holding rest_x/y/z of
+// ONE vertex for 16*FT frames and skins them without any cross-lane traffic.
+// XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch); all frame tiles of one vertex quad are
+// given to one XCD, consecutively, so each 338 KB slice of Bm is pulled into that XCD's L2 once per launch.
+#include "common.h"
+
+namespace smplpp_hip
+{
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------- pose kernel
+__device__ inline void rodrigues_dev(float t0, float t1, float t2, float * R)
+{
+  const float eps = 1e-8f;
+  float a0 = t0 + eps, a1 = t1 + eps, a2 = t2 + eps; // src/BlendShape.cpp:813-814
+  float angle = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+  float k0 = t0 / angle, k1 = t1 / angle, k2 = t2 / angle; // :815
+  float K[9] = {0.0f, -k2, k1, k2, 0.0f, -k0, -k1, k0, 0.0f};
+  float s = sinf(angle), c1 = 1.0f - cosf(angle);
+#pragma unroll
+  for(int r = 0; r < 3; r++)
+#pragma unroll
+    for(int c = 0; c < 3; c++)
+    {
+      float kk = K[r * 3 + 0] * K[0 * 3 + c] + K[r * 3 + 1] * K[1 * 3 + c] + K[r * 3 + 2] * K[2 * 3 + c];
+      R[r * 3 + c] = ((r == c) ? 1.0f : 0.0f) + K[r * 3 + c] * s + kk * c1; // :841
+    }
+}
+
+// grid = n frames, block = 64.  rot_in (nullable): use these [n,24,3,3] matrices instead of Rodrigues(theta)
+// (stage entry point WorldTransformation::transform on arbitrary 3x3 input); joints_in likewise.
+__global__ __launch_bounds__(64) void pose_kernel(const float * __restrict__ beta, const float * __restrict__ theta,
+                                                  const float * __restrict__ J0, const float * __restrict__ JS,
+                                                  const int32_t * __restrict__ parent, float * __restrict__ AT, int64_t ldA,
+                                                  float * __restrict__ Gp, float * __restrict__ joints_out,
+                                                  float * __restrict__ rot_out, float * __restrict__ xf44_out,
+                                                  const float * __restrict__ rot_in, const float * __restrict__ joints_in,
+                                                  int64_t n)
+{
+  const int64_t f = blockIdx.x;
+  const int lane = threadIdx.x;
+  __shared__ float sR[NJ][9];
+  __shared__ float sJ[NJ][3];
+  __shared__ float sG[NJ][12]; // global transforms [A | g], 3x4 row-major
+  __shared__ float sBeta[NB];
+  __shared__ int sPar[NJ];
+  if(f >= n) return;
+  if(lane < NB && beta) sBeta[lane] = beta[f * NB + lane];
+  if(lane < NJ) sPar[lane] = parent[lane];
+  if(lane < NJ)
+  {
+    float R[9];
+    if(rot_in)
+    {
+#pragma unroll
+      for(int q = 0; q < 9; q++) R[q] = rot_in[(f * NJ + lane) * 9 + q];
+    }
+    else
+    {
+      const float * th = theta + (f * (NJ + 1) + 1 + lane) * 3; // theta[:,1:,:] (src/SMPL.cpp:685-686)
+      rodrigues_dev(th[0], th[1], th[2], R);
+    }
+#pragma unroll
+    for(int q = 0; q < 9; q++) sR[lane][q] = R[q];
+    if(rot_out)
+#pragma unroll
+      for(int q = 0; q < 9; q++) rot_out[(f * NJ + lane) * 9 + q] = R[q];
+    if(AT && lane >= 1) // root joint has no pose corrective (src/BlendShape.cpp:884-887)
+#pragma unroll
+      for(int q = 0; q < 9; q++) AT[(int64_t)(9 * (lane - 1) + q) * ldA + f] = R[q] - ((q == 0 || q == 4 || q == 8) ? 1.0f : 0.0f);
+  }
+  __syncthreads();
+  if(AT)
+  {
+    if(lane < NB) AT[(int64_t)(K_BETA + lane) * ldA + f] = sBeta[lane];
+    if(lane == NB) AT[(int64_t)K_ONE * ldA + f] = 1.0f;
+    if(lane == NB + 1) AT[(int64_t)(K_ONE + 1) * ldA + f] = 0.0f;
+    if(lane == NB + 2) AT[(int64_t)(K_ONE + 2) * ldA + f] = 0.0f;
+  }
+  for(int e = lane; e < NJ * 3; e += 64) // joints (src/JointRegression.cpp:588-590 through the folded regressor)
+  {
+    float s;
+    if(joints_in)
+      s = joints_in[f * NJ * 3 + e];
+    else
+    {
+      s = J0[e];
+#pragma unroll
+      for(int k = 0; k < NB; k++) s += JS[e * NB + k] * sBeta[k];
+    }
+    sJ[e / 3][e % 3] = s;
+    if(joints_out) joints_out[f * NJ * 3 + e] = s;
+  }
+  __syncthreads();
+  // chain: G_0 = L_0, G_i = G_p(i) . L_i with L_i = [R_i | j_i - j_p(i)] (src/WorldTransformation.cpp:508-610)
+  if(lane < 12)
+  {
+    int r = lane / 4, c = lane % 4;
+    sG[0][lane] = (c < 3) ? sR[0][r * 3 + c] : sJ[0][r];
+  }
+  __syncthreads();
+  for(int i = 1; i < NJ; i++)
+  {
+    if(lane < 12)
+    {
+      int r = lane / 4, c = lane % 4, p = sPar[i];
+      float v;
+      if(c < 3)
+        v = sG[p][r * 4 + 0] * sR[i][0 * 3 + c] + sG[p][r * 4 + 1] * sR[i][1 * 3 + c] + sG[p][r * 4 + 2] * sR[i][2 * 3 + c];
+      else
+      {
+        float t0 = sJ[i][0] - sJ[p][0], t1 = sJ[i][1] - sJ[p][1], t2 = sJ[i][2] - sJ[p][2];
+        v = sG[p][r * 4 + 0] * t0 + sG[p][r * 4 + 1] * t1 + sG[p][r * 4 + 2] * t2 + sG[p][r * 4 + 3];
+      }
+      sG[i][lane] = v;
+    }
+    __syncthreads();
+  }
+  // relative transforms: translation -= A_i . j_i (src/WorldTransformation.cpp:657-677)
+  for(int e = lane; e < NJ * 12; e += 64)
+  {
+    int i = e / 12, q = e % 12, r = q / 4, c = q % 4;
+    float v = sG[i][q];
+    if(c == 3) v -= sG[i][r * 4 + 0] * sJ[i][0] + sG[i][r * 4 + 1] * sJ[i][1] + sG[i][r * 4 + 2] * sJ[i][2];
+    if(Gp) Gp[(f * NJ + i) * 12 + q] = v;
+    if(xf44_out) xf44_out[(f * NJ + i) * 16 + q] = v;
+  }
+  if(xf44_out)
+    for(int e = lane; e < NJ * 4; e += 64) xf44_out[(f * NJ + e / 4) * 16 + 12 + e % 4] = (e % 4 == 3) ? 1.0f : 0.0f;
+}
+
+// rows [n, ldA) of AT are padding for the last 32-frame tile: keep them zero (re-zeroed whenever n changes)
+__global__ void zero_pad_kernel(float * __restrict__ AT, int64_t ldA, int64_t n)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t pad = ldA - n;
+  if(i >= (int64_t)KP * pad) return;
+  AT[(i / pad) * ldA + n + i % pad] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------- fused kernel
+constexpr int KSTEPS = KP / 2; // 110 MFMA k-steps of 2
+constexpr int UNR = 5;         // k-steps per software-pipeline chunk (110 = 22 * 5)
+
+template<int FT, int MAXW>
+__global__ __launch_bounds__(256, 2) void skin_kernel(const float * __restrict__ AT, int64_t ldA, const float * __restrict__ Bm,
+                                                   int64_t ldB, const float * __restrict__ Gp, const float * __restrict__ theta,
+                                                   const uint8_t * __restrict__ wIdx, const float * __restrict__ wVal,
+                                                   const float * __restrict__ wSum, float * __restrict__ verts,
+                                                   float * __restrict__ rest, int64_t n, int64_t V, int VGn, int nft)
+{
+  extern __shared__ __attribute__((aligned(16))) float lds[]; // [32*FT][24][12] G' + [32*FT][3] root translation
+  constexpr int FRAMES = 32 * FT;
+  float * sG = lds;
+  float * sRoot = lds + FRAMES * NJ * 12;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nq = (VGn + 3) / 4;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int q = (slot / nft) * 8 + xcd;
+  const int ftile = slot % nft;
+  if(q >= nq) return;
+  const int64_t f0 = (int64_t)ftile * FRAMES;
+  const int vg = q * 4 + wave;
+
+  // stage G' and root translations of this frame tile (frames >= n read as zero)
+  {
+    const int64_t nvalid = (n - f0 < FRAMES ? n - f0 : FRAMES) * (NJ * 12);
+    const float4 * src = reinterpret_cast<const float4 *>(Gp + f0 * NJ * 12);
+    float4 * dst = reinterpret_cast<float4 *>(sG);
+    for(int i = tid; i < FRAMES * NJ * 3; i += 256)
+    {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if((int64_t)i * 4 < nvalid) v = src[i];
+      dst[i] = v;
+    }
+    for(int i = tid; i < FRAMES * 3; i += 256)
+    {
+      int64_t f = f0 + i / 3;
+      sRoot[i] = (f < n) ? theta[f * (NJ + 1) * 3 + i % 3] : 0.0f; // theta[:,0,:] (src/SMPL.cpp:726-727)
+    }
+  }
+
+  f32x16 acc[FT][3];
+#pragma unroll
+  for(int t = 0; t < FT; t++)
+#pragma unroll
+    for(int x = 0; x < 3; x++)
+#pragma unroll
+      for(int r = 0; r < 16; r++) acc[t][x][r] = 0.0f;
+
+  if(vg < VGn)
+  {
+    // operand pointers: lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31]
+    const float * Ap = AT + (int64_t)(lane >> 5) * ldA + f0 + (lane & 31);
+    const float * Bp = Bm + (int64_t)(lane >> 5) * ldB + (int64_t)vg * (3 * VG) + (lane & 31);
+    float a_cur[UNR][FT], b_cur[UNR][3], a_nxt[UNR][FT], b_nxt[UNR][3];
+#pragma unroll
+    for(int u = 0; u < UNR; u++)
+    {
+#pragma unroll
+      for(int t = 0; t < FT; t++) a_cur[u][t] = Ap[(int64_t)(2 * u) * ldA + 32 * t];
+#pragma unroll
+      for(int x = 0; x < 3; x++) b_cur[u][x] = Bp[(int64_t)(2 * u) * ldB + VG * x];
+    }
+    for(int c = 0; c < KSTEPS / UNR; c++)
+    {
+      if(c + 1 < KSTEPS / UNR)
+      {
+        const float * An = Ap + (int64_t)(2 * UNR) * (c + 1) * ldA;
+        const float * Bn = Bp + (int64_t)(2 * UNR) * (c + 1) * ldB;
+#pragma unroll
+        for(int u = 0; u < UNR; u++)
+        {
+#pragma unroll
+          for(int t = 0; t < FT; t++) a_nxt[u][t] = An[(int64_t)(2 * u) * ldA + 32 * t];
+#pragma unroll
+          for(int x = 0; x < 3; x++) b_nxt[u][x] = Bn[(int64_t)(2 * u) * ldB + VG * x];
+        }
+      }
+#pragma unroll
+      for(int u = 0; u < UNR; u++)
+#pragma unroll
+        for(int t = 0; t < FT; t++)
+#pragma unroll
+          for(int x = 0; x < 3; x++) acc[t][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][t], b_cur[u][x], acc[t][x], 0, 0, 0);
+#pragma unroll
+      for(int u = 0; u < UNR; u++)
+      {
+#pragma unroll
+        for(int t = 0; t < FT; t++) a_cur[u][t] = a_nxt[u][t];
+#pragma unroll
+        for(int x = 0; x < 3; x++) b_cur[u][x] = b_nxt[u][x];
+      }
+    }
+  }
+  __syncthreads(); // G' staged
+
+  if(vg >= VGn) return;
+  const int64_t v = (int64_t)vg * VG + (lane & 31);
+  if(v >= V) return;
+  // this lane's skinning weights
+  int jidx[MAXW];
+  float jw[MAXW];
+#pragma unroll
+  for(int i = 0; i < MAXW; i++)
+  {
+    jidx[i] = wIdx[v * MAXW + i];
+    jw[i] = wVal[v * MAXW + i];
+  }
+  const float wsum = wSum[v];
+#pragma unroll
+  for(int t = 0; t < FT; t++)
+#pragma unroll
+    for(int r = 0; r < 16; r++)
+    {
+      const int fl = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); // accumulator row -> frame in tile
+      const int64_t f = f0 + fl;
+      if(f >= n) continue;
+      const float rx = acc[t][0][r], ry = acc[t][1][r], rz = acc[t][2][r];
+      if(rest)
+      {
+        float * o = rest + (f * V + v) * 3;
+        o[0] = rx;
+        o[1] = ry;
+        o[2] = rz;
+      }
+      if(!verts) continue;
+      // M = sum_j W[v,j] G'_j (src/LinearBlendSkinning.cpp:463), rows of [A | b]
+      float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0, m2 = m0;
+      const float * g = sG + fl * (NJ * 12);
+#pragma unroll
+      for(int i = 0; i < MAXW; i++)
+      {
+        const float4 * gj = reinterpret_cast<const float4 *>(g + jidx[i] * 12);
+        const float4 g0 = gj[0], g1 = gj[1], g2 = gj[2];
+        const float w = jw[i];
+        m0.x += w * g0.x; m0.y += w * g0.y; m0.z += w * g0.z; m0.w += w * g0.w;
+        m1.x += w * g1.x; m1.y += w * g1.y; m1.z += w * g1.z; m1.w += w * g1.w;
+        m2.x += w * g2.x; m2.y += w * g2.y; m2.z += w * g2.z; m2.w += w * g2.w;
+      }
+      // h = M [rest; 1] (:465-467); cart = h[:3] / h[3] (:545-550) with h[3] = sum_j W[v,j]; + root (:475)
+      const float hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
+      const float hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
+      const float hz = ((m2.x * rx + m2.y * ry) + m2.z * rz) + m2.w;
+      float * o = verts + (f * V + v) * 3;
+      o[0] = hx / wsum + sRoot[fl * 3 + 0];
+      o[1] = hy / wsum + sRoot[fl * 3 + 1];
+      o[2] = hz / wsum + sRoot[fl * 3 + 2];
+    }
+}
+
+template<int FT, int MAXW>
+static hipError_t launch_skin(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest,
+                              hipStream_t st)
+{
+  const int nft = (int)((n + 32 * FT - 1) / (32 * FT));
+  const int nq = (int)((m->VGn + 3) / 4);
+  const int grid = 8 * ((nq + 7) / 8) * nft;
+  const size_t shmem = sizeof(float) * (size_t)(32 * FT) * (NJ * 12 + 3);
+  static bool attr_set = false;
+  if(!attr_set)
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&skin_kernel<FT, MAXW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if(e != hipSuccess) return e;
+    attr_set = true;
+  }
+  skin_kernel<FT, MAXW><<<dim3(grid), dim3(256), shmem, st>>>(m->ws.AT.as<float>(), m->ws.ldA, m->Bm, m->ldB,
+                                                              m->ws.Gp.as<float>(), theta, m->wIdx, m->wVal, m->wSum, verts,
+                                                              rest, n, m->V, (int)m->VGn, nft);
+  return hipGetLastError();
+}
+
+template<int FT>
+static hipError_t launch_skin_w(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest,
+                                hipStream_t st)
+{
+  switch(m->maxw)
+  {
+    case 4:
+      return launch_skin<FT, 4>(m, n, theta, verts, rest, st);
+    case 8:
+      return launch_skin<FT, 8>(m, n, theta, verts, rest, st);
+    default:
+      return launch_skin<FT, NJ>(m, n, theta, verts, rest, st);
+  }
+}
+
+// Device-pointer FK (enqueue only).  Used by smplpp_fk and by the IK solver.
+int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
+              float * xforms44, float * rest, float * poserot, hipStream_t st)
+{
+  Workspace & ws = m->ws;
+  const int64_t ldA = ((n + 63) / 64) * 64;
+  const bool relaid = (ldA != ws.ldA);
+  HIP_TRY(ws.AT.reserve(sizeof(float) * (size_t)KP * ldA));
+  HIP_TRY(ws.Gp.reserve(sizeof(float) * (size_t)n * NJ * 12));
+  ws.ldA = ldA;
+  (void)relaid;
+  if(ldA > n)
+  {
+    int64_t cnt = (int64_t)KP * (ldA - n);
+    zero_pad_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(ws.AT.as<float>(), ldA, n);
+  }
+  pose_kernel<<<dim3((unsigned)n), dim3(64), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, ws.AT.as<float>(), ldA,
+                                                      ws.Gp.as<float>(), joints, poserot, xforms44, nullptr, nullptr, n);
+  HIP_TRY(hipGetLastError());
+  if(verts || rest)
+  {
+    if(n <= 32)
+      HIP_TRY(launch_skin_w<1>(m, n, theta, verts, rest, st));
+    else
+      HIP_TRY(launch_skin_w<2>(m, n, theta, verts, rest, st));
+  }
+  return SMPLPP_OK;
+}
+} // namespace smplpp_hip
+
+using namespace smplpp_hip;
+
+extern "C" int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
+                         float * xforms, float * rest, int space, void * stream)
+{
+  if(!m) return fail(SMPLPP_ERR_INVALID, "Cannot launch a SMPL model!"); // src/SMPL.cpp:676
+  if(n <= 0 || !beta || !theta) return fail(SMPLPP_ERR_INVALID, "Cannot launch a SMPL model!");
+  if(space != SMPLPP_HOST && space != SMPLPP_DEVICE) return fail(SMPLPP_ERR_INVALID, "smplpp_fk: bad memory space");
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if(space == SMPLPP_DEVICE) return fk_device(m, n, beta, theta, verts, joints, xforms, rest, nullptr, st);
+
+  Workspace & ws = m->ws;
+  const size_t nb = sizeof(float) * (size_t)n * NB, nt = sizeof(float) * (size_t)n * (NJ + 1) * 3;
+  const size_t nv = sizeof(float) * (size_t)n * m->V * 3;
+  HIP_TRY(ws.beta.reserve(nb));
+  HIP_TRY(ws.theta.reserve(nt));
+  if(verts) HIP_TRY(ws.verts.reserve(nv));
+  if(rest) HIP_TRY(ws.rest.reserve(nv));
+  if(joints) HIP_TRY(ws.joints.reserve(sizeof(float) * (size_t)n * NJ * 3));
+  if(xforms) HIP_TRY(ws.xf44.reserve(sizeof(float) * (size_t)n * NJ * 16));
+  HIP_TRY(hipMemcpyAsync(ws.beta.p, beta, nb, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ws.theta.p, theta, nt, hipMemcpyHostToDevice, st));
+  int rc = fk_device(m, n, ws.beta.as<float>(), ws.theta.as<float>(), verts ? ws.verts.as<float>() : nullptr,
+                     joints ? ws.joints.as<float>() : nullptr, xforms ? ws.xf44.as<float>() : nullptr,
+                     rest ? ws.rest.as<float>() : nullptr, nullptr, st);
+  if(rc) return rc;
+  if(verts) HIP_TRY(hipMemcpyAsync(verts, ws.verts.p, nv, hipMemcpyDeviceToHost, st));
+  if(rest) HIP_TRY(hipMemcpyAsync(rest, ws.rest.p, nv, hipMemcpyDeviceToHost, st));
+  if(joints) HIP_TRY(hipMemcpyAsync(joints, ws.joints.p, sizeof(float) * (size_t)n * NJ * 3, hipMemcpyDeviceToHost, st));
+  if(xforms) HIP_TRY(hipMemcpyAsync(xforms, ws.xf44.p, sizeof(float) * (size_t)n * NJ * 16, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return SMPLPP_OK;
+}

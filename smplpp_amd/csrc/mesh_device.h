@@ -1,0 +1,189 @@
+// Device-side geometry helpers shared by mesh.hip and ik.hip (fp32, the reference's operation order).
+#pragma once
+#include "common.h"
+
+namespace smplpp_hip
+{
+__device__ inline void cross3(const float * a, const float * b, float * c)
+{
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// torch::nn::functional::normalize: x / max(||x||, 1e-12)
+__device__ inline void normalize3(float * x)
+{
+  float nrm = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  nrm = fmaxf(nrm, 1e-12f);
+  x[0] /= nrm;
+  x[1] /= nrm;
+  x[2] /= nrm;
+}
+
+// SMPL::calcNormal (src/SMPL.cpp:518-525)
+__device__ inline void face_normal_dev(const float * verts, const int32_t * faces, int face, float * nn)
+{
+  const float * v0 = verts + 3 * faces[face * 3 + 0];
+  const float * v1 = verts + 3 * faces[face * 3 + 1];
+  const float * v2 = verts + 3 * faces[face * 3 + 2];
+  float a[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+  float b[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+  cross3(a, b, nn);
+  normalize3(nn);
+}
+
+// SMPL::calcVertexNormal (src/SMPL.cpp:527-535), uniform weights 1/deg (:630-639), ascending face id
+__device__ inline void vertex_normal_dev(const float * verts, const int32_t * faces, const int32_t * adjOff,
+                                         const int32_t * adjFace, int vertex, float * nn)
+{
+  const int b = adjOff[vertex], e = adjOff[vertex + 1];
+  float sum = 0.0f;
+  for(int q = b; q < e; q++) sum += 1.0f;
+  const float w = 1.0f / sum;
+  float acc[3] = {0.f, 0.f, 0.f};
+  for(int q = b; q < e; q++)
+  {
+    float fn[3];
+    face_normal_dev(verts, faces, adjFace[q], fn);
+    acc[0] += w * fn[0];
+    acc[1] += w * fn[1];
+    acc[2] += w * fn[2];
+  }
+  normalize3(acc);
+  nn[0] = acc[0];
+  nn[1] = acc[1];
+  nn[2] = acc[2];
+}
+
+// calcTriangleVertexWeights (include/smplpp/toolbox/GeometryUtils.h:42-52)
+__device__ inline void triangle_weights_dev(const float * pos, const float * tri /*[3][3]*/, float * w)
+{
+  float d[3][3], c[3];
+  for(int i = 0; i < 3; i++)
+    for(int x = 0; x < 3; x++) d[i][x] = tri[i * 3 + x] - pos[x];
+  for(int i = 0; i < 3; i++)
+  {
+    cross3(d[(i + 1) % 3], d[(i + 2) % 3], c);
+    w[i] = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+  }
+  float s = (w[0] + w[1]) + w[2];
+  w[0] /= s;
+  w[1] /= s;
+  w[2] /= s;
+}
+
+// closest point on triangle abc to p (Ericson, Real-Time Collision Detection 5.1.5)
+__device__ inline void closest_on_triangle_dev(const float * p, const float * a, const float * b, const float * c, float * out)
+{
+  float ab[3], ac[3], ap[3], bp[3], cp[3];
+  for(int x = 0; x < 3; x++)
+  {
+    ab[x] = b[x] - a[x];
+    ac[x] = c[x] - a[x];
+    ap[x] = p[x] - a[x];
+    bp[x] = p[x] - b[x];
+    cp[x] = p[x] - c[x];
+  }
+#define SMPLPP_D3(u, v) (u[0] * v[0] + u[1] * v[1] + u[2] * v[2])
+  const float d1 = SMPLPP_D3(ab, ap), d2 = SMPLPP_D3(ac, ap);
+  const float d3 = SMPLPP_D3(ab, bp), d4 = SMPLPP_D3(ac, bp);
+  const float d5 = SMPLPP_D3(ab, cp), d6 = SMPLPP_D3(ac, cp);
+#undef SMPLPP_D3
+  if(d1 <= 0.0f && d2 <= 0.0f)
+  {
+    out[0] = a[0]; out[1] = a[1]; out[2] = a[2];
+    return;
+  }
+  if(d3 >= 0.0f && d4 <= d3)
+  {
+    out[0] = b[0]; out[1] = b[1]; out[2] = b[2];
+    return;
+  }
+  const float vc = d1 * d4 - d3 * d2;
+  if(vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f)
+  {
+    const float v = d1 / (d1 - d3);
+    for(int x = 0; x < 3; x++) out[x] = a[x] + v * ab[x];
+    return;
+  }
+  if(d6 >= 0.0f && d5 <= d6)
+  {
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
+    return;
+  }
+  const float vb = d5 * d2 - d1 * d6;
+  if(vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f)
+  {
+    const float w = d2 / (d2 - d6);
+    for(int x = 0; x < 3; x++) out[x] = a[x] + w * ac[x];
+    return;
+  }
+  const float va = d3 * d6 - d5 * d4;
+  if(va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f)
+  {
+    const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    for(int x = 0; x < 3; x++) out[x] = b[x] + w * (c[x] - b[x]);
+    return;
+  }
+  const float denom = 1.0f / (va + vb + vc);
+  const float v = vb * denom, w = vc * denom;
+  for(int x = 0; x < 3; x++) out[x] = a[x] + ab[x] * v + ac[x] * w;
+}
+
+// Block-wide (256 threads) closest point of ONE query against all F faces of one frame's mesh.
+// Ties resolve to the lowest face id.  Results written by thread 0.
+__device__ inline void closest_point_block(const float * verts, const int32_t * faces, int64_t F, const float * point,
+                                           int64_t * face_out, float * closest_out, float * sq_out)
+{
+  const float p[3] = {point[0], point[1], point[2]};
+  float best = INFINITY;
+  int bf = 0x7fffffff;
+  float bc[3] = {0.f, 0.f, 0.f};
+  for(int64_t f = threadIdx.x; f < F; f += blockDim.x)
+  {
+    float c[3];
+    closest_on_triangle_dev(p, verts + 3 * faces[f * 3], verts + 3 * faces[f * 3 + 1], verts + 3 * faces[f * 3 + 2], c);
+    const float dx = c[0] - p[0], dy = c[1] - p[1], dz = c[2] - p[2];
+    const float d = dx * dx + dy * dy + dz * dz;
+    if(d < best) // f ascends within a thread, so the first minimum is the lowest id
+    {
+      best = d;
+      bf = (int)f;
+      bc[0] = c[0]; bc[1] = c[1]; bc[2] = c[2];
+    }
+  }
+  for(int off = 32; off > 0; off >>= 1)
+  {
+    const float od = __shfl_down(best, off, 64);
+    const int of = __shfl_down(bf, off, 64);
+    const float o0 = __shfl_down(bc[0], off, 64), o1 = __shfl_down(bc[1], off, 64), o2 = __shfl_down(bc[2], off, 64);
+    if(od < best || (od == best && of < bf))
+    {
+      best = od; bf = of; bc[0] = o0; bc[1] = o1; bc[2] = o2;
+    }
+  }
+  __shared__ float s_d[4], s_c[4][3];
+  __shared__ int s_f[4];
+  const int wave = threadIdx.x >> 6;
+  if((threadIdx.x & 63) == 0)
+  {
+    s_d[wave] = best; s_f[wave] = bf; s_c[wave][0] = bc[0]; s_c[wave][1] = bc[1]; s_c[wave][2] = bc[2];
+  }
+  __syncthreads();
+  if(threadIdx.x == 0)
+  {
+    int w = 0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for(int i = 1; i < nw; i++)
+      if(s_d[i] < s_d[w] || (s_d[i] == s_d[w] && s_f[i] < s_f[w])) w = i;
+    if(face_out) *face_out = s_f[w];
+    if(closest_out)
+    {
+      closest_out[0] = s_c[w][0]; closest_out[1] = s_c[w][1]; closest_out[2] = s_c[w][2];
+    }
+    if(sq_out) *sq_out = s_d[w];
+  }
+  __syncthreads();
+}
+} // namespace smplpp_hip

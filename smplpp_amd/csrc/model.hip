@@ -1,0 +1,290 @@
+// Model creation: replaces SMPL::init (/root/reference/src/SMPL.cpp:560-643) minus the JSON parse.
+//
+// HBM layout produced here (all fp32 unless noted, resident for the life of the handle):
+//   Bm   [220][ldB]   B operand of the fused blend-shape GEMM, K-major: rows 0..206 posedirs, 207..216 shapedirs,
+//                     217 template, 218..219 zero.  Columns are grouped per 32 vertices as [32 x | 32 y | 32 z] so
+//                     that one 32x32 MFMA tile is one coordinate of 32 consecutive vertices (ldB = ceil(V/32)*96).
+//   wIdx/wVal [Vpad][maxw]  skinning weights, the maxw (4, 8 or 24) non-zeros per vertex in ascending joint order.
+//   wSum [Vpad]       sum_j W[v,j]: the blended homogeneous coordinate the reference divides by
+//                     (src/LinearBlendSkinning.cpp:545-550).
+//   J0 [24][3], JS [24][3][10]  joint regressor folded through template and shapedirs:
+//                     joints = J0 + JS . beta  ==  Jreg . (T + S . beta)   (src/JointRegression.cpp:588-590)
+//   faces, adjOff/adjFace      0-based faces and the per-vertex adjacent-face table (src/SMPL.cpp:620-640).
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace smplpp_hip
+{
+static thread_local std::string g_last_error;
+
+void set_error(const std::string & msg)
+{
+  g_last_error = msg;
+}
+
+int fail(int code, const std::string & msg)
+{
+  g_last_error = msg;
+  return code;
+}
+
+int hip_fail(hipError_t e, const char * what, const char * file, int line)
+{
+  char buf[512];
+  snprintf(buf, sizeof(buf), "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  g_last_error = buf;
+  return SMPLPP_ERR_HIP;
+}
+
+// Bm[k][bcol(v,x)] <- P[v][x][k] (k < 207) | S[v][x][k-207] | T[v][x] | 0
+__global__ void relayout_basis_kernel(const float * __restrict__ P, const float * __restrict__ S, const float * __restrict__ T,
+                                      float * __restrict__ Bm, int64_t V, int64_t ldB)
+{
+  int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(col >= ldB) return;
+  int64_t g = col / (3 * VG);
+  int x = (int)((col % (3 * VG)) / VG);
+  int64_t v = g * VG + col % VG;
+  for(int k = 0; k < KP; k++)
+  {
+    float val = 0.0f;
+    if(v < V)
+    {
+      if(k < NP)
+        val = P[(v * 3 + x) * NP + k];
+      else if(k < NP + NB)
+        val = S[(v * 3 + x) * NB + (k - NP)];
+      else if(k == K_ONE)
+        val = T[v * 3 + x];
+    }
+    Bm[(int64_t)k * ldB + col] = val;
+  }
+}
+
+// One block per (joint j, coordinate x, term t): t < 10 -> JS[j][x][t] = sum_v Jreg[j,v] S[v,x,t];
+// t == 10 -> J0[j][x] = sum_v Jreg[j,v] T[v,x].  Wavefront (64-lane) shuffle reduction, then across the 4 waves.
+__global__ __launch_bounds__(256) void fold_regressor_kernel(const float * __restrict__ Jreg, const float * __restrict__ S,
+                                                              const float * __restrict__ T, float * __restrict__ J0,
+                                                              float * __restrict__ JS, int64_t V)
+{
+  const int t = blockIdx.x % (NB + 1);
+  const int x = (blockIdx.x / (NB + 1)) % 3;
+  const int j = blockIdx.x / (3 * (NB + 1));
+  double acc = 0.0; // fp64 partials: the reference's GEMM summation order over 6890 terms is BLAS-defined
+  for(int64_t v = threadIdx.x; v < V; v += blockDim.x)
+  {
+    float w = Jreg[(int64_t)j * V + v];
+    float b = (t < NB) ? S[(v * 3 + x) * NB + t] : T[v * 3 + x];
+    acc += (double)w * (double)b;
+  }
+  for(int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double part[4];
+  if((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if(threadIdx.x == 0)
+  {
+    double s = (part[0] + part[1]) + (part[2] + part[3]);
+    if(t < NB)
+      JS[(j * 3 + x) * NB + t] = (float)s;
+    else
+      J0[j * 3 + x] = (float)s;
+  }
+}
+
+template<class T>
+static hipError_t upload(T ** dst, const T * src, size_t count)
+{
+  hipError_t e = hipMalloc((void **)dst, sizeof(T) * std::max<size_t>(count, 1));
+  if(e != hipSuccess) return e;
+  if(count) e = hipMemcpy(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice);
+  return e;
+}
+} // namespace smplpp_hip
+
+using namespace smplpp_hip;
+
+extern "C" const char * smplpp_last_error(void)
+{
+  return g_last_error.c_str();
+}
+
+extern "C" int smplpp_device_count(int * count)
+{
+  if(!count) return fail(SMPLPP_ERR_INVALID, "smplpp_device_count: null argument");
+  *count = 0;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if(e != hipSuccess || n <= 0)
+  {
+    (void)hipGetLastError();
+    return fail(SMPLPP_ERR_HIP, "no HIP device visible (libsmplpp_hip.so is MI355X-only and has no CPU path)");
+  }
+  *count = n;
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_model_destroy(smplpp_model * m)
+{
+  if(!m) return SMPLPP_OK;
+  (void)hipSetDevice(m->device);
+  void * ptrs[] = {m->Bm, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense};
+  for(void * p : ptrs)
+    if(p) (void)hipFree(p);
+  Workspace & w = m->ws;
+  for(DevBuf * b : {&w.AT, &w.Gp, &w.joints, &w.poserot, &w.beta, &w.theta, &w.verts, &w.rest, &w.xf44}) b->release();
+  delete m;
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const float * S, const float * P,
+                                   const float * Jreg, const float * W, const int64_t * kintree, const int32_t * faces1,
+                                   int device, smplpp_model ** out)
+{
+  if(!out) return fail(SMPLPP_ERR_INVALID, "smplpp_model_create: null output");
+  *out = nullptr;
+  if(V <= 0 || F < 0 || !vt || !S || !P || !Jreg || !W || !kintree || (F > 0 && !faces1))
+    return fail(SMPLPP_ERR_INVALID, "Cannot initialize a SMPL model!"); // src/SMPL.cpp:616
+  int ndev = 0;
+  int rc = smplpp_device_count(&ndev);
+  if(rc) return rc;
+  if(device < 0 || device >= ndev) return fail(SMPLPP_ERR_INVALID, "Failed to fetch device index!"); // src/SMPL.cpp:295
+  // kinematic tree: row 0 = parent (src/WorldTransformation.cpp:523); must be topologically ordered like SMPL's
+  std::vector<int32_t> parent(NJ);
+  parent[0] = -1;
+  for(int i = 1; i < NJ; i++)
+  {
+    if(kintree[i] < 0 || kintree[i] >= i) return fail(SMPLPP_ERR_INVALID, "Cannot set kinematic tree: parent(i) must precede i");
+    parent[i] = (int32_t)kintree[i];
+  }
+  for(int64_t i = 0; i < F * 3; i++)
+    if(faces1[i] < 1 || faces1[i] > V) return fail(SMPLPP_ERR_INVALID, "face_indices must be 1-based vertex ids");
+
+  HIP_TRY(hipSetDevice(device));
+  smplpp_model * m = new smplpp_model();
+  m->device = device;
+  m->V = V;
+  m->F = F;
+  m->VGn = (V + VG - 1) / VG;
+  m->ldB = m->VGn * 3 * VG;
+  m->h_parent = parent;
+
+#define TRY_OR_FREE(expr)                                      \
+  do                                                           \
+  {                                                            \
+    hipError_t _e = (expr);                                    \
+    if(_e != hipSuccess)                                       \
+    {                                                          \
+      int _rc = hip_fail(_e, #expr, __FILE__, __LINE__);       \
+      smplpp_model_destroy(m);                                 \
+      return _rc;                                              \
+    }                                                          \
+  } while(0)
+
+  // --- blend bases -> Bm, regressor fold (device side; the raw arrays are only needed transiently) ---
+  float *dP = nullptr, *dS = nullptr, *dT = nullptr, *dJreg = nullptr;
+  TRY_OR_FREE(upload(&dP, P, (size_t)V * 3 * NP));
+  TRY_OR_FREE(upload(&dS, S, (size_t)V * 3 * NB));
+  TRY_OR_FREE(upload(&dT, vt, (size_t)V * 3));
+  TRY_OR_FREE(upload(&dJreg, Jreg, (size_t)NJ * V));
+  TRY_OR_FREE(hipMalloc((void **)&m->Bm, sizeof(float) * (size_t)KP * m->ldB));
+  TRY_OR_FREE(hipMalloc((void **)&m->J0, sizeof(float) * NJ * 3));
+  TRY_OR_FREE(hipMalloc((void **)&m->JS, sizeof(float) * NJ * 3 * NB));
+  relayout_basis_kernel<<<dim3((unsigned)((m->ldB + 255) / 256)), dim3(256)>>>(dP, dS, dT, m->Bm, V, m->ldB);
+  fold_regressor_kernel<<<dim3(NJ * 3 * (NB + 1)), dim3(256)>>>(dJreg, dS, dT, m->J0, m->JS, V);
+  TRY_OR_FREE(hipGetLastError());
+  TRY_OR_FREE(hipDeviceSynchronize());
+  (void)hipFree(dP);
+  (void)hipFree(dS);
+  (void)hipFree(dT);
+  (void)hipFree(dJreg);
+
+  // --- skinning weights: keep the non-zeros (real SMPL has <= 4 per vertex), dense fallback otherwise ---
+  int maxnz = 0;
+  for(int64_t v = 0; v < V; v++)
+  {
+    int nz = 0;
+    for(int j = 0; j < NJ; j++) nz += (W[v * NJ + j] != 0.0f);
+    maxnz = std::max(maxnz, nz);
+  }
+  m->maxw = maxnz <= 4 ? 4 : (maxnz <= 8 ? 8 : NJ);
+  const int64_t Vpad = m->VGn * VG;
+  std::vector<uint8_t> hIdx((size_t)Vpad * m->maxw, 0);
+  std::vector<float> hVal((size_t)Vpad * m->maxw, 0.0f), hSum((size_t)Vpad, 1.0f);
+  for(int64_t v = 0; v < V; v++)
+  {
+    int q = 0;
+    float s = 0.0f;
+    for(int j = 0; j < NJ; j++)
+    {
+      float w = W[v * NJ + j];
+      s += w; // ascending j, fp32: h[3] = sum_j W[v,j] * 1 (src/LinearBlendSkinning.cpp:463-467)
+      if(m->maxw == NJ)
+      {
+        hIdx[v * NJ + j] = (uint8_t)j;
+        hVal[v * NJ + j] = w;
+      }
+      else if(w != 0.0f)
+      {
+        hIdx[v * m->maxw + q] = (uint8_t)j;
+        hVal[v * m->maxw + q] = w;
+        q++;
+      }
+    }
+    hSum[v] = s;
+  }
+  TRY_OR_FREE(upload(&m->wIdx, hIdx.data(), hIdx.size()));
+  TRY_OR_FREE(upload(&m->wVal, hVal.data(), hVal.size()));
+  TRY_OR_FREE(upload(&m->wSum, hSum.data(), hSum.size()));
+  TRY_OR_FREE(upload(&m->Wdense, W, (size_t)V * NJ));
+  TRY_OR_FREE(upload(&m->parent, parent.data(), parent.size()));
+
+  // --- faces + adjacency (src/SMPL.cpp:620-640; emplace keeps one entry per (vertex, face)) ---
+  m->h_faces.resize((size_t)F * 3);
+  for(int64_t i = 0; i < F * 3; i++) m->h_faces[i] = faces1[i] - 1;
+  std::vector<std::vector<int32_t>> adj((size_t)V);
+  for(int64_t f = 0; f < F; f++)
+    for(int i = 0; i < 3; i++)
+    {
+      auto & a = adj[m->h_faces[f * 3 + i]];
+      if(a.empty() || a.back() != (int32_t)f) a.push_back((int32_t)f);
+    }
+  m->h_adjOff.assign((size_t)V + 1, 0);
+  for(int64_t v = 0; v < V; v++) m->h_adjOff[v + 1] = m->h_adjOff[v] + (int32_t)adj[v].size();
+  m->h_adjFace.reserve((size_t)m->h_adjOff[V]);
+  for(int64_t v = 0; v < V; v++) m->h_adjFace.insert(m->h_adjFace.end(), adj[v].begin(), adj[v].end());
+  TRY_OR_FREE(upload(&m->faces, m->h_faces.data(), m->h_faces.size()));
+  TRY_OR_FREE(upload(&m->adjOff, m->h_adjOff.data(), m->h_adjOff.size()));
+  TRY_OR_FREE(upload(&m->adjFace, m->h_adjFace.data(), m->h_adjFace.size()));
+#undef TRY_OR_FREE
+  *out = m;
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_model_info(const smplpp_model * m, int64_t * V, int64_t * F, int * wpv, int * device)
+{
+  if(!m) return fail(SMPLPP_ERR_INVALID, "smplpp_model_info: null model");
+  if(V) *V = m->V;
+  if(F) *F = m->F;
+  if(wpv) *wpv = m->maxw;
+  if(device) *device = m->device;
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_adjacent_faces(const smplpp_model * m, int64_t vertex, int64_t cap, int64_t * faces, float * weights,
+                                     int64_t * count)
+{
+  if(!m || !count) return fail(SMPLPP_ERR_INVALID, "smplpp_adjacent_faces: null argument");
+  if(vertex < 0 || vertex >= m->V) return fail(SMPLPP_ERR_INVALID, "smplpp_adjacent_faces: vertex out of range");
+  int32_t b = m->h_adjOff[vertex], e = m->h_adjOff[vertex + 1];
+  *count = e - b;
+  float sum = 0.0f;
+  for(int32_t q = b; q < e; q++) sum += 1.0f;
+  for(int32_t q = b; q < e && q - b < cap; q++)
+  {
+    if(faces) faces[q - b] = m->h_adjFace[q];
+    if(weights) weights[q - b] = 1.0f / sum; // uniform 1/deg (src/SMPL.cpp:630-639)
+  }
+  return SMPLPP_OK;
+}

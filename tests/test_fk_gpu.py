@@ -1,0 +1,179 @@
+"""GPU parity of the FK path (SMPL::launch) through the C ABI: against the reference's golden vectors, the
+Tester.cpp KATs, and the C oracle on seeded inputs.  Tolerance: 1e-5 m on vertices (BASELINE.json north_star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+VERT_TOL = 1e-5  # metres
+
+
+@pytest.fixture(scope="module")
+def smpl(synth_model):
+    from smplpp_amd.smpl import SMPL
+
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(synth_model)
+    return s
+
+
+@pytest.fixture(scope="module")
+def kats():
+    with open(os.path.join(GOLDEN, "tester_kats.json")) as f:
+        return json.load(f)
+
+
+def test_native_library_loaded():
+    from smplpp_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH)
+    assert _lib.require_gpu() >= 1
+
+
+def test_model_info(smpl):
+    info = smpl.info()
+    assert info["vertex_num"] == 6890 and info["face_num"] == 13776 and info["weights_per_vertex"] == 4
+
+
+def test_fk_golden_reference_vectors(smpl, golden_fk_synth):
+    """Outputs of the reference's own compiled stages (oracle/_ref) on the synthetic model."""
+    g = golden_fk_synth
+    o = smpl.launch(g["beta"], g["theta"])
+    ids = g["vertex_ids"]
+    assert np.abs(o["verts"][:, ids] - g["verts"]).max() < VERT_TOL
+    assert np.abs(o["rest"][:, ids] - g["rest"]).max() < VERT_TOL
+    assert np.abs(o["joints"] - g["joints"]).max() < VERT_TOL
+    assert np.abs(o["xforms"] - g["xforms"]).max() < VERT_TOL
+    np.testing.assert_allclose(o["verts"].astype(np.float64).sum(axis=1), g["verts_sum"], atol=5e-3)
+    np.testing.assert_allclose(np.abs(o["verts"].astype(np.float64)).sum(axis=1), g["verts_abs_sum"], rtol=2e-6)
+
+
+def test_fk_zero_pose_is_template(smpl, synth_model):
+    """BASELINE config 1."""
+    o = smpl.launch(np.zeros((1, 10), np.float32), np.zeros((1, 25, 3), np.float32))
+    assert np.abs(o["verts"][0] - synth_model["vertices_template"]).max() < 1e-6
+    assert np.abs(o["xforms"][0] - np.tile(np.eye(4, dtype=np.float32), (24, 1, 1))).max() < 1e-6
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 70, 257])
+def test_fk_vs_oracle_ragged_batches(smpl, oracle_synth, n):
+    from smplpp_amd import model_io
+
+    beta, theta = model_io.synthetic_inputs(n, seed=100 + n)
+    o = smpl.launch(beta, theta)
+    r = oracle_synth.fk(beta, theta)
+    for k in ("verts", "rest", "joints", "xforms"):
+        assert np.abs(o[k] - r[k]).max() < VERT_TOL, k
+
+
+def test_fk_batch1024_properties_and_sample(smpl, oracle_synth):
+    """BASELINE config 2 (batch 1024): sampled frames against the oracle; frames are independent (a frame's result
+    does not depend on its batch position or neighbours); translation enters additively."""
+    from smplpp_amd import model_io
+
+    beta, theta = model_io.synthetic_inputs(1024, seed=1)
+    o = smpl.launch(beta, theta, want=("verts",))["verts"].copy()
+    sel = np.array([0, 1, 63, 64, 511, 512, 1000, 1023])
+    r = oracle_synth.fk(beta[sel], theta[sel], want=("verts",))["verts"]
+    assert np.abs(o[sel] - r).max() < VERT_TOL
+    perm = np.random.default_rng(0).permutation(1024)
+    o2 = smpl.launch(beta[perm], theta[perm], want=("verts",))["verts"]
+    assert np.abs(o2 - o[perm]).max() < 1e-6
+    theta_t = theta.copy()
+    theta_t[:, 0, :] += np.float32(0.5)
+    o3 = smpl.launch(beta, theta_t, want=("verts",))["verts"]
+    assert np.abs((o3 - o) - np.float32(0.5)).max() < 1e-5
+    assert np.isfinite(o).all()
+
+
+def test_fk_dense_weights_and_ragged_vertex_count():
+    """61-vertex model with all 24 skinning weights non-zero (dense path) — golden from the reference build."""
+    from smplpp_amd import model_io
+    from smplpp_amd.smpl import SMPL
+
+    g = np.load(os.path.join(GOLDEN, "fk_tiny.npz"))
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(model_io.tiny_model(61, seed=7))
+    assert s.info()["weights_per_vertex"] == 24
+    o = s.launch(g["beta"], g["theta"])
+    for k in ("verts", "rest", "joints", "xforms"):
+        assert np.abs(o[k] - g[k]).max() < VERT_TOL, k
+
+
+def test_fk_device_pointers_torch(smpl, oracle_synth):
+    import torch
+    from smplpp_amd import model_io
+
+    beta, theta = model_io.synthetic_inputs(96, seed=5)
+    o = smpl.launch(torch.from_numpy(beta).cuda(), torch.from_numpy(theta).cuda())
+    torch.cuda.synchronize()
+    r = oracle_synth.fk(beta, theta)
+    assert o["verts"].is_cuda
+    assert np.abs(o["verts"].cpu().numpy() - r["verts"]).max() < VERT_TOL
+    assert np.abs(o["joints"].cpu().numpy() - r["joints"]).max() < VERT_TOL
+
+
+def test_stage_kats_on_gpu(kats):
+    """The reference's own stage KATs (src/toolbox/Tester.cpp) through the stage-level entry points."""
+    from smplpp_amd import smpl as S
+
+    i, e = kats["blendShape"]["inputs"], kats["blendShape"]["expected"]
+    bs, bp, rot = S.stage_blend_shape(i["beta"], i["theta"], np.array(i["shapeBlendBasis"]), np.array(i["poseBlendBasis"]))
+    np.testing.assert_allclose(bs.reshape(1, 3), np.array(e["shapeBlendShape"]), atol=2e-6)
+    np.testing.assert_allclose(bp.reshape(1, 1, 3), np.array(e["poseBlendShape"]), atol=6e-6)
+    np.testing.assert_allclose(rot[0, :5], np.array(e["poseRotation"]), atol=2e-6)
+    i, e = kats["jointRegression"]["inputs"], kats["jointRegression"]["expected"]
+    rest, joints = S.stage_joint_regression(i["templateShape"], i["jointRegressor"], i["shapeBlendShape"], i["poseBlendShape"])
+    np.testing.assert_allclose(rest, np.array(e["restShape"]), atol=2e-6)
+    np.testing.assert_allclose(joints[0], np.array(e["joints"]), atol=4e-6)
+    i, e = kats["worldTransformation"]["inputs"], kats["worldTransformation"]["expected"]
+    out = S.stage_world_transformation(np.array(i["kineTree"]), i["joints"], i["poseRotation"])
+    np.testing.assert_allclose(out[0, :5], np.array(e["transformations"]), atol=6e-6)
+    i, e = kats["linearBlendSkinning"]["inputs"], kats["linearBlendSkinning"]["expected"]
+    out = S.stage_skinning(np.array(i["weights"]), np.array(i["restShape"]), np.array(i["transformations"]), None)
+    np.testing.assert_allclose(out, np.array(e["vertices"]), atol=2e-6)
+
+
+def test_mesh_queries_vs_oracle(smpl, oracle_synth, synth_model):
+    from smplpp_amd import model_io
+
+    beta, theta = model_io.synthetic_inputs(3, seed=9)
+    o = smpl.launch(beta, theta)
+    verts = o["verts"]
+    fids = np.array([0, 100, 5000, 13775])
+    vids = np.array([0, 17, 3000, 6889])
+    fn = smpl.calcNormalBatch(fids)
+    vn = smpl.calcVertexNormalBatch(vids)
+    for f in range(3):
+        for a, fid in enumerate(fids):
+            assert np.abs(fn[f, a] - oracle_synth.face_normal(verts[f], int(fid))).max() < 2e-5
+        for a, vid in enumerate(vids):
+            assert np.abs(vn[f, a] - oracle_synth.vertex_normal(verts[f], int(vid))).max() < 2e-5
+    assert np.abs(smpl.calcNormal(100) - fn[0, 1]).max() == 0
+    rng = np.random.default_rng(3)
+    pts = verts[:, rng.integers(0, 6890, 7)] + rng.normal(0, 0.01, (3, 7, 3)).astype(np.float32)
+    face, closest, sq = smpl.closestPoints(pts)
+    for f in range(3):
+        rf, rc, rs = oracle_synth.closest_points(verts[f], pts[f])
+        assert np.abs(closest[f] - rc).max() < 1e-6
+        assert np.abs(sq[f] - rs).max() < 1e-7
+        assert (face[f] == rf).all()
+    adj = smpl.getAdjacentFaces(17)
+    of, ow = oracle_synth.get_adjacency(17)
+    assert sorted(adj) == sorted(of.tolist()) and abs(sum(adj.values()) - 1) < 1e-6
+
+
+def test_errors_are_loud(smpl):
+    from smplpp_amd._lib import SmplppError
+
+    with pytest.raises(SmplppError):
+        smpl.launch(np.zeros((2, 9), np.float32), np.zeros((2, 25, 3), np.float32))
+    with pytest.raises(SmplppError):
+        smpl.launch(np.zeros((2, 10), np.float32), np.zeros((2, 24, 3), np.float32))
