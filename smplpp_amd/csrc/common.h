@@ -98,6 +98,8 @@ struct smplpp_model
   int32_t * adjOff = nullptr;  // [V+1]
   int32_t * adjFace = nullptr; // [adjOff[V]] ascending face id per vertex
   float * Wdense = nullptr;    // [V][24] original weights (stage entry points / IK)
+  float * Pvm = nullptr;       // [V][3][207] posedirs, vertex-major (IK Jacobian: pose-corrective term of a few vertices)
+  float * Svm = nullptr;       // [V][3][10]  shapedirs, vertex-major (IK Jacobian: beta columns)
   // host mirrors
   std::vector<int32_t> h_parent, h_faces, h_adjOff, h_adjFace;
   smplpp_hip::Workspace ws;

@@ -1,0 +1,1295 @@
+// The IK loop of the reference (node/node.cpp:645-1002) for a batch of independent frames, one workgroup per frame.
+//
+//  ik_eval_kernel    node.cpp:798-877.  The reference gets each Jacobian row by a full reverse-mode autograd pass
+//                    through the 6890-vertex FK graph (3-4 passes per task); here the same derivative is the analytic
+//                    forward-mode Jacobian of only the vertices the tasks touch: per frame the chain
+//                    derivatives dG'_i/dtheta_{j,k} of all 72 rotation columns are built once in LDS (83 KB), then every
+//                    task reads them for its face vertices (and their 1-rings when a normal is involved).
+//  ik_solve_kernel   node.cpp:883-968: A = J^T J + damping in fp64, Cholesky (packed lower-triangular in LDS, fp64) or
+//                    the box QP by a primal active set, config update, query points for the re-projection.
+//  ik_project_kernel node.cpp:970-1001: closest point on the posed mesh (brute force over 13776 faces, one workgroup
+//                    per query), new face id and area-ratio weights.
+// All fp32 where the reference is fp32 (FK, task geometry, autograd gradients), fp64 where it is fp64 (Eigen).
+#include "mesh_device.h"
+#include "staging.h"
+
+#include <algorithm>
+
+struct smplpp_vposer;
+
+namespace smplpp_hip
+{
+int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
+              float * xforms44, float * rest, float * poserot, hipStream_t st);
+int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
+                          float * jac, hipStream_t st);
+
+constexpr int TD75 = SMPLPP_THETA_DIM;        // 75
+constexpr int TD44 = SMPLPP_LATENT_POSE_DIM;  // 44
+constexpr int NQ = TD75 + NB;                 // differentiation columns handled per frame: theta(75) | beta(10)
+constexpr int MAXADJ = 12;                    // adjacent faces per vertex supported by the normal Jacobian
+constexpr int MAXRING = 3 * (MAXADJ + 1) + 1; // distinct vertices a task can touch
+constexpr int MAXD = 170;                     // unknowns per frame supported by the in-LDS solver
+
+struct TaskArrays
+{
+  int32_t * face;  // [n,K]
+  float * vw;      // [n,K,3]
+  float * tang;    // [n,K,3,2]
+  float * tpos;    // [n,K,3]
+  float * tnrm;    // [n,K,3]
+  float * posw;    // [n,K]
+  float * nrmw;    // [n,K]
+  float * philim;  // [n,K]
+  float * noff;    // [n,K]
+  float * apos;    // [n,K,3]
+  float * anrm;    // [n,K,3]
+};
+
+struct ModelView
+{
+  const int32_t * faces;
+  const int32_t * adjOff;
+  const int32_t * adjFace;
+  const int32_t * parent;
+  const uint8_t * wIdx;
+  const float * wVal;
+  const float * wSum;
+  const float * Pvm;
+  const float * Svm;
+  const float * JS;
+  int64_t V;
+  int maxw;
+};
+
+// ------------------------------------------------------------------------------------------------ eval kernel
+// derivative of Rodrigues (src/BlendShape.cpp:813-841) wrt theta_m, including the ||theta + eps|| angle
+__device__ inline void rodrigues_grad_dev(const float * th, int m, float * dR)
+{
+  const float eps = 1e-8f;
+  const float ae0 = th[0] + eps, ae1 = th[1] + eps, ae2 = th[2] + eps;
+  const float a = sqrtf(ae0 * ae0 + ae1 * ae1 + ae2 * ae2);
+  const float s = sinf(a), c = cosf(a);
+  const float k[3] = {th[0] / a, th[1] / a, th[2] / a};
+  const float K[9] = {0.f, -k[2], k[1], k[2], 0.f, -k[0], -k[1], k[0], 0.f};
+  const float aem = (m == 0) ? ae0 : (m == 1 ? ae1 : ae2);
+  const float da = aem / a;
+  float dk[3];
+  for(int x = 0; x < 3; x++) dk[x] = ((x == m) ? 1.0f : 0.0f) / a - th[x] * da / (a * a);
+  const float dK[9] = {0.f, -dk[2], dk[1], dk[2], 0.f, -dk[0], -dk[1], dk[0], 0.f};
+  for(int r = 0; r < 3; r++)
+    for(int cc = 0; cc < 3; cc++)
+    {
+      float kk = 0.f, d1 = 0.f, d2 = 0.f;
+      for(int q = 0; q < 3; q++)
+      {
+        kk += K[r * 3 + q] * K[q * 3 + cc];
+        d1 += dK[r * 3 + q] * K[q * 3 + cc];
+        d2 += K[r * 3 + q] * dK[q * 3 + cc];
+      }
+      dR[r * 3 + cc] = dK[r * 3 + cc] * s + K[r * 3 + cc] * c * da + (d1 + d2) * (1.0f - c) + kk * s * da;
+    }
+}
+
+// d normalize(x) = (dx - n (n . dx)) / max(||x||, 1e-12)
+__device__ inline void dnormalize_dev(const float * x, const float * dx, float * dn)
+{
+  float nrm = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  nrm = fmaxf(nrm, 1e-12f);
+  const float n0 = x[0] / nrm, n1 = x[1] / nrm, n2 = x[2] / nrm;
+  const float d = n0 * dx[0] + n1 * dx[1] + n2 * dx[2];
+  dn[0] = (dx[0] - n0 * d) / nrm;
+  dn[1] = (dx[1] - n1 * d) / nrm;
+  dn[2] = (dx[2] - n2 * d) / nrm;
+}
+
+__device__ inline void actual_normal_dev(const ModelView & mv, const float * verts, int face, const float * w, float * nn)
+{
+  float acc[3] = {0.f, 0.f, 0.f};
+  for(int i = 0; i < 3; i++) // src/IkTask.cpp:78-84
+  {
+    float vn[3];
+    vertex_normal_dev(verts, mv.faces, mv.adjOff, mv.adjFace, mv.faces[face * 3 + i], vn);
+    acc[0] += w[i] * vn[0];
+    acc[1] += w[i] * vn[1];
+    acc[2] += w[i] * vn[2];
+  }
+  normalize3(acc);
+  nn[0] = acc[0];
+  nn[1] = acc[1];
+  nn[2] = acc[2];
+}
+
+__device__ inline void actual_pos_dev(const ModelView & mv, const float * verts, int face, const float * w, float off, float * p)
+{
+  for(int x = 0; x < 3; x++) // src/IkTask.cpp:64
+  {
+    float s = 0.f;
+    for(int i = 0; i < 3; i++) s += verts[3 * mv.faces[face * 3 + i] + x] * w[i];
+    p[x] = s;
+  }
+  if(off > 0.0f) // :66-69
+  {
+    float nn[3];
+    actual_normal_dev(mv, verts, face, w, nn);
+    p[0] += off * nn[0];
+    p[1] += off * nn[1];
+    p[2] += off * nn[2];
+  }
+}
+
+// LDS carve-up (floats) of ik_eval_kernel
+constexpr int L_R = 0;                         // [24][9]
+constexpr int L_J = L_R + NJ * 9;              // [24][3]
+constexpr int L_G = L_J + NJ * 3;              // [24][12]  relative transforms [A | b]
+constexpr int L_T = L_G + NJ * 12;             // [24][3]   local translations j_i - j_p(i)
+constexpr int L_DR = L_T + NJ * 3;             // [72][9]
+constexpr int L_DAB = L_DR + 72 * 9;           // [24*12][72]  (joint, entry) major, column fastest
+constexpr int L_DBB = L_DAB + NJ * 12 * 72;    // [24*3][10]
+constexpr int L_RV = L_DBB + NJ * 3 * NB;      // [MAXRING][16]  rest(3) Ablend(9) wsum(1)
+constexpr int L_DP = L_RV + MAXRING * 16;      // [MAXRING][3][NQ]
+constexpr int L_VN = L_DP + MAXRING * 3 * NQ;  // [3][3] vertex normals + [3] their weighted sum
+constexpr int L_END = L_VN + 12;
+constexpr int L_ANC_BYTES = NJ * 4;            // int anc[24] after the float region
+
+__global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ theta25,
+                                                      const float * __restrict__ verts_all, const float * __restrict__ rest_all,
+                                                      const float * __restrict__ Gp, const float * __restrict__ joints,
+                                                      const float * __restrict__ poserot, int K, int optimize_beta,
+                                                      int phi_live, int min_valid, int32_t * __restrict__ ring_buf,
+                                                      uint8_t * __restrict__ map_buf, float * __restrict__ pos804,
+                                                      double * __restrict__ e_out, double * __restrict__ J_out,
+                                                      int * __restrict__ skip)
+{
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int * sAnc = reinterpret_cast<int *>(lds + L_END);
+  const int64_t f = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int nq = TD75 + (optimize_beta ? NB : 0);
+  const int D = TD75 + 2 * K + (optimize_beta ? NB : 0);
+  const float * verts = verts_all + f * mv.V * 3;
+  const float * rest = rest_all + f * mv.V * 3;
+  const int64_t tb = f * K; // task base
+
+  // node.cpp:785 — a frame with too few valid markers skips the whole solve block (no task refresh either)
+  {
+    __shared__ int s_valid;
+    if(tid == 0) s_valid = 0;
+    __syncthreads();
+    if(tid < K && ta.posw[tb + tid] > 0.0f) atomicAdd(&s_valid, 1);
+    __syncthreads();
+    const int sk = (s_valid < min_valid) ? 1 : 0;
+    if(tid == 0) skip[f] = sk;
+    if(sk) return;
+  }
+
+  // ---- frame constants into LDS
+  for(int i = tid; i < NJ * 9; i += 256) lds[L_R + i] = poserot[f * NJ * 9 + i];
+  for(int i = tid; i < NJ * 3; i += 256) lds[L_J + i] = joints[f * NJ * 3 + i];
+  for(int i = tid; i < NJ * 12; i += 256) lds[L_G + i] = Gp[f * NJ * 12 + i];
+  if(tid == 0)
+    for(int i = 0; i < NJ; i++) sAnc[i] = (1 << i) | (i ? sAnc[mv.parent[i]] : 0);
+  __syncthreads();
+  for(int i = tid; i < NJ * 3; i += 256)
+  {
+    const int j = i / 3, x = i % 3, p = mv.parent[j];
+    lds[L_T + i] = (j == 0) ? lds[L_J + x] : lds[L_J + i] - lds[L_J + p * 3 + x];
+  }
+  if(tid < 72)
+  {
+    float dR[9];
+    rodrigues_grad_dev(theta25 + (f * (NJ + 1) + 1 + tid / 3) * 3, tid % 3, dR);
+    for(int q = 0; q < 9; q++) lds[L_DR + tid * 9 + q] = dR[q];
+  }
+  __syncthreads();
+
+  // ---- chain derivatives: thread c = rotation column (joint c/3, component c%3)
+  if(tid < 72)
+  {
+    const int c = tid, jc = c / 3;
+    for(int i = 0; i < NJ; i++)
+    {
+      float dA[9], dg[3] = {0.f, 0.f, 0.f};
+      const int p = mv.parent[i];
+      if(!((sAnc[i] >> jc) & 1))
+      {
+        for(int q = 0; q < 9; q++) dA[q] = 0.f;
+      }
+      else if(i == jc)
+      {
+        const float * dR = lds + L_DR + c * 9;
+        if(i == 0)
+          for(int q = 0; q < 9; q++) dA[q] = dR[q];
+        else
+        {
+          const float * Ap = lds + L_G + p * 12;
+          for(int r = 0; r < 3; r++)
+            for(int cc = 0; cc < 3; cc++)
+              dA[r * 3 + cc] = Ap[r * 4 + 0] * dR[cc] + Ap[r * 4 + 1] * dR[3 + cc] + Ap[r * 4 + 2] * dR[6 + cc];
+        }
+      }
+      else
+      {
+        // parent's dA and dg (dg_p = db_p + dA_p . j_p)
+        float dAp[9], dgp[3];
+        for(int q = 0; q < 9; q++) dAp[q] = lds[L_DAB + (p * 12 + (q / 3) * 4 + q % 3) * 72 + c];
+        for(int r = 0; r < 3; r++)
+          dgp[r] = lds[L_DAB + (p * 12 + r * 4 + 3) * 72 + c]
+                   + (dAp[r * 3] * lds[L_J + p * 3] + dAp[r * 3 + 1] * lds[L_J + p * 3 + 1] + dAp[r * 3 + 2] * lds[L_J + p * 3 + 2]);
+        const float * Ri = lds + L_R + i * 9;
+        const float * ti = lds + L_T + i * 3;
+        for(int r = 0; r < 3; r++)
+        {
+          for(int cc = 0; cc < 3; cc++) dA[r * 3 + cc] = dAp[r * 3] * Ri[cc] + dAp[r * 3 + 1] * Ri[3 + cc] + dAp[r * 3 + 2] * Ri[6 + cc];
+          dg[r] = (dAp[r * 3] * ti[0] + dAp[r * 3 + 1] * ti[1] + dAp[r * 3 + 2] * ti[2]) + dgp[r];
+        }
+      }
+      for(int r = 0; r < 3; r++)
+      {
+        for(int cc = 0; cc < 3; cc++) lds[L_DAB + (i * 12 + r * 4 + cc) * 72 + c] = dA[r * 3 + cc];
+        lds[L_DAB + (i * 12 + r * 4 + 3) * 72 + c] =
+            dg[r] - (dA[r * 3] * lds[L_J + i * 3] + dA[r * 3 + 1] * lds[L_J + i * 3 + 1] + dA[r * 3 + 2] * lds[L_J + i * 3 + 2]);
+      }
+    }
+  }
+  else if(tid < 72 + NB && optimize_beta) // beta columns: joints move, rotations do not
+  {
+    const int k = tid - 72;
+    float dgl[NJ][3];
+    for(int i = 0; i < NJ; i++)
+    {
+      const int p = mv.parent[i];
+      float dj[3], dt[3];
+      for(int x = 0; x < 3; x++)
+      {
+        dj[x] = mv.JS[(i * 3 + x) * NB + k];
+        dt[x] = (i == 0) ? dj[x] : dj[x] - mv.JS[(p * 3 + x) * NB + k];
+      }
+      if(i == 0)
+        for(int x = 0; x < 3; x++) dgl[0][x] = dt[x];
+      else
+      {
+        const float * Ap = lds + L_G + p * 12;
+        for(int r = 0; r < 3; r++) dgl[i][r] = (Ap[r * 4] * dt[0] + Ap[r * 4 + 1] * dt[1] + Ap[r * 4 + 2] * dt[2]) + dgl[p][r];
+      }
+      const float * Ai = lds + L_G + i * 12;
+      for(int r = 0; r < 3; r++)
+        lds[L_DBB + (i * 3 + r) * NB + k] = dgl[i][r] - (Ai[r * 4] * dj[0] + Ai[r * 4 + 1] * dj[1] + Ai[r * 4 + 2] * dj[2]);
+    }
+  }
+
+  // ---- phase A: one thread per task — tangents, weight refresh, residual rows, ring list (node.cpp:803-820)
+  if(tid < K)
+  {
+    const int k = tid;
+    const int face = ta.face[tb + k];
+    float tri[9];
+    for(int i = 0; i < 3; i++)
+      for(int x = 0; x < 3; x++) tri[i * 3 + x] = verts[3 * mv.faces[face * 3 + i] + x];
+    const float off = ta.noff[tb + k], wp = ta.posw[tb + k], wn = ta.nrmw[tb + k];
+    const bool use_normal = (off > 0.0f) || (wn > 0.0f);
+    // calcTangents (src/IkTask.cpp:33-47)
+    {
+      float t1[3] = {tri[3] - tri[0], tri[4] - tri[1], tri[5] - tri[2]};
+      float e2[3] = {tri[6] - tri[0], tri[7] - tri[1], tri[8] - tri[2]};
+      float nn[3], t2[3];
+      cross3(t1, e2, nn);
+      cross3(nn, t1, t2);
+      normalize3(t1);
+      normalize3(t2);
+      for(int x = 0; x < 3; x++)
+      {
+        ta.tang[(tb + k) * 6 + x * 2 + 0] = t1[x];
+        ta.tang[(tb + k) * 6 + x * 2 + 1] = t2[x];
+      }
+    }
+    float w[3] = {ta.vw[(tb + k) * 3], ta.vw[(tb + k) * 3 + 1], ta.vw[(tb + k) * 3 + 2]};
+    float pos[3];
+    actual_pos_dev(mv, verts, face, w, off, pos);
+    for(int x = 0; x < 3; x++) pos804[(tb + k) * 3 + x] = pos[x]; // the point calcVertexWeights is differentiated at
+    triangle_weights_dev(pos, tri, w); // calcVertexWeights with phi_ == 0 (src/IkTask.cpp:49-57, node.cpp:804)
+    for(int i = 0; i < 3; i++) ta.vw[(tb + k) * 3 + i] = w[i];
+    float ap[3], an[3] = {0.f, 0.f, 0.f};
+    actual_pos_dev(mv, verts, face, w, off, ap);
+    actual_normal_dev(mv, verts, face, w, an);
+    for(int x = 0; x < 3; x++)
+    {
+      ta.apos[(tb + k) * 3 + x] = ap[x];
+      ta.anrm[(tb + k) * 3 + x] = an[x];
+      e_out[(f * K + k) * 4 + x] = (double)(wp * (ap[x] - ta.tpos[(tb + k) * 3 + x])); // node.cpp:807
+    }
+    if(wn > 0.0f)
+    {
+      const float dt = (an[0] * ta.tnrm[(tb + k) * 3] + an[1] * ta.tnrm[(tb + k) * 3 + 1]) + an[2] * ta.tnrm[(tb + k) * 3 + 2];
+      e_out[(f * K + k) * 4 + 3] = (double)(wn * (dt + 1.0f)); // :813-814
+    }
+    else
+      e_out[(f * K + k) * 4 + 3] = 0.0; // :819
+    // ring: distinct vertices of the face and (when a normal is differentiated) of the faces around its vertices
+    int32_t * ring = ring_buf + (f * K + k) * (MAXRING + 1);
+    uint8_t * map = map_buf + (f * K + k) * (3 * MAXADJ * 3);
+    int nr = 0;
+    for(int i = 0; i < 3; i++) ring[1 + nr++] = mv.faces[face * 3 + i]; // slots 0..2 = the face's own vertices
+    if(use_normal)
+      for(int i = 0; i < 3; i++)
+      {
+        const int u = mv.faces[face * 3 + i];
+        const int b = mv.adjOff[u];
+        int cnt = mv.adjOff[u + 1] - b;
+        if(cnt > MAXADJ) cnt = MAXADJ;
+        for(int a = 0; a < cnt; a++)
+          for(int cc = 0; cc < 3; cc++)
+          {
+            const int v = mv.faces[mv.adjFace[b + a] * 3 + cc];
+            int slot = -1;
+            for(int q = 0; q < nr; q++)
+              if(ring[1 + q] == v) slot = q;
+            if(slot < 0 && nr < MAXRING)
+            {
+              slot = nr;
+              ring[1 + nr++] = v;
+            }
+            map[(i * MAXADJ + a) * 3 + cc] = (uint8_t)(slot < 0 ? 0 : slot);
+          }
+      }
+    ring[0] = nr;
+  }
+  __syncthreads();
+  __threadfence_block();
+
+  // ---- phase B: Jacobian rows, tasks in sequence, columns/vertices across the workgroup (node.cpp:823-873)
+  for(int k = 0; k < K; k++)
+  {
+    const int face = ta.face[tb + k];
+    const float off = ta.noff[tb + k], wp = ta.posw[tb + k], wn = ta.nrmw[tb + k], plim = ta.philim[tb + k];
+    const bool use_normal = (off > 0.0f) || (wn > 0.0f);
+    const int32_t * ring = ring_buf + (f * K + k) * (MAXRING + 1);
+    const uint8_t * map = map_buf + (f * K + k) * (3 * MAXADJ * 3);
+    const int nr = ring[0];
+    const float w0 = ta.vw[(tb + k) * 3], w1 = ta.vw[(tb + k) * 3 + 1], w2 = ta.vw[(tb + k) * 3 + 2];
+    double * Jk = J_out + ((f * K + k) * 4) * (int64_t)D;
+
+    if(tid < nr) // B1: per ring vertex rest position, blended rotation, blended w
+    {
+      const int v = ring[1 + tid];
+      float * rv = lds + L_RV + tid * 16;
+      rv[0] = rest[v * 3];
+      rv[1] = rest[v * 3 + 1];
+      rv[2] = rest[v * 3 + 2];
+      float Ab[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for(int m = 0; m < mv.maxw; m++)
+      {
+        const float wm = mv.wVal[(int64_t)v * mv.maxw + m];
+        const float * A = lds + L_G + mv.wIdx[(int64_t)v * mv.maxw + m] * 12;
+        for(int r = 0; r < 3; r++)
+          for(int cc = 0; cc < 3; cc++) Ab[r * 3 + cc] += wm * A[r * 4 + cc];
+      }
+      for(int q = 0; q < 9; q++) rv[3 + q] = Ab[q];
+      rv[12] = mv.wSum[v];
+    }
+    __syncthreads();
+    for(int item = tid; item < nr * nq; item += 256) // B2: dp[rv][:, q]  
+    {
+      const int r_ = item / nq, q = item % nq;
+      const int v = ring[1 + r_];
+      const float * rv = lds + L_RV + r_ * 16;
+      float acc[3] = {0.f, 0.f, 0.f};
+      if(q < 3)
+        acc[q] = rv[12]; // root translation: identity (divided by wsum below)
+      else if(q < TD75)
+      {
+        const int c = q - 3, jc = c / 3;
+        for(int m = 0; m < mv.maxw; m++)
+        {
+          const float wm = mv.wVal[(int64_t)v * mv.maxw + m];
+          if(wm == 0.0f) continue;
+          const int i = mv.wIdx[(int64_t)v * mv.maxw + m];
+          const float * d = lds + L_DAB + (i * 12) * 72 + c;
+          for(int r = 0; r < 3; r++)
+            acc[r] += wm * (((d[(r * 4) * 72] * rv[0] + d[(r * 4 + 1) * 72] * rv[1]) + d[(r * 4 + 2) * 72] * rv[2]) + d[(r * 4 + 3) * 72]);
+        }
+        if(jc >= 1) // pose correctives; the root joint has none (src/BlendShape.cpp:884-887)
+        {
+          const float * dR = lds + L_DR + c * 9;
+          float dr[3];
+          for(int x = 0; x < 3; x++)
+          {
+            const float * Pv = mv.Pvm + ((int64_t)v * 3 + x) * NP + 9 * (jc - 1);
+            float s = 0.f;
+            for(int e = 0; e < 9; e++) s += Pv[e] * dR[e];
+            dr[x] = s;
+          }
+          for(int r = 0; r < 3; r++) acc[r] += (rv[3 + r * 3] * dr[0] + rv[3 + r * 3 + 1] * dr[1]) + rv[3 + r * 3 + 2] * dr[2];
+        }
+      }
+      else
+      {
+        const int kb = q - TD75;
+        float ds[3];
+        for(int x = 0; x < 3; x++) ds[x] = mv.Svm[((int64_t)v * 3 + x) * NB + kb];
+        for(int r = 0; r < 3; r++) acc[r] = (rv[3 + r * 3] * ds[0] + rv[3 + r * 3 + 1] * ds[1]) + rv[3 + r * 3 + 2] * ds[2];
+        for(int m = 0; m < mv.maxw; m++)
+        {
+          const float wm = mv.wVal[(int64_t)v * mv.maxw + m];
+          if(wm == 0.0f) continue;
+          const int i = mv.wIdx[(int64_t)v * mv.maxw + m];
+          for(int r = 0; r < 3; r++) acc[r] += wm * lds[L_DBB + (i * 3 + r) * NB + kb];
+        }
+      }
+      for(int r = 0; r < 3; r++) lds[L_DP + (r_ * 3 + r) * NQ + q] = acc[r] / rv[12];
+    }
+    __syncthreads();
+    if(tid < nq) // B3: one thread per differentiation column
+    {
+      const int q = tid;
+      float dn[3] = {0.f, 0.f, 0.f};
+      if(use_normal) // d actualNormal / dq  
+      {
+        float msum[3] = {0.f, 0.f, 0.f}, dm[3] = {0.f, 0.f, 0.f};
+        const float wv[3] = {w0, w1, w2};
+        for(int i = 0; i < 3; i++)
+        {
+          const int u = mv.faces[face * 3 + i];
+          const int b = mv.adjOff[u];
+          int cnt = mv.adjOff[u + 1] - b;
+          float sum = 0.f;
+          for(int a = 0; a < cnt; a++) sum += 1.0f;
+          const float aw = 1.0f / sum;
+          if(cnt > MAXADJ) cnt = MAXADJ;
+          float mu[3] = {0.f, 0.f, 0.f}, dmu[3] = {0.f, 0.f, 0.f};
+          for(int a = 0; a < cnt; a++)
+          {
+            const int fa = mv.adjFace[b + a];
+            const float * p0 = verts + 3 * mv.faces[fa * 3];
+            const float * p1 = verts + 3 * mv.faces[fa * 3 + 1];
+            const float * p2 = verts + 3 * mv.faces[fa * 3 + 2];
+            const float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+            const float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+            float cr[3];
+            cross3(e1, e2, cr);
+            const uint8_t * mp = map + (i * MAXADJ + a) * 3;
+            const float * d0 = lds + L_DP + (mp[0] * 3) * NQ + q;
+            const float * d1 = lds + L_DP + (mp[1] * 3) * NQ + q;
+            const float * d2 = lds + L_DP + (mp[2] * 3) * NQ + q;
+            const float de1[3] = {d1[0] - d0[0], d1[NQ] - d0[NQ], d1[2 * NQ] - d0[2 * NQ]};
+            const float de2[3] = {d2[0] - d0[0], d2[NQ] - d0[NQ], d2[2 * NQ] - d0[2 * NQ]};
+            float t1[3], t2[3], dnf[3];
+            cross3(de1, e2, t1);
+            cross3(e1, de2, t2);
+            const float dc[3] = {t1[0] + t2[0], t1[1] + t2[1], t1[2] + t2[2]};
+            dnormalize_dev(cr, dc, dnf);
+            float cn = fmaxf(sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]), 1e-12f);
+            for(int x = 0; x < 3; x++)
+            {
+              mu[x] += aw * (cr[x] / cn);
+              dmu[x] += aw * dnf[x];
+            }
+          }
+          float dvn[3];
+          dnormalize_dev(mu, dmu, dvn);
+          const float mn = fmaxf(sqrtf(mu[0] * mu[0] + mu[1] * mu[1] + mu[2] * mu[2]), 1e-12f);
+          for(int x = 0; x < 3; x++)
+          {
+            const float vnx = mu[x] / mn;
+            msum[x] += wv[i] * vnx;
+            dm[x] += wv[i] * dvn[x];
+            if(q == 0) lds[L_VN + i * 3 + x] = vnx;
+          }
+        }
+        dnormalize_dev(msum, dm, dn);
+        if(q == 0)
+          for(int x = 0; x < 3; x++) lds[L_VN + 9 + x] = msum[x];
+      }
+      const int jcol = (q < TD75) ? q : TD75 + 2 * K + (q - TD75);
+      float nd = 0.f;
+      for(int x = 0; x < 3; x++)
+      {
+        float dpos = (w0 * lds[L_DP + (0 * 3 + x) * NQ + q] + w1 * lds[L_DP + (1 * 3 + x) * NQ + q]) + w2 * lds[L_DP + (2 * 3 + x) * NQ + q];
+        if(off > 0.0f) dpos += off * dn[x];
+        Jk[(int64_t)x * D + jcol] = (double)(wp * dpos);
+        nd += dn[x] * ta.tnrm[(tb + k) * 3 + x];
+      }
+      Jk[(int64_t)3 * D + jcol] = (wn > 0.0f) ? (double)(wn * nd) : 0.0;
+    }
+    // phi columns of every task are zero except this task's own two (node.cpp:792, :834-839)
+    for(int c = tid; c < 2 * K; c += 256)
+      if(c / 2 != k || !(phi_live && plim > 0.0f))
+        for(int r = 0; r < 4; r++) Jk[(int64_t)r * D + TD75 + c] = 0.0;
+    if(!optimize_beta)
+    {
+      // nothing: D has no beta columns
+    }
+    __syncthreads();
+    if(tid < 2 && phi_live && plim > 0.0f) // B4: d/dphi through calcTriangleVertexWeights (vertices detached)
+    {
+      const int c = tid;
+      float tri[9];
+      for(int i = 0; i < 3; i++)
+        for(int x = 0; x < 3; x++) tri[i * 3 + x] = verts[3 * mv.faces[face * 3 + i] + x];
+      // the point calcVertexWeights was evaluated at (node.cpp:804): pos + tangents . phi with phi == 0
+      float pos[3] = {pos804[(tb + k) * 3], pos804[(tb + k) * 3 + 1], pos804[(tb + k) * 3 + 2]};
+      float d[3][3], a[3], cr[3][3];
+      for(int i = 0; i < 3; i++)
+        for(int x = 0; x < 3; x++) d[i][x] = tri[i * 3 + x] - pos[x];
+      for(int i = 0; i < 3; i++)
+      {
+        cross3(d[(i + 1) % 3], d[(i + 2) % 3], cr[i]);
+        a[i] = sqrtf(cr[i][0] * cr[i][0] + cr[i][1] * cr[i][1] + cr[i][2] * cr[i][2]);
+      }
+      const float asum = (a[0] + a[1]) + a[2];
+      const float nd[3] = {-ta.tang[(tb + k) * 6 + 0 * 2 + c], -ta.tang[(tb + k) * 6 + 1 * 2 + c], -ta.tang[(tb + k) * 6 + 2 * 2 + c]};
+      float da[3], dasum = 0.f, dw[3];
+      for(int i = 0; i < 3; i++)
+      {
+        float t1[3], t2[3];
+        cross3(nd, d[(i + 2) % 3], t1);
+        cross3(d[(i + 1) % 3], nd, t2);
+        da[i] = (a[i] > 0.f) ? (cr[i][0] * (t1[0] + t2[0]) + cr[i][1] * (t1[1] + t2[1]) + cr[i][2] * (t1[2] + t2[2])) / a[i] : 0.f;
+        dasum += da[i];
+      }
+      for(int i = 0; i < 3; i++) dw[i] = (da[i] - (a[i] / asum) * dasum) / asum;
+      float dpos[3] = {0.f, 0.f, 0.f}, dnn[3] = {0.f, 0.f, 0.f};
+      for(int i = 0; i < 3; i++)
+        for(int x = 0; x < 3; x++) dpos[x] += dw[i] * tri[i * 3 + x];
+      if(use_normal)
+      {
+        float dmm[3] = {0.f, 0.f, 0.f};
+        for(int i = 0; i < 3; i++)
+          for(int x = 0; x < 3; x++) dmm[x] += dw[i] * lds[L_VN + i * 3 + x];
+        dnormalize_dev(lds + L_VN + 9, dmm, dnn);
+      }
+      float ndot = 0.f;
+      for(int x = 0; x < 3; x++)
+      {
+        if(off > 0.0f) dpos[x] += off * dnn[x];
+        Jk[(int64_t)x * D + TD75 + 2 * k + c] = (double)(wp * dpos[x]);
+        ndot += dnn[x] * ta.tnrm[(tb + k) * 3 + x];
+      }
+      Jk[(int64_t)3 * D + TD75 + 2 * k + c] = (wn > 0.0f) ? (double)(wn * ndot) : 0.0;
+    }
+    __syncthreads();
+  }
+}
+
+// J over the 44-d latent layout from J over theta75 (node.cpp:761-772): columns 0..5 and 69..74 pass through,
+// columns 6..68 (joints 1..21) are pulled back through d(vposer out)/dz [63,32].
+__global__ void ik_latent_jacobian_kernel(const double * __restrict__ J75, const float * __restrict__ vjac, double * __restrict__ Jl,
+                                          int K, int beta_dim, const int * __restrict__ skip)
+{
+  const int64_t f = blockIdx.x;
+  if(skip[f]) return;
+  const int D75 = TD75 + 2 * K + beta_dim, Dl = TD44 + 2 * K + beta_dim;
+  const double * Jf = J75 + f * 4 * K * (int64_t)D75;
+  double * Lf = Jl + f * 4 * K * (int64_t)Dl;
+  const float * vj = vjac + f * 63 * 32;
+  for(int item = threadIdx.x; item < 4 * K * Dl; item += blockDim.x)
+  {
+    const int r = item / Dl, c = item % Dl;
+    double v;
+    if(c < 6)
+      v = Jf[(int64_t)r * D75 + c];
+    else if(c < 6 + 32)
+    {
+      double s = 0.0;
+      for(int q = 0; q < 63; q++) s += Jf[(int64_t)r * D75 + 6 + q] * (double)vj[q * 32 + (c - 6)];
+      v = s;
+    }
+    else if(c < TD44)
+      v = Jf[(int64_t)r * D75 + 69 + (c - 38)];
+    else
+      v = Jf[(int64_t)r * D75 + TD75 + (c - TD44)];
+    Lf[(int64_t)r * Dl + c] = v;
+  }
+}
+
+// theta25 from the latent configuration (node.cpp:763-771)
+__global__ void ik_splice_kernel(const float * __restrict__ g44, const float * __restrict__ vout /*[n,63]*/,
+                                 float * __restrict__ theta25, int64_t n)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n * 75) return;
+  const int64_t f = i / 75;
+  const int c = (int)(i % 75);
+  float v;
+  if(c < 6)
+    v = g44[f * TD44 + c];
+  else if(c < 69)
+    v = vout[f * 63 + (c - 6)];
+  else
+    v = g44[f * TD44 + 38 + (c - 69)];
+  theta25[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ solve kernel
+__device__ inline int tri_idx(int i, int j)
+{
+  return i * (i + 1) / 2 + j; // i >= j
+}
+
+// In-place Cholesky of the packed lower-triangular (nf+1)x(nf+1) augmented matrix [A b; b' *] held in LDS:
+// the last row becomes y = L^-1 b.  Left-looking, one barrier per column.  Returns non-zero pivot failure via *bad.
+__device__ inline void chol_aug(double * M, int nf, int * bad)
+{
+  const int tid = threadIdx.x;
+  for(int j = 0; j < nf; j++)
+  {
+    double d = M[tri_idx(j, j)];
+    for(int k = 0; k < j; k++)
+    {
+      const double l = M[tri_idx(j, k)];
+      d -= l * l;
+    }
+    if(!(d > 0.0))
+    {
+      if(tid == 0) *bad = 1;
+      d = 1.0;
+    }
+    const double piv = sqrt(d);
+    double mine[1];
+    int rows[1];
+    int cnt = 0;
+    for(int i = j + 1 + tid; i <= nf; i += blockDim.x) // nf + 1 rows: at most one row per thread when nf < blockDim
+    {
+      double s = M[tri_idx(i, j)];
+      for(int k = 0; k < j; k++) s -= M[tri_idx(i, k)] * M[tri_idx(j, k)];
+      mine[0] = s / piv;
+      rows[0] = i;
+      cnt = 1;
+    }
+    __syncthreads(); // every read of column j's old content and of row j is done
+    if(cnt) M[tri_idx(rows[0], j)] = mine[0];
+    if(tid == 0) M[tri_idx(j, j)] = piv;
+    __syncthreads();
+  }
+}
+
+// back substitution L^T x = y (y = row nf of M), x returned in xs[0..nf)
+__device__ inline void back_subst(const double * M, int nf, double * xs)
+{
+  const int tid = threadIdx.x;
+  for(int i = tid; i < nf; i += blockDim.x) xs[i] = M[tri_idx(nf, i)];
+  __syncthreads();
+  for(int j = nf - 1; j >= 0; j--)
+  {
+    const double xj = xs[j] / M[tri_idx(j, j)];
+    __syncthreads();
+    for(int k = tid; k < j; k += blockDim.x) xs[k] -= M[tri_idx(j, k)] * xj;
+    if(tid == 0) xs[j] = xj;
+    __syncthreads();
+  }
+}
+
+// One workgroup per frame.  LDS: packed (MAXD+1)(MAXD+2)/2 doubles + vectors.
+__global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const double * __restrict__ e_all, const double * __restrict__ J_all,
+                                                       double * __restrict__ Afull_all, float * __restrict__ theta, float * __restrict__ beta,
+                                                       float * __restrict__ pts, int K, int theta_dim, int beta_dim, int phi_live,
+                                                       int enable_qp, int use_prior, const int * __restrict__ skip,
+                                                       double * __restrict__ e2_out, int * __restrict__ status, double * __restrict__ x_out)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int64_t f = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int D = theta_dim + 2 * K + beta_dim, rows = 4 * K;
+  const int64_t tb = f * K;
+  double * M = sm;                                   // packed augmented matrix
+  double * xs = sm + (MAXD + 1) * (MAXD + 2) / 2;    // [MAXD] solution on the free set
+  double * xfull = xs + MAXD;                        // [MAXD]
+  double * bfull = xfull + MAXD;                     // [MAXD]
+  double * lo = bfull + MAXD;                        // [MAXD]
+  double * hi = lo + MAXD;                           // [MAXD]
+  int * idx = reinterpret_cast<int *>(hi + MAXD);    // [MAXD] free-set -> full index
+  int * state = idx + MAXD;                          // [MAXD] 0 free, -1 at lo, +1 at hi, 2 pinned
+  __shared__ int s_bad, s_nf, s_block, s_bside, s_rel, s_done;
+  __shared__ double s_alpha, s_e2;
+  if(skip[f])
+  {
+    if(tid == 0 && e2_out) e2_out[f] = 0.0;
+    for(int k = tid; k < K * 3; k += 256) pts[tb * 3 + k] = ta.apos[tb * 3 + k];
+    return;
+  }
+  const double * e = e_all + f * rows;
+  const double * J = J_all + f * rows * (int64_t)D;
+  double * Af = Afull_all + f * (int64_t)D * D;
+
+  // A = J^T J, b = J^T e (node.cpp:884-885), fp64
+  for(int item = tid; item < D * D; item += 256)
+  {
+    const int i = item / D, j = item % D;
+    if(j > i) continue;
+    double s = 0.0;
+    for(int r = 0; r < rows; r++) s += J[(int64_t)r * D + i] * J[(int64_t)r * D + j];
+    Af[(int64_t)i * D + j] = s;
+    Af[(int64_t)j * D + i] = s;
+  }
+  for(int i = tid; i < D; i += 256)
+  {
+    double s = 0.0;
+    for(int r = 0; r < rows; r++) s += J[(int64_t)r * D + i] * e[r];
+    bfull[i] = s;
+  }
+  if(tid == 0)
+  {
+    double s = 0.0;
+    for(int r = 0; r < rows; r++) s += e[r] * e[r];
+    s_e2 = s;
+    s_bad = 0;
+    if(e2_out) e2_out[f] = s;
+  }
+  __syncthreads();
+  for(int i = tid; i < D; i += 256)
+  {
+    const double reg = (i < theta_dim) ? 1e-3 : (i < theta_dim + 2 * K ? 1e-1 : 1e-3); // node.cpp:887-892
+    double a = Af[(int64_t)i * D + i] + reg + s_e2;                                       // :893
+    if(use_prior && i < theta_dim) // :895-904 (VPoser latent layout)
+    {
+      const double w = (i < 6) ? 0.0 : (i >= theta_dim - 6 ? 1e3 : 1e-5);
+      a += w;
+      bfull[i] += w * (double)theta[f * theta_dim + i];
+    }
+    Af[(int64_t)i * D + i] = a;
+    // bounds (node.cpp:916-928); theta is free
+    double l = -1e30, h = 1e30;
+    int st = 0;
+    if(i >= theta_dim && i < theta_dim + 2 * K)
+    {
+      const double pl = phi_live ? (double)ta.philim[tb + (i - theta_dim) / 2] : 0.0;
+      if(enable_qp)
+      {
+        l = -pl;
+        h = pl;
+      }
+      // with a zero limit the phi columns of J are zero: the QP pins x_phi = 0 and the LLT solution of the
+      // block-diagonal system has x_phi = 0 as well, so the variable is removed from the system in both modes
+      if(!(pl > 0.0))
+      {
+        l = 0.0;
+        h = 0.0;
+        st = 2;
+      }
+    }
+    else if(i >= theta_dim + 2 * K && enable_qp)
+    {
+      l = -0.5; // :925
+      h = 0.5;
+    }
+    lo[i] = l;
+    hi[i] = h;
+    state[i] = st;
+    xfull[i] = 0.0;
+  }
+  __syncthreads();
+
+  const int max_it = enable_qp ? 4 * D + 20 : 1;
+  for(int it = 0; it < max_it; it++)
+  {
+    if(tid == 0)
+    {
+      int nf = 0;
+      for(int i = 0; i < D; i++)
+        if(state[i] == 0) idx[nf++] = i;
+      s_nf = nf;
+      s_alpha = 1.0;
+      s_block = -1;
+      s_rel = -1;
+      s_done = 0;
+    }
+    __syncthreads();
+    const int nf = s_nf;
+    // gather the free-set system; rhs = b_F + A_FB x_B
+    for(int item = tid; item < (nf + 1) * (nf + 2) / 2; item += 256)
+    {
+      // invert tri_idx
+      int i = (int)((sqrt(8.0 * item + 1.0) - 1.0) * 0.5);
+      while(tri_idx(i + 1, 0) <= item) i++;
+      while(tri_idx(i, 0) > item) i--;
+      const int j = item - tri_idx(i, 0);
+      double v;
+      if(i < nf)
+        v = Af[(int64_t)idx[i] * D + idx[j]];
+      else if(j < nf)
+      {
+        double r = bfull[idx[j]];
+        for(int q = 0; q < D; q++)
+          if(state[q] == -1 || state[q] == 1) r += Af[(int64_t)idx[j] * D + q] * xfull[q];
+        v = r;
+      }
+      else
+        v = 0.0;
+      M[item] = v;
+    }
+    __syncthreads();
+    chol_aug(M, nf, &s_bad);
+    back_subst(M, nf, xs);
+    // candidate x_F = -xs ; ratio test against the box
+    if(enable_qp)
+    {
+      if(tid == 0)
+      {
+        double alpha = 1.0;
+        int block = -1, bside = 0;
+        for(int a = 0; a < nf; a++)
+        {
+          const int i = idx[a];
+          const double xn = -xs[a], dx = xn - xfull[i];
+          if(xn > hi[i] + 1e-14 && dx > 0)
+          {
+            const double al = (hi[i] - xfull[i]) / dx;
+            if(al < alpha) { alpha = al; block = a; bside = 1; }
+          }
+          else if(xn < lo[i] - 1e-14 && dx < 0)
+          {
+            const double al = (lo[i] - xfull[i]) / dx;
+            if(al < alpha) { alpha = al; block = a; bside = -1; }
+          }
+        }
+        s_alpha = alpha;
+        s_block = block;
+        s_bside = bside;
+      }
+      __syncthreads();
+      for(int a = tid; a < nf; a += 256) xfull[idx[a]] += s_alpha * (-xs[a] - xfull[idx[a]]);
+      __syncthreads();
+      if(tid == 0)
+      {
+        if(s_block >= 0)
+        {
+          const int i = idx[s_block];
+          state[i] = s_bside;
+          xfull[i] = s_bside > 0 ? hi[i] : lo[i];
+        }
+        else
+        {
+          double worst = 1e-12;
+          int rel = -1;
+          for(int i = 0; i < D; i++)
+          {
+            if(state[i] != -1 && state[i] != 1) continue;
+            double g = bfull[i];
+            for(int q = 0; q < D; q++) g += Af[(int64_t)i * D + q] * xfull[q];
+            const double viol = (state[i] < 0) ? -g : g;
+            if(viol > worst) { worst = viol; rel = i; }
+          }
+          if(rel < 0)
+            s_done = 1;
+          else
+            state[rel] = 0;
+        }
+      }
+      __syncthreads();
+      if(s_done) break;
+    }
+    else
+    {
+      for(int a = tid; a < nf; a += 256) xfull[idx[a]] = -xs[a]; // x = -LLT(A)^-1 b (node.cpp:938)
+      __syncthreads();
+    }
+  }
+  if(tid == 0) status[f] = s_bad ? 1 : ((enable_qp && !s_done) ? 2 : 0);
+  const bool ok = !s_bad;
+  // config update (node.cpp:945-968), fp32
+  for(int i = tid; i < theta_dim; i += 256)
+    if(ok) theta[f * theta_dim + i] += (float)xfull[i];
+  for(int i = tid; i < beta_dim; i += 256)
+    if(ok) beta[f * NB + i] += (float)xfull[theta_dim + 2 * K + i];
+  for(int i = tid; i < K * 3; i += 256) // p_k = actualPos_k + tangents_k . x_phi_k (:956-959)
+  {
+    const int k = i / 3, x = i % 3;
+    const float p0 = ok ? (float)xfull[theta_dim + 2 * k] : 0.0f, p1 = ok ? (float)xfull[theta_dim + 2 * k + 1] : 0.0f;
+    pts[tb * 3 + i] = ta.apos[tb * 3 + i] + (ta.tang[(tb + k) * 6 + x * 2] * p0 + ta.tang[(tb + k) * 6 + x * 2 + 1] * p1);
+  }
+  if(x_out)
+    for(int i = tid; i < D; i += 256) x_out[f * D + i] = xfull[i];
+}
+
+// node.cpp:970-1001: one workgroup per (frame, task)
+__global__ __launch_bounds__(256) void ik_project_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all,
+                                                          const float * __restrict__ pts, int64_t F, int K, const int * __restrict__ skip)
+{
+  const int64_t f = blockIdx.x / K;
+  if(skip[f]) return;
+  const float * verts = verts_all + f * mv.V * 3;
+  __shared__ int64_t s_face;
+  __shared__ float s_cl[3];
+  closest_point_block(verts, mv.faces, F, pts + (int64_t)blockIdx.x * 3, &s_face, s_cl, nullptr);
+  if(threadIdx.x == 0)
+  {
+    const int face = (int)s_face;
+    float tri[9], w[3];
+    for(int i = 0; i < 3; i++)
+      for(int x = 0; x < 3; x++) tri[i * 3 + x] = verts[3 * mv.faces[face * 3 + i] + x];
+    triangle_weights_dev(s_cl, tri, w); // calcVertexWeights(closest point), phi_ == 0 (:997-998)
+    ta.face[blockIdx.x] = face;
+    for(int i = 0; i < 3; i++) ta.vw[(int64_t)blockIdx.x * 3 + i] = w[i];
+  }
+}
+
+__global__ void fill_f32_kernel(float * p, float v, int64_t n)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n) p[i] = v;
+}
+__global__ void fill_nrm_kernel(float * p, int64_t n)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n) p[i] = (i % 3 == 2) ? 1.0f : 0.0f;
+}
+__global__ void i64_to_i32_kernel(const int64_t * a, int32_t * b, int64_t n)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n) b[i] = (int32_t)a[i];
+}
+__global__ void i32_to_i64_kernel(const int32_t * a, int64_t * b, int64_t n)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n) b[i] = a[i];
+}
+__global__ void f64_to_f32_kernel(const double * a, float * b, int64_t n)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n) b[i] = (float)a[i];
+}
+} // namespace smplpp_hip
+
+using namespace smplpp_hip;
+
+struct smplpp_ik
+{
+  smplpp_model * m = nullptr;
+  smplpp_vposer * vp = nullptr;
+  int64_t n = 0, K = 0;
+  int theta_dim = TD75;
+  TaskArrays ta{};
+  float *theta = nullptr, *beta = nullptr, *theta25 = nullptr, *vout = nullptr, *vjac = nullptr;
+  float *verts = nullptr, *rest = nullptr, *joints = nullptr, *poserot = nullptr, *pts = nullptr;
+  double *e = nullptr, *J = nullptr, *Jl = nullptr, *Afull = nullptr, *e2 = nullptr, *xout = nullptr;
+  int32_t * ring = nullptr;
+  uint8_t * map = nullptr;
+  int *skip = nullptr, *status = nullptr;
+  std::vector<void *> owned;
+  bool have_eval = false;
+};
+
+template<class T>
+static hipError_t dalloc(smplpp_ik * s, T ** p, size_t count)
+{
+  hipError_t e = hipMalloc((void **)p, sizeof(T) * std::max<size_t>(count, 1));
+  if(e == hipSuccess) s->owned.push_back(*p);
+  return e;
+}
+
+static ModelView view_of(const smplpp_model * m)
+{
+  ModelView mv;
+  mv.faces = m->faces;
+  mv.adjOff = m->adjOff;
+  mv.adjFace = m->adjFace;
+  mv.parent = m->parent;
+  mv.wIdx = m->wIdx;
+  mv.wVal = m->wVal;
+  mv.wSum = m->wSum;
+  mv.Pvm = m->Pvm;
+  mv.Svm = m->Svm;
+  mv.JS = m->JS;
+  mv.V = m->V;
+  mv.maxw = m->maxw;
+  return mv;
+}
+
+extern "C" int smplpp_ik_destroy(smplpp_ik * s)
+{
+  if(!s) return SMPLPP_OK;
+  (void)hipSetDevice(s->m->device);
+  for(void * p : s->owned) (void)hipFree(p);
+  delete s;
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_vposer * vposer, smplpp_ik ** out)
+{
+  if(!m || !out || n <= 0 || K <= 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: bad argument");
+  *out = nullptr;
+  if(m->F <= 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: the model has no faces");
+  if(TD75 + 2 * K + NB > MAXD)
+    return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: too many tasks for the in-LDS solver (75 + 2K + 10 must be <= 170)");
+  int maxadj = 0;
+  for(int64_t v = 0; v < m->V; v++) maxadj = std::max(maxadj, (int)(m->h_adjOff[v + 1] - m->h_adjOff[v]));
+  if(maxadj > MAXADJ) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: a vertex has more than 12 adjacent faces");
+  HIP_TRY(hipSetDevice(m->device));
+  smplpp_ik * s = new smplpp_ik();
+  s->m = m;
+  s->vp = vposer;
+  s->n = n;
+  s->K = K;
+  s->theta_dim = vposer ? TD44 : TD75;
+  const size_t nk = (size_t)n * K;
+  const size_t Dmax = TD75 + 2 * K + NB;
+#define A_(field, count)                                         \
+  do                                                             \
+  {                                                              \
+    hipError_t _e = dalloc(s, &s->field, (count));               \
+    if(_e != hipSuccess)                                         \
+    {                                                            \
+      int _rc = hip_fail(_e, #field, __FILE__, __LINE__);        \
+      smplpp_ik_destroy(s);                                      \
+      return _rc;                                                \
+    }                                                            \
+  } while(0)
+  A_(ta.face, nk);
+  A_(ta.vw, nk * 3);
+  A_(ta.tang, nk * 6);
+  A_(ta.tpos, nk * 3);
+  A_(ta.tnrm, nk * 3);
+  A_(ta.posw, nk);
+  A_(ta.nrmw, nk);
+  A_(ta.philim, nk);
+  A_(ta.noff, nk);
+  A_(ta.apos, nk * 3);
+  A_(ta.anrm, nk * 3);
+  A_(theta, (size_t)n * s->theta_dim);
+  A_(beta, (size_t)n * NB);
+  A_(theta25, (size_t)n * 75);
+  A_(verts, (size_t)n * m->V * 3);
+  A_(rest, (size_t)n * m->V * 3);
+  A_(joints, (size_t)n * NJ * 3);
+  A_(poserot, (size_t)n * NJ * 9);
+  A_(pts, nk * 3);
+  A_(e, nk * 4);
+  A_(J, nk * 4 * Dmax);
+  A_(Afull, (size_t)n * Dmax * Dmax);
+  A_(e2, (size_t)n);
+  A_(xout, (size_t)n * Dmax);
+  A_(ring, nk * (MAXRING + 1));
+  A_(map, nk * 3 * MAXADJ * 3);
+  A_(skip, (size_t)n);
+  A_(status, (size_t)n);
+  if(vposer)
+  {
+    A_(Jl, nk * 4 * Dmax);
+    A_(vout, (size_t)n * 63);
+    A_(vjac, (size_t)n * 63 * 32);
+  }
+#undef A_
+  // IkTask defaults (include/smplpp/IkTask.h:54-84)
+  auto grid = [](size_t c) { return dim3((unsigned)((c + 255) / 256)); };
+  HIP_TRY(hipMemset(s->ta.face, 0, sizeof(int32_t) * nk));
+  fill_f32_kernel<<<grid(nk * 3), 256>>>(s->ta.vw, 1.0f / 3.0f, nk * 3);
+  fill_f32_kernel<<<grid(nk * 6), 256>>>(s->ta.tang, 0.0f, nk * 6);
+  fill_f32_kernel<<<grid(nk * 3), 256>>>(s->ta.tpos, 0.0f, nk * 3);
+  fill_nrm_kernel<<<grid(nk * 3), 256>>>(s->ta.tnrm, nk * 3);
+  fill_f32_kernel<<<grid(nk), 256>>>(s->ta.posw, 1.0f, nk);
+  fill_f32_kernel<<<grid(nk), 256>>>(s->ta.nrmw, 1.0f, nk);
+  fill_f32_kernel<<<grid(nk), 256>>>(s->ta.philim, 0.04f, nk);
+  fill_f32_kernel<<<grid(nk), 256>>>(s->ta.noff, 0.0f, nk);
+  HIP_TRY(hipMemset(s->theta, 0, sizeof(float) * n * s->theta_dim));
+  HIP_TRY(hipMemset(s->beta, 0, sizeof(float) * n * NB));
+  HIP_TRY(hipMemset(s->skip, 0, sizeof(int) * n));
+  HIP_TRY(hipMemset(s->status, 0, sizeof(int) * n));
+  HIP_TRY(hipDeviceSynchronize());
+  *out = s;
+  return SMPLPP_OK;
+}
+
+// copy caller array -> solver array with optional conversion
+template<class Src, class Dst, class Conv>
+static int set_array(const Src * src, Dst * dst, size_t count, int space, Conv conv)
+{
+  if(!src) return SMPLPP_OK;
+  In<Src> in;
+  HIP_TRY(in.init(src, count, space, nullptr));
+  conv(in.d, dst, (int64_t)count);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_ik_set_tasks(smplpp_ik * s, const int64_t * face_idx, const float * vertex_weights, const float * target_pos,
+                                   const float * target_normal, const double * pos_task_weight, const double * normal_task_weight,
+                                   const double * phi_limit, const double * normal_offset, int space)
+{
+  if(!s) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_set_tasks: null solver");
+  int rc = check_space(space, "smplpp_ik_set_tasks");
+  if(rc) return rc;
+  HIP_TRY(hipSetDevice(s->m->device));
+  const size_t nk = (size_t)s->n * s->K;
+  if(face_idx && space == SMPLPP_HOST)
+    for(size_t i = 0; i < nk; i++)
+      if(face_idx[i] < 0 || face_idx[i] >= s->m->F) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_set_tasks: face index out of range");
+  auto g = [](int64_t c) { return dim3((unsigned)((c + 255) / 256)); };
+  auto cpf = [](const float * a, float * b, int64_t c) { (void)hipMemcpy(b, a, sizeof(float) * c, hipMemcpyDeviceToDevice); };
+  auto cvd = [&](const double * a, float * b, int64_t c) { f64_to_f32_kernel<<<g(c), 256>>>(a, b, c); };
+  auto cvi = [&](const int64_t * a, int32_t * b, int64_t c) { i64_to_i32_kernel<<<g(c), 256>>>(a, b, c); };
+  if((rc = set_array(face_idx, s->ta.face, nk, space, cvi))) return rc;
+  if((rc = set_array(vertex_weights, s->ta.vw, nk * 3, space, cpf))) return rc;
+  if((rc = set_array(target_pos, s->ta.tpos, nk * 3, space, cpf))) return rc;
+  if((rc = set_array(target_normal, s->ta.tnrm, nk * 3, space, cpf))) return rc;
+  if((rc = set_array(pos_task_weight, s->ta.posw, nk, space, cvd))) return rc;
+  if((rc = set_array(normal_task_weight, s->ta.nrmw, nk, space, cvd))) return rc;
+  if((rc = set_array(phi_limit, s->ta.philim, nk, space, cvd))) return rc;
+  if((rc = set_array(normal_offset, s->ta.noff, nk, space, cvd))) return rc;
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_ik_set_config(smplpp_ik * s, const float * beta, const float * theta, int space)
+{
+  if(!s) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_set_config: null solver");
+  int rc = check_space(space, "smplpp_ik_set_config");
+  if(rc) return rc;
+  HIP_TRY(hipSetDevice(s->m->device));
+  hipMemcpyKind kind = space == SMPLPP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  if(beta) HIP_TRY(hipMemcpy(s->beta, beta, sizeof(float) * s->n * NB, kind));
+  if(theta) HIP_TRY(hipMemcpy(s->theta, theta, sizeof(float) * s->n * s->theta_dim, kind));
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_ik_get_config(smplpp_ik * s, float * beta, float * theta, int space)
+{
+  if(!s) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_get_config: null solver");
+  int rc = check_space(space, "smplpp_ik_get_config");
+  if(rc) return rc;
+  HIP_TRY(hipSetDevice(s->m->device));
+  HIP_TRY(hipDeviceSynchronize());
+  hipMemcpyKind kind = space == SMPLPP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if(beta) HIP_TRY(hipMemcpy(beta, s->beta, sizeof(float) * s->n * NB, kind));
+  if(theta) HIP_TRY(hipMemcpy(theta, s->theta, sizeof(float) * s->n * s->theta_dim, kind));
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_ik_get_tasks(smplpp_ik * s, int64_t * face_idx, float * vertex_weights, float * tangents, float * actual_pos,
+                                   float * actual_normal, int space)
+{
+  if(!s) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_get_tasks: null solver");
+  int rc = check_space(space, "smplpp_ik_get_tasks");
+  if(rc) return rc;
+  HIP_TRY(hipSetDevice(s->m->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t nk = (size_t)s->n * s->K;
+  hipMemcpyKind kind = space == SMPLPP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if(face_idx)
+  {
+    Out<int64_t> o;
+    HIP_TRY(o.init(face_idx, nk, space));
+    i32_to_i64_kernel<<<dim3((unsigned)((nk + 255) / 256)), 256>>>(s->ta.face, o.d, (int64_t)nk);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(o.finish(nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  if(vertex_weights) HIP_TRY(hipMemcpy(vertex_weights, s->ta.vw, sizeof(float) * nk * 3, kind));
+  if(tangents) HIP_TRY(hipMemcpy(tangents, s->ta.tang, sizeof(float) * nk * 6, kind));
+  if(actual_pos) HIP_TRY(hipMemcpy(actual_pos, s->ta.apos, sizeof(float) * nk * 3, kind));
+  if(actual_normal) HIP_TRY(hipMemcpy(actual_normal, s->ta.anrm, sizeof(float) * nk * 3, kind));
+  return SMPLPP_OK;
+}
+
+// forward + eval for all frames (enqueue only)
+static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64_t min_valid, hipStream_t st)
+{
+  smplpp_model * m = s->m;
+  const int64_t n = s->n;
+  const int K = (int)s->K;
+  const float * th25 = s->theta;
+  if(s->vp) // node.cpp:761-772
+  {
+    int rc = vposer_forward_device(s->vp, n, s->theta + 6, TD44, s->vout, 63, s->vjac, st);
+    if(rc) return rc;
+    ik_splice_kernel<<<dim3((unsigned)((n * 75 + 255) / 256)), 256, 0, st>>>(s->theta, s->vout, s->theta25, n);
+    th25 = s->theta25;
+  }
+  int rc = fk_device(m, n, s->beta, th25, s->verts, s->joints, nullptr, s->rest, s->poserot, st); // node.cpp:777
+  if(rc) return rc;
+  const size_t shmem = sizeof(float) * L_END + L_ANC_BYTES;
+  static bool attr = false;
+  if(!attr)
+  {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ik_eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    attr = true;
+  }
+  ik_eval_kernel<<<dim3((unsigned)n), dim3(256), shmem, st>>>(view_of(m), s->ta, th25, s->verts, s->rest, m->ws.Gp.as<float>(),
+                                                              s->joints, s->poserot, K, optimize_beta, phi_live, (int)min_valid,
+                                                              s->ring, s->map, s->pts, s->e, s->J, s->skip);
+  HIP_TRY(hipGetLastError());
+  if(s->vp)
+  {
+    ik_latent_jacobian_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(s->J, s->vjac, s->Jl, K, optimize_beta ? NB : 0, s->skip);
+    HIP_TRY(hipGetLastError());
+  }
+  s->have_eval = true;
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_ik_eval(smplpp_ik * s, int optimize_beta, double * e, double * J, int space, void * stream)
+{
+  if(!s) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_eval: null solver");
+  int rc = check_space(space, "smplpp_ik_eval");
+  if(rc) return rc;
+  HIP_TRY(hipSetDevice(s->m->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  rc = ik_forward_eval(s, optimize_beta, 1, 0, st);
+  if(rc) return rc;
+  const int64_t D = s->theta_dim + 2 * s->K + (optimize_beta ? NB : 0);
+  hipMemcpyKind kind = space == SMPLPP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if(e) HIP_TRY(hipMemcpyAsync(e, s->e, sizeof(double) * s->n * s->K * 4, kind, st));
+  if(J) HIP_TRY(hipMemcpyAsync(J, s->vp ? s->Jl : s->J, sizeof(double) * s->n * s->K * 4 * D, kind, st));
+  if(space == SMPLPP_HOST) HIP_TRY(hipStreamSynchronize(st));
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int optimize_beta_from, int64_t min_valid,
+                                 double * e_sqnorm, int space, void * stream)
+{
+  if(!s || iters < 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_iterate: bad argument");
+  int rc = check_space(space, "smplpp_ik_iterate");
+  if(rc) return rc;
+  smplpp_model * m = s->m;
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int K = (int)s->K;
+  const size_t solve_shmem = sizeof(double) * ((size_t)(MAXD + 1) * (MAXD + 2) / 2 + 5 * MAXD) + sizeof(int) * 2 * MAXD;
+  static bool attr = false;
+  if(!attr)
+  {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ik_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_shmem));
+    attr = true;
+  }
+  for(int it = 0; it < iters; it++)
+  {
+    const int opt_beta = (optimize_beta_from >= 0 && it >= optimize_beta_from) ? 1 : 0; // node.cpp:655
+    const int phi_live = (optimize_beta_from >= 0) ? (it >= optimize_beta_from ? 1 : 0) : 1; // :693-700
+    rc = ik_forward_eval(s, opt_beta, phi_live, min_valid, st);
+    if(rc) return rc;
+    const int beta_dim = opt_beta ? NB : 0;
+    ik_solve_kernel<<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(s->ta, s->e, s->vp ? s->Jl : s->J, s->Afull, s->theta, s->beta,
+                                                                        s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp,
+                                                                        s->vp ? 1 : 0, s->skip, s->e2, s->status, s->xout);
+    HIP_TRY(hipGetLastError());
+    ik_project_kernel<<<dim3((unsigned)(s->n * K)), dim3(256), 0, st>>>(view_of(m), s->ta, s->verts, s->pts, m->F, K, s->skip);
+    HIP_TRY(hipGetLastError());
+  }
+  if(e_sqnorm)
+  {
+    hipMemcpyKind kind = space == SMPLPP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIP_TRY(hipMemcpyAsync(e_sqnorm, s->e2, sizeof(double) * s->n, kind, st));
+  }
+  if(space == SMPLPP_HOST)
+  {
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<int> h((size_t)s->n);
+    HIP_TRY(hipMemcpy(h.data(), s->status, sizeof(int) * s->n, hipMemcpyDeviceToHost));
+    for(int64_t f = 0; f < s->n; f++)
+      if(h[f] == 1) return fail(SMPLPP_ERR_NUMERIC, "LLT has numerical issue!"); // node.cpp:934-937
+  }
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_ik_get_vertices(smplpp_ik * s, float * verts, int space, void * stream)
+{
+  if(!s || !verts) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_get_vertices: bad argument");
+  if(!s->have_eval) return fail(SMPLPP_ERR_STATE, "Failed to get vertices of new pose!");
+  int rc = check_space(space, "smplpp_ik_get_vertices");
+  if(rc) return rc;
+  HIP_TRY(hipSetDevice(s->m->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipMemcpyKind kind = space == SMPLPP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  HIP_TRY(hipMemcpyAsync(verts, s->verts, sizeof(float) * s->n * s->m->V * 3, kind, st));
+  if(space == SMPLPP_HOST) HIP_TRY(hipStreamSynchronize(st));
+  return SMPLPP_OK;
+}

@@ -1,6 +1,6 @@
 // Model creation: replaces SMPL::init (/root/reference/src/SMPL.cpp:560-643) minus the JSON parse.
 //
-// HBM layout produced here (all fp32 unless noted, resident for the life of the handle):
+// HBM layout produced here (all fp32 unless noted, resident for the life of the handle; ~37 MB for SMPL):
 //   Bm   [220][ldB]   B operand of the fused blend-shape GEMM, K-major: rows 0..206 posedirs, 207..216 shapedirs,
 //                     217 template, 218..219 zero.  Columns are grouped per 32 vertices as [32 x | 32 y | 32 z] so
 //                     that one 32x32 MFMA tile is one coordinate of 32 consecutive vertices (ldB = ceil(V/32)*96).
@@ -10,6 +10,8 @@
 //   J0 [24][3], JS [24][3][10]  joint regressor folded through template and shapedirs:
 //                     joints = J0 + JS . beta  ==  Jreg . (T + S . beta)   (src/JointRegression.cpp:588-590)
 //   faces, adjOff/adjFace      0-based faces and the per-vertex adjacent-face table (src/SMPL.cpp:620-640).
+//   Pvm [V][3][207], Svm [V][3][10]  the bases once more in the file's vertex-major order, for the IK Jacobian of a
+//                     handful of task vertices (a K-major gather would touch 207 cache lines per vertex).
 #include "common.h"
 
 #include <algorithm>
@@ -129,7 +131,7 @@ extern "C" int smplpp_model_destroy(smplpp_model * m)
 {
   if(!m) return SMPLPP_OK;
   (void)hipSetDevice(m->device);
-  void * ptrs[] = {m->Bm, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense};
+  void * ptrs[] = {m->Bm, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm};
   for(void * p : ptrs)
     if(p) (void)hipFree(p);
   Workspace & w = m->ws;
@@ -195,8 +197,8 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   fold_regressor_kernel<<<dim3(NJ * 3 * (NB + 1)), dim3(256)>>>(dJreg, dS, dT, m->J0, m->JS, V);
   TRY_OR_FREE(hipGetLastError());
   TRY_OR_FREE(hipDeviceSynchronize());
-  (void)hipFree(dP);
-  (void)hipFree(dS);
+  m->Pvm = dP; // kept: vertex-major copies serve the sparse IK Jacobian (contiguous 2.5 KB per vertex)
+  m->Svm = dS;
   (void)hipFree(dT);
   (void)hipFree(dJreg);
 

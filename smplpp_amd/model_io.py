@@ -185,7 +185,7 @@ def synthetic_model(seed: int = 20250205) -> Dict[str, np.ndarray]:
 
 
 def tiny_model(vertex_num: int, seed: int = 7, faces: np.ndarray | None = None) -> Dict[str, np.ndarray]:
-    """A small dense random model (any vertex count) for fast oracle/parity cases and ragged-size tests.
+    """A small dense random model (any vertex count) for fast parity cases and ragged-size tests.
 
     Weights and regressor are fully dense here on purpose (every joint non-zero) so the dense skinning path and
     the sparse one can be checked against each other.

@@ -1,0 +1,199 @@
+"""GPU parity of the IK path (node/node.cpp:704-1001) through the C ABI against the reference's autograd goldens and
+the C oracle.  Tolerances: residual rows 2e-6 m (position) / 5e-5 (normal); Jacobian to fp32 rounding of the
+reference's autograd path; joint angles 1e-4 rad per step (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def smpl(synth_model):
+    from smplpp_amd.smpl import SMPL
+
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(synth_model)
+    return s
+
+
+def _solver(smpl, g, n, cfg, vertex_weights=None, faces=None):
+    from smplpp_amd.ik import IkSolver
+
+    pl, no, ob, nw, pw = cfg
+    K = len(g["face_idx"])
+    s = IkSolver(smpl, n, K)
+    s.setTasks(face_idx=g["face_idx"] if faces is None else faces, target_pos=g["target_pos"], target_normal=g["target_normal"],
+               pos_task_weight=np.full(K, pw), normal_task_weight=np.full(K, nw), phi_limit=np.full(K, pl),
+               normal_offset=np.full(K, no), vertex_weights=vertex_weights)
+    return s
+
+
+@pytest.mark.parametrize("case", ["plain", "body", "full", "motion", "missing"])
+def test_ik_eval_vs_reference_autograd(smpl, golden_ik_synth, case):
+    """e and J of node.cpp:798-877 against libtorch autograd through the reference's compiled FK stages."""
+    g = golden_ik_synth
+    cfg = g[case + "_cfg"]
+    K = len(g["face_idx"])
+    n = 3  # same frame three times: batch slots are independent
+    s = _solver(smpl, g, n, cfg)
+    s.setConfig(np.tile(g["beta"], (n, 1)), np.tile(g["theta"], (n, 1, 1)))
+    e, J = s.eval(optimize_beta=bool(cfg[2]))
+    Jg, eg = g[case + "_J"], g[case + "_e"]
+    assert J.shape[1:] == Jg.shape
+    for f in range(n):
+        de = np.abs(e[f] - eg).reshape(K, 4)
+        assert de[:, :3].max() < 2e-6 and de[:, 3].max() < 5e-5
+        dJ = np.abs(J[f] - Jg).reshape(K, 4, -1)
+        scale = max(1.0, np.abs(Jg).max())
+        assert dJ[:, :3].max() < 5e-5 * scale
+        assert dJ[:, 3].max() < 6e-4 * scale
+    t = s.getTasks()
+    assert np.abs(t["vertex_weights"][0] - g[case + "_vertex_weights"]).max() < 2e-5
+    assert np.abs(t["tangents"][0] - g[case + "_tangents"]).max() < 1e-4
+    assert np.abs(t["actual_pos"][0] - g[case + "_actual_pos"]).max() < 2e-6
+    assert np.abs(t["actual_normal"][0] - g[case + "_actual_normal"]).max() < 5e-5
+    if cfg[4] == 0.0:
+        assert not e.any() and not J.any()
+
+
+def test_ik_eval_vs_oracle_random_frames(smpl, oracle_synth, synth_model):
+    from oracle import cpu
+    from smplpp_amd import model_io
+    from smplpp_amd.ik import IkSolver
+
+    rng = np.random.default_rng(21)
+    n, K = 5, 9
+    beta, theta = model_io.synthetic_inputs(n, seed=77)
+    theta[:, 1:] *= 0.5
+    faces = rng.integers(0, 13776, (n, K))
+    tp = rng.normal(0, 0.4, (n, K, 3)).astype(np.float32)
+    tn = rng.normal(0, 1, (n, K, 3)).astype(np.float32)
+    tn /= np.linalg.norm(tn, axis=2, keepdims=True)
+    bary = rng.dirichlet(np.ones(3), (n, K)).astype(np.float32)
+    s = IkSolver(smpl, n, K)
+    s.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, vertex_weights=bary, phi_limit=np.full((n, K), 0.04),
+               normal_offset=np.full((n, K), 0.015), pos_task_weight=rng.uniform(0.5, 2, (n, K)),
+               normal_task_weight=rng.uniform(0.5, 2, (n, K)))
+    s.setConfig(beta, theta)
+    e, J = s.eval(optimize_beta=True)
+    pw, nw = None, None
+    for f in range(n):
+        ts = cpu.TaskSet(faces[f], tp[f], tn[f], vertex_weights=bary[f], phi_limit=np.full(K, 0.04), normal_offset=np.full(K, 0.015))
+        # same weights as set above (re-draw in the same order)
+        if pw is None:
+            r2 = np.random.default_rng(21)
+            r2.integers(0, 13776, (n, K)); r2.normal(0, 0.4, (n, K, 3)); r2.normal(0, 1, (n, K, 3)); r2.dirichlet(np.ones(3), (n, K))
+            pw = r2.uniform(0.5, 2, (n, K)); nw = r2.uniform(0.5, 2, (n, K))
+        ts.pos_task_weight[:] = pw[f]
+        ts.normal_task_weight[:] = nw[f]
+        r = oracle_synth.ik_eval(beta[f], theta[f], ts, True)
+        de = np.abs(r["e"] - e[f]).reshape(K, 4)
+        assert de[:, :3].max() < 5e-6 and de[:, 3].max() < 1e-4
+        dJ = np.abs(r["J"] - J[f]).reshape(K, 4, -1)
+        scale = max(1.0, np.abs(r["J"]).max())
+        assert dJ[:, :3].max() < 5e-5 * scale, f
+        assert dJ[:, 3].max() < 6e-4 * scale, f
+
+
+def test_ik_step_from_golden_states(smpl, golden_ik_synth):
+    """One iteration from each state of the reference-autograd trajectory: joint angles within 1e-4 rad."""
+    g = golden_ik_synth
+    K = len(g["face_idx"])
+    traj, faces, weights = g["traj_theta"], g["traj_faces"], g["traj_weights"]
+    n = traj.shape[0] - 1
+    from smplpp_amd.ik import IkSolver
+
+    s = IkSolver(smpl, n, K)
+    s.setTasks(face_idx=faces[:n], vertex_weights=weights[:n], target_pos=g["target_pos"], target_normal=g["target_normal"],
+               phi_limit=np.zeros(K))
+    s.setConfig(np.zeros((n, 10), np.float32), traj[:n])
+    e2 = s.iterate(1)
+    _, theta = s.getConfig()
+    t = s.getTasks()
+    for it in range(n):
+        assert np.abs(theta[it] - traj[it + 1]).max() < 1e-4, it
+        assert abs(e2[it] - g["traj_e_sqnorm"][it]) < 2e-5 * max(1.0, e2[it])
+        assert (t["face_idx"][it] == faces[it + 1]).all()
+        assert np.abs(t["vertex_weights"][it] - weights[it + 1]).max() < 2e-3
+
+
+def test_ik_free_running_converges_like_reference(smpl, golden_ik_synth):
+    g = golden_ik_synth
+    K = len(g["face_idx"])
+    traj = g["traj_theta"]
+    from smplpp_amd.ik import IkSolver
+
+    s = IkSolver(smpl, 2, K)
+    s.setTasks(face_idx=g["face_idx"], target_pos=g["target_pos"], target_normal=g["target_normal"], phi_limit=np.zeros(K))
+    s.setConfig(np.zeros((2, 10), np.float32), np.tile(traj[0], (2, 1, 1)))
+    for it in range(1, traj.shape[0]):
+        e2 = s.iterate(1)
+        _, theta = s.getConfig()
+        tol = 1e-4 if g["traj_e_sqnorm"][it - 1] > 1e-3 else 3e-3
+        assert np.abs(theta[0] - traj[it]).max() < tol, it
+        assert np.abs(theta[0] - theta[1]).max() == 0  # identical frames stay identical
+    assert e2.max() < 2e-5
+
+
+def test_ik_batch_vs_oracle_solve(smpl, oracle_synth, golden_ik_synth):
+    """BASELINE config 3 in miniature: 6 targets, several perturbed starts, 8 iterations, vs the oracle loop."""
+    from oracle import cpu
+    from smplpp_amd.ik import IkSolver
+
+    g = golden_ik_synth
+    K = len(g["face_idx"])
+    rng = np.random.default_rng(4)
+    n = 4
+    theta0 = np.tile(g["traj_theta"][0], (n, 1, 1)) + rng.normal(0, 0.05, (n, 25, 3)).astype(np.float32)
+    s = IkSolver(smpl, n, K)
+    s.setTasks(face_idx=g["face_idx"], target_pos=g["target_pos"], target_normal=g["target_normal"], phi_limit=np.zeros(K))
+    s.setConfig(np.zeros((n, 10), np.float32), theta0)
+    e2 = s.iterate(5)
+    _, theta = s.getConfig()
+    for f in range(n):
+        ts = cpu.TaskSet(g["face_idx"], g["target_pos"], g["target_normal"], phi_limit=np.zeros(K))
+        _, th, oe2 = oracle_synth.ik_solve(np.zeros(10, np.float32), theta0[f], ts, 5)
+        assert np.abs(theta[f] - th).max() < 1e-4, f
+        assert abs(e2[f] - oe2) < 1e-4 * max(1.0, oe2)
+
+
+def test_ik_body_mode_box_qp_vs_oracle(smpl, oracle_synth, golden_ik_synth):
+    """solveMocapBody-style: theta only for 2 iterations, then theta + phi (|phi| <= 0.04) + beta (|dbeta| <= 0.5) by box QP."""
+    from oracle import cpu
+    from smplpp_amd.ik import IkSolver
+
+    g = golden_ik_synth
+    K = len(g["face_idx"])
+    s = IkSolver(smpl, 1, K)
+    kw = dict(face_idx=g["face_idx"], target_pos=g["target_pos"], target_normal=g["target_normal"],
+              phi_limit=np.full(K, 0.04), normal_offset=np.full(K, 0.015), normal_task_weight=np.zeros(K))
+    s.setTasks(**kw)
+    s.setConfig(g["beta"][None], g["traj_theta"][0][None])
+    s.iterate(4, enable_qp=True, optimize_beta_from=2)
+    beta, theta = s.getConfig()
+    ts = cpu.TaskSet(g["face_idx"], g["target_pos"], g["target_normal"], phi_limit=np.full(K, 0.04),
+                     normal_offset=np.full(K, 0.015), normal_task_weight=np.zeros(K))
+    ob, oth, _ = oracle_synth.ik_solve(g["beta"], g["traj_theta"][0], ts, 4, enable_qp=True, optimize_beta_from=2)
+    assert np.abs(theta[0] - oth).max() < 2e-4
+    assert np.abs(beta[0] - ob).max() < 2e-3
+    assert np.abs(beta[0] - g["beta"]).max() <= 1.0 + 1e-6  # two beta steps of at most 0.5 each
+
+
+def test_ik_skips_frames_with_too_few_markers(smpl, golden_ik_synth):
+    """node.cpp:785: valid < K/2 -> the whole solve block is skipped for that frame."""
+    from smplpp_amd.ik import IkSolver
+
+    g = golden_ik_synth
+    K = len(g["face_idx"])
+    s = IkSolver(smpl, 2, K)
+    pw = np.ones((2, K))
+    pw[1, : K - 2] = 0.0  # frame 1: only 2 valid markers
+    s.setTasks(face_idx=g["face_idx"], target_pos=g["target_pos"], target_normal=g["target_normal"], phi_limit=np.zeros(K),
+               pos_task_weight=pw, normal_task_weight=np.zeros(K), normal_offset=np.full(K, 0.015))
+    th0 = np.tile(g["traj_theta"][0], (2, 1, 1))
+    s.setConfig(np.zeros((2, 10), np.float32), th0)
+    s.iterate(1, enable_qp=True, min_valid=K // 2)
+    _, theta = s.getConfig()
+    assert np.abs(theta[0] - th0[0]).max() > 1e-3
+    assert np.abs(theta[1] - th0[1]).max() == 0
