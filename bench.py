@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline metric on MI355X: SMPL FK evals/s (+ IK iterations/s), batch 1024 frames.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (SMPL::launch: pose/chain kernel + fused blend-shape GEMM + skinning kernel)
+over one batch of 1024 synthetic frames per GPU, inputs and outputs resident in HBM (BASELINE.json configs[1]).
+Frames are independent, so N GPUs run N independent shards (weak scaling) with no data-path collective; timing is
+barrier + synchronize on both sides, max over ranks.  Rank 0 prints ONE JSON line.
+
+Also reported in the same line:
+  roofline      dominant kernel (skin_kernel): algorithmic FLOPs / bytes per launch divided by
+                the kernel's mean duration measured with HIP events on its launch stream over the timed region;
+  ik            IK iterations/s on BASELINE.json configs[2] (6 targets, 50 iterations, 256 frames per GPU);
+  cpu_baseline  the reference's own compiled FK stages (oracle/_ref, libtorch-CPU) — or the C port when that
+                library is absent — timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+V = 6890
+# model constants once per batch + per-frame beta/theta in and vertices out
+ALG_BYTES_CONST = 19_347_120
+ALG_BYTES_PER_FRAME = 83_020
+# fp32 FLOPs of the dense contraction the MFMA pipe executes per frame: 2 * 20670 * (207 posedirs + 10 shapedirs)
+ALG_MFMA_FLOPS_PER_FRAME = 2 * 20670 * 217
+ALG_FLOPS_PER_FRAME = 15.5e6  # whole FK
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
+
+
+def cpu_baseline(model, frames, budget_s=12.0):
+    """Reference libtorch-CPU FK (oracle/_ref) on this box's cores; falls back to the C port.  Checker code is only
+    ever used here as the thing timed for the reported baseline — never on the GPU product path."""
+    from smplpp_amd import model_io
+
+    beta, theta = model_io.synthetic_inputs(frames, seed=1)
+    kind, cores, run = None, 1, None
+    try:
+        from oracle import ref
+
+        if ref.available():
+            R = ref.RefModel(model)
+            cores = ref.lib().ref_get_num_threads()
+            run = lambda: R.fk_launch_only(beta, theta)
+            kind = "reference"
+    except Exception as e:  # libtorch unusable here: fall back to the port
+        sys.stderr.write("cpu_baseline: reference build unavailable (%s); using the C port\n" % e)
+    if run is None:
+        from oracle import cpu
+
+        O = cpu.OracleModel(model)
+        cores = cpu.lib().oracle_max_threads()
+        run = lambda: O.fk(beta, theta, want=("verts",))
+        kind = "port"
+    run()  # warm
+    t0 = time.perf_counter()
+    batches = 0
+    while True:
+        run()
+        batches += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or batches >= 40:
+            break
+    return {
+        "value": frames * batches / el, "unit": "FK evals/s", "cores": int(cores), "kind": kind,
+        "sample": "%d batches of %d frames (%.1f s) of the same synthetic workload, SMPL::launch only" % (batches, frames, el),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step (BASELINE: 1024)")
+    ap.add_argument("--ik-frames", type=int, default=256)
+    ap.add_argument("--ik-iters", type=int, default=50)
+    ap.add_argument("--no-ik", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="also time one final RCCL gather of all vertices to rank 0")
+    args = ap.parse_args()
+
+    import torch
+
+    from smplpp_amd import dist as D
+    from smplpp_amd import model_io
+    from smplpp_amd.smpl import SMPL
+
+    rank, world, local = D.env_rank_world()
+    if world != args.gpus and world != 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local)
+    D.init_process_group("nccl" if world > 1 else None)
+
+    model = model_io.synthetic_model()
+    smpl = SMPL()
+    smpl.setDevice("cuda:%d" % local)
+    smpl.init(model)
+
+    n = args.frames
+    beta_h, theta_h = model_io.synthetic_inputs(n, seed=1 + rank)
+    beta = torch.from_numpy(beta_h).cuda()
+    theta = torch.from_numpy(theta_h).cuda()
+    out = {"verts": torch.empty((n, V, 3), dtype=torch.float32, device="cuda")}
+
+    def step():
+        smpl.launch(beta, theta, want=("verts",), out=out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    D.barrier()
+    smpl.profileEnable(True)
+    smpl.profileRead()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    launches, skin_ms = smpl.profileRead()
+    smpl.profileEnable(False)
+    elapsed = D.max_over_ranks(elapsed)
+    skin_ms = D.max_over_ranks(skin_ms)
+
+    # ---- IK leg (BASELINE.json configs[2]): 6 targets, 50 iterations, 256 frames per GPU
+    ik = None
+    if not args.no_ik:
+        from smplpp_amd.ik import IkSolver, reference_task_faces
+
+        K = 6
+        _, faces = reference_task_faces(K)
+        rng = np.random.default_rng(100 + rank)
+        hid = np.zeros((args.ik_frames, 25, 3), np.float32)
+        hid[:, 1:] = rng.normal(0, 0.2, (args.ik_frames, 24, 3))
+        hv = smpl.launch(np.zeros((args.ik_frames, 10), np.float32), hid, want=("verts",))["verts"]
+        f0 = model["face_indices"][faces] - 1
+        tp = hv[:, f0].mean(axis=2)  # reachable targets: task points of a hidden pose
+        theta0 = np.zeros((args.ik_frames, 25, 3), np.float32)
+        theta0[:, 1:] = rng.normal(0, 0.05, (args.ik_frames, 24, 3))
+        solver = IkSolver(smpl, args.ik_frames, K)
+        solver.setTasks(face_idx=faces, target_pos=tp, phi_limit=np.zeros(K), normal_task_weight=np.zeros(K))
+        reps = 3
+        ik_t = 0.0
+        for rep in range(reps + 1):
+            solver.setTasks(face_idx=faces, vertex_weights=np.full((K, 3), 1 / 3, np.float32))
+            solver.setConfig(np.zeros((args.ik_frames, 10), np.float32), theta0)
+            torch.cuda.synchronize()
+            D.barrier()
+            t1 = time.perf_counter()
+            e2 = solver.iterate(args.ik_iters)
+            torch.cuda.synchronize()
+            D.barrier()
+            if rep > 0:  # rep 0 is warm-up
+                ik_t += time.perf_counter() - t1
+        ik_t = D.max_over_ranks(ik_t / reps)
+        ik = {
+            "value": world * args.ik_frames * args.ik_iters / ik_t, "unit": "IK iterations/s", "frames_per_gpu": args.ik_frames,
+            "iters": args.ik_iters, "tasks": K, "ms_per_iter_batch": ik_t / args.ik_iters * 1e3,
+            "final_max_e_sqnorm": float(np.max(e2)), "workload": "configs[2]: 6-target IK, 50 iterations, direct theta (D = 87)",
+        }
+
+    gather_ms = None
+    if args.gather and world > 1:
+        torch.cuda.synchronize()
+        D.barrier()
+        t1 = time.perf_counter()
+        full = D.gather_rows(out["verts"], n * world)
+        torch.cuda.synchronize()
+        gather_ms = D.max_over_ranks((time.perf_counter() - t1) * 1e3)
+        del full
+
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n * args.steps / elapsed
+    mfma_tflops = ALG_MFMA_FLOPS_PER_FRAME * n / (skin_ms * 1e-3) / 1e12 if skin_ms > 0 else 0.0
+    hbm_gbs = (ALG_BYTES_CONST + ALG_BYTES_PER_FRAME * n) / (skin_ms * 1e-3) / 1e9 if skin_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
+        try:
+            traffic = json.load(open(tpath)).get("skin_kernel_hbm_bytes_per_launch_n%d" % n)
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "SMPL FK evals/s + IK iters/s, batch 1024 frames, 1/2/4/8 MI355X",
+        "value": value,
+        "unit": "FK evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "configs[1]: batch-%d random beta/theta FK+LBS per GPU, synthetic SMPL-shaped model "
+                        "(6890 verts, 24 joints, 207 pose / 10 shape PCs), HBM-resident in/out" % n,
+            "frames_per_gpu": n, "parallelism": "frames sharded x%d, no data-path collective" % world,
+        },
+        "roofline": {
+            "kernel": "skin_kernel<2,4> (fused blend-shape GEMM + linear blend skinning)",
+            "bound": "mfma", "achieved": mfma_tflops, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+            "frac": mfma_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": traffic,
+            "kernel_ms": skin_ms, "launches_timed": launches,
+            "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
+                    "algorithmic_bytes_per_launch": ALG_BYTES_CONST + ALG_BYTES_PER_FRAME * n},
+            "note": "batch 1024 in exact fp32 has 152 FLOP/B: the fp32 MFMA pipe binds before HBM (ridge ~20 FLOP/B)",
+        },
+    }
+    if ik is not None:
+        line["ik"] = ik
+    if gather_ms is not None:
+        line["final_gather_ms"] = gather_ms
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(model, n)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

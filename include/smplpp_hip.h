@@ -83,6 +83,12 @@ int smplpp_model_info(const smplpp_model * m, int64_t * vertex_num, int64_t * fa
 int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
               float * xforms, float * rest, int space, void * stream);
 
+/* Measurement hook (bench.py): while enabled, every launch of the fused blend-shape + skinning kernel is bracketed by
+ * HIP events on the stream it is launched on; smplpp_profile_read waits for them, returns the number of launches
+ * and the mean kernel duration in milliseconds since the last read, and clears the record. */
+int smplpp_profile_enable(smplpp_model * m, int enable);
+int smplpp_profile_read(smplpp_model * m, int64_t * launches, double * mean_skin_kernel_ms);
+
 /* Stage-level entry points with the reference's stage semantics on arbitrary inputs (the Tester.cpp KATs feed
  * non-rotation matrices and 4x4 transforms with a non-trivial last row).  Host or device pointers.
  *   BlendShape::blend            src/BlendShape.cpp:620-647     JointRegression::regress   src/JointRegression.cpp:507-532

@@ -56,6 +56,8 @@ def load():
         "smplpp_model_create": [C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(vp)],
         "smplpp_model_destroy": [vp],
         "smplpp_model_info": [vp, i64p, i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "smplpp_profile_enable": [vp, C.c_int],
+        "smplpp_profile_read": [vp, i64p, f64p],
         "smplpp_fk": [vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int, vp],
         "smplpp_stage_blend_shape": [C.c_int, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp],
         "smplpp_stage_joint_regression": [C.c_int, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int, vp],

@@ -102,5 +102,8 @@ struct smplpp_model
   float * Svm = nullptr;       // [V][3][10]  shapedirs, vertex-major (IK Jacobian: beta columns)
   // host mirrors
   std::vector<int32_t> h_parent, h_faces, h_adjOff, h_adjFace;
+  // measurement hook (smplpp_profile_*)
+  bool profiling = false;
+  std::vector<hipEvent_t> prof_events; // begin/end pairs around the fused kernel
   smplpp_hip::Workspace ws;
 };

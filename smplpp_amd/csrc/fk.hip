@@ -361,16 +361,57 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
   HIP_TRY(hipGetLastError());
   if(verts || rest)
   {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if(m->profiling)
+    {
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, st));
+    }
     if(n <= 32)
       HIP_TRY(launch_skin_w<1>(m, n, theta, verts, rest, st));
     else
       HIP_TRY(launch_skin_w<2>(m, n, theta, verts, rest, st));
+    if(m->profiling)
+    {
+      HIP_TRY(hipEventRecord(e1, st));
+      m->prof_events.push_back(e0);
+      m->prof_events.push_back(e1);
+    }
   }
   return SMPLPP_OK;
 }
 } // namespace smplpp_hip
 
 using namespace smplpp_hip;
+
+extern "C" int smplpp_profile_enable(smplpp_model * m, int enable)
+{
+  if(!m) return fail(SMPLPP_ERR_INVALID, "smplpp_profile_enable: null model");
+  m->profiling = enable != 0;
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_profile_read(smplpp_model * m, int64_t * launches, double * mean_ms)
+{
+  if(!m || !launches || !mean_ms) return fail(SMPLPP_ERR_INVALID, "smplpp_profile_read: null argument");
+  HIP_TRY(hipSetDevice(m->device));
+  double total = 0.0;
+  const size_t pairs = m->prof_events.size() / 2;
+  for(size_t i = 0; i < pairs; i++)
+  {
+    float ms = 0.0f;
+    HIP_TRY(hipEventSynchronize(m->prof_events[2 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms, m->prof_events[2 * i], m->prof_events[2 * i + 1]));
+    total += ms;
+    (void)hipEventDestroy(m->prof_events[2 * i]);
+    (void)hipEventDestroy(m->prof_events[2 * i + 1]);
+  }
+  m->prof_events.clear();
+  *launches = (int64_t)pairs;
+  *mean_ms = pairs ? total / (double)pairs : 0.0;
+  return SMPLPP_OK;
+}
 
 extern "C" int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
                          float * xforms, float * rest, int space, void * stream)

@@ -132,57 +132,72 @@ __device__ inline void closest_on_triangle_dev(const float * p, const float * a,
 }
 
 // Block-wide (256 threads) closest point of ONE query against all F faces of one frame's mesh.
-// Ties resolve to the lowest face id.  Results written by thread 0.
+// A point above a convex edge projects ONTO that edge, so exact ties between the two faces sharing it are common
+// (every mocap task with a normal offset); the rule here (the CPU checker uses the same) is: among faces whose squared
+// distance is within 1e-6 (relative) of the minimum, the LOWEST face id wins.  (libigl's own tie order depends on its
+// AABB traversal and is not pinned by any reference test; the closest POINT is the same either way.)
+// Results written by thread 0.
+__device__ inline float tri_sqdist_dev(const float * verts, const int32_t * faces, int64_t f, const float * p, float * c)
+{
+  closest_on_triangle_dev(p, verts + 3 * faces[f * 3], verts + 3 * faces[f * 3 + 1], verts + 3 * faces[f * 3 + 2], c);
+  const float dx = c[0] - p[0], dy = c[1] - p[1], dz = c[2] - p[2];
+  return dx * dx + dy * dy + dz * dz;
+}
+
 __device__ inline void closest_point_block(const float * verts, const int32_t * faces, int64_t F, const float * point,
                                            int64_t * face_out, float * closest_out, float * sq_out)
 {
   const float p[3] = {point[0], point[1], point[2]};
+  __shared__ float s_d[4];
+  __shared__ int s_f[4];
+  __shared__ float s_min;
+  __shared__ int s_best;
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  // pass 1: minimum squared distance
   float best = INFINITY;
-  int bf = 0x7fffffff;
-  float bc[3] = {0.f, 0.f, 0.f};
   for(int64_t f = threadIdx.x; f < F; f += blockDim.x)
   {
     float c[3];
-    closest_on_triangle_dev(p, verts + 3 * faces[f * 3], verts + 3 * faces[f * 3 + 1], verts + 3 * faces[f * 3 + 2], c);
-    const float dx = c[0] - p[0], dy = c[1] - p[1], dz = c[2] - p[2];
-    const float d = dx * dx + dy * dy + dz * dz;
-    if(d < best) // f ascends within a thread, so the first minimum is the lowest id
-    {
-      best = d;
-      bf = (int)f;
-      bc[0] = c[0]; bc[1] = c[1]; bc[2] = c[2];
-    }
+    best = fminf(best, tri_sqdist_dev(verts, faces, f, p, c));
   }
-  for(int off = 32; off > 0; off >>= 1)
-  {
-    const float od = __shfl_down(best, off, 64);
-    const int of = __shfl_down(bf, off, 64);
-    const float o0 = __shfl_down(bc[0], off, 64), o1 = __shfl_down(bc[1], off, 64), o2 = __shfl_down(bc[2], off, 64);
-    if(od < best || (od == best && of < bf))
-    {
-      best = od; bf = of; bc[0] = o0; bc[1] = o1; bc[2] = o2;
-    }
-  }
-  __shared__ float s_d[4], s_c[4][3];
-  __shared__ int s_f[4];
-  const int wave = threadIdx.x >> 6;
-  if((threadIdx.x & 63) == 0)
-  {
-    s_d[wave] = best; s_f[wave] = bf; s_c[wave][0] = bc[0]; s_c[wave][1] = bc[1]; s_c[wave][2] = bc[2];
-  }
+  for(int off = 32; off > 0; off >>= 1) best = fminf(best, __shfl_down(best, off, 64));
+  if((threadIdx.x & 63) == 0) s_d[wave] = best;
   __syncthreads();
   if(threadIdx.x == 0)
   {
-    int w = 0;
-    const int nw = (blockDim.x + 63) >> 6;
-    for(int i = 1; i < nw; i++)
-      if(s_d[i] < s_d[w] || (s_d[i] == s_d[w] && s_f[i] < s_f[w])) w = i;
-    if(face_out) *face_out = s_f[w];
+    float m = s_d[0];
+    for(int i = 1; i < nw; i++) m = fminf(m, s_d[i]);
+    s_min = m;
+  }
+  __syncthreads();
+  // pass 2: lowest face id within the tie band
+  const float thr = s_min * (1.0f + 1e-6f) + 1e-12f;
+  int bf = 0x7fffffff;
+  for(int64_t f = threadIdx.x; f < F; f += blockDim.x)
+  {
+    float c[3];
+    if(tri_sqdist_dev(verts, faces, f, p, c) <= thr && (int)f < bf) bf = (int)f;
+  }
+  for(int off = 32; off > 0; off >>= 1)
+  {
+    const int of = __shfl_down(bf, off, 64);
+    bf = of < bf ? of : bf;
+  }
+  if((threadIdx.x & 63) == 0) s_f[wave] = bf;
+  __syncthreads();
+  if(threadIdx.x == 0)
+  {
+    int b = s_f[0];
+    for(int i = 1; i < nw; i++) b = s_f[i] < b ? s_f[i] : b;
+    s_best = b;
+    float c[3];
+    const float d = tri_sqdist_dev(verts, faces, b, p, c);
+    if(face_out) *face_out = b;
     if(closest_out)
     {
-      closest_out[0] = s_c[w][0]; closest_out[1] = s_c[w][1]; closest_out[2] = s_c[w][2];
+      closest_out[0] = c[0]; closest_out[1] = c[1]; closest_out[2] = c[2];
     }
-    if(sq_out) *sq_out = s_d[w];
+    if(sq_out) *sq_out = d;
   }
   __syncthreads();
 }

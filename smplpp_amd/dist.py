@@ -1,0 +1,94 @@
+"""Multi-GPU: frames (FK) or whole sequences/restarts (IK) are independent, so a job shards embarrassingly — one
+process per GPU, contiguous blocks per rank, NO collective inside the compute — and the only exchange is the final
+gather of results (RCCL over xGMI: `torch.distributed` backend "nccl" is RCCL on ROCm; "gloo" on CPU for tests).
+
+The reference has no counterpart (single process, device index 0: node/node.cpp:372); SURVEY.md §8(e) is the spec.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+import numpy as np
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torchrun environment; (0, 1, 0) when not launched distributed."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of `total` independent units for `rank`; sizes differ by at most one and the
+    blocks tile [0, total) in rank order (strong scaling: total fixed)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(total: int, world: int) -> List[int]:
+    return [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+
+
+def init_process_group(backend: str | None = None):
+    """Initialise torch.distributed from the torchrun environment (MASTER_ADDR defaults to 127.0.0.1)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world, local = env_rank_world()
+    if world == 1:
+        return None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return dist
+
+
+def gather_rows(local, total: int, dst: int = 0):
+    """Final gather of per-rank row blocks (shard_range order) to `dst`: returns the [total, ...] tensor on dst, None
+    elsewhere.  Ragged blocks are padded to the largest shard for the collective and trimmed afterwards.
+    With the nccl backend this is one RCCL all-gather over xGMI (every peer sends on its own link)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sizes = shard_sizes(total, world)
+    if local.shape[0] != sizes[rank]:
+        raise ValueError("rank %d holds %d rows, expected %d" % (rank, local.shape[0], sizes[rank]))
+    mx = max(sizes)
+    pad = local
+    if local.shape[0] < mx:
+        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))])
+    pad = pad.contiguous()
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    if rank != dst:
+        return None
+    return torch.cat([o[:s] for o, s in zip(out, sizes)])
+
+
+def max_over_ranks(value: float) -> float:
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return value
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()

@@ -118,9 +118,20 @@ class SMPL:
         check(_lib.load().smplpp_model_info(self.handle, C.byref(V), C.byref(F), C.byref(w), C.byref(d)))
         return dict(vertex_num=V.value, face_num=F.value, weights_per_vertex=w.value, device=d.value)
 
+    # ---- measurement hook
+    def profileEnable(self, enable=True):
+        check(_lib.load().smplpp_profile_enable(self.handle, int(enable)))
+
+    def profileRead(self):
+        """(launches, mean fused-kernel duration in ms) since the last read; HIP events on the launch stream."""
+        n, ms = C.c_int64(), C.c_double()
+        check(_lib.load().smplpp_profile_read(self.handle, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     # ---- launch (SMPL.h:268, src/SMPL.cpp:671-737)
-    def launch(self, beta, theta, want=("verts", "joints", "xforms", "rest")):
-        """beta [N,10], theta [N,25,3] (row 0 = root translation).  Outputs are kept for the getters."""
+    def launch(self, beta, theta, want=("verts", "joints", "xforms", "rest"), out=None):
+        """beta [N,10], theta [N,25,3] (row 0 = root translation).  Outputs are kept for the getters.
+        `out` (optional dict of preallocated arrays/tensors keyed like `want`) avoids per-call allocation."""
         V = self.vertex_num
         L = _lib.load()
         if _is_torch(beta) != _is_torch(theta):
@@ -141,11 +152,12 @@ class SMPL:
                 raise SmplppError(1, "Cannot launch a SMPL model!")
             mk = lambda *s: np.empty(s, np.float32)
             space = HOST
+        pre = out or {}
         out = {
-            "verts": mk(n, V, 3) if "verts" in want else None,
-            "joints": mk(n, 24, 3) if "joints" in want else None,
-            "xforms": mk(n, 24, 4, 4) if "xforms" in want else None,
-            "rest": mk(n, V, 3) if "rest" in want else None,
+            "verts": pre.get("verts", mk(n, V, 3) if "verts" in want else None),
+            "joints": pre.get("joints", mk(n, 24, 3) if "joints" in want else None),
+            "xforms": pre.get("xforms", mk(n, 24, 4, 4) if "xforms" in want else None),
+            "rest": pre.get("rest", mk(n, V, 3) if "rest" in want else None),
         }
         check(L.smplpp_fk(self.handle, n, _ptr(beta), _ptr(theta), _ptr(out["verts"]), _ptr(out["joints"]),
                           _ptr(out["xforms"]), _ptr(out["rest"]), space, _stream() if space == DEVICE else None))
