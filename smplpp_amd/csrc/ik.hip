@@ -14,6 +14,7 @@
 #include "staging.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 struct smplpp_vposer;
 
@@ -1250,20 +1251,32 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ik_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_shmem));
     attr = true;
   }
+  const bool dbg = getenv("SMPLPP_DEBUG_SYNC") != nullptr;
+#define DBG_SYNC(tag)                                                            \
+  if(dbg)                                                                        \
+  {                                                                              \
+    fprintf(stderr, "[smplpp dbg] it %d: %s ...\n", it, tag);                    \
+    HIP_TRY(hipStreamSynchronize(st));                                           \
+    fprintf(stderr, "[smplpp dbg] it %d: %s done\n", it, tag);                   \
+  }
   for(int it = 0; it < iters; it++)
   {
     const int opt_beta = (optimize_beta_from >= 0 && it >= optimize_beta_from) ? 1 : 0; // node.cpp:655
     const int phi_live = (optimize_beta_from >= 0) ? (it >= optimize_beta_from ? 1 : 0) : 1; // :693-700
     rc = ik_forward_eval(s, opt_beta, phi_live, min_valid, st);
     if(rc) return rc;
+    DBG_SYNC("forward+eval");
     const int beta_dim = opt_beta ? NB : 0;
     ik_solve_kernel<<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(s->ta, s->e, s->vp ? s->Jl : s->J, s->Afull, s->theta, s->beta,
                                                                         s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp,
                                                                         s->vp ? 1 : 0, s->skip, s->e2, s->status, s->xout);
     HIP_TRY(hipGetLastError());
+    DBG_SYNC("solve");
     ik_project_kernel<<<dim3((unsigned)(s->n * K)), dim3(256), 0, st>>>(view_of(m), s->ta, s->verts, s->pts, m->F, K, s->skip);
     HIP_TRY(hipGetLastError());
+    DBG_SYNC("project");
   }
+#undef DBG_SYNC
   if(e_sqnorm)
   {
     hipMemcpyKind kind = space == SMPLPP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;

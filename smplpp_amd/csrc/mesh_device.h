@@ -137,7 +137,10 @@ __device__ inline void closest_on_triangle_dev(const float * p, const float * a,
 // distance is within 1e-6 (relative) of the minimum, the LOWEST face id wins.  (libigl's own tie order depends on its
 // AABB traversal and is not pinned by any reference test; the closest POINT is the same either way.)
 // Results written by thread 0.
-__device__ inline float tri_sqdist_dev(const float * verts, const int32_t * faces, int64_t f, const float * p, float * c)
+// noinline: both passes below must round identically (two inlined copies may contract FMAs differently, and for a
+// query ON the surface the squared distance is pure rounding noise).
+__device__ __attribute__((noinline)) inline float tri_sqdist_dev(const float * verts, const int32_t * faces, int64_t f,
+                                                                    const float * p, float * c)
 {
   closest_on_triangle_dev(p, verts + 3 * faces[f * 3], verts + 3 * faces[f * 3 + 1], verts + 3 * faces[f * 3 + 2], c);
   const float dx = c[0] - p[0], dy = c[1] - p[1], dz = c[2] - p[2];
@@ -151,45 +154,67 @@ __device__ inline void closest_point_block(const float * verts, const int32_t * 
   __shared__ float s_d[4];
   __shared__ int s_f[4];
   __shared__ float s_min;
-  __shared__ int s_best;
+  __shared__ int s_argmin;
   const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  // pass 1: minimum squared distance
+  // pass 1: minimum squared distance (and its face, the fallback if the tie band comes up empty, e.g. NaN input)
   float best = INFINITY;
+  int bf = 0;
   for(int64_t f = threadIdx.x; f < F; f += blockDim.x)
   {
     float c[3];
-    best = fminf(best, tri_sqdist_dev(verts, faces, f, p, c));
+    const float d = tri_sqdist_dev(verts, faces, f, p, c);
+    if(d < best)
+    {
+      best = d;
+      bf = (int)f;
+    }
   }
-  for(int off = 32; off > 0; off >>= 1) best = fminf(best, __shfl_down(best, off, 64));
-  if((threadIdx.x & 63) == 0) s_d[wave] = best;
+  for(int off = 32; off > 0; off >>= 1)
+  {
+    const float od = __shfl_down(best, off, 64);
+    const int of = __shfl_down(bf, off, 64);
+    if(od < best || (od == best && of < bf))
+    {
+      best = od;
+      bf = of;
+    }
+  }
+  if((threadIdx.x & 63) == 0)
+  {
+    s_d[wave] = best;
+    s_f[wave] = bf;
+  }
   __syncthreads();
   if(threadIdx.x == 0)
   {
-    float m = s_d[0];
-    for(int i = 1; i < nw; i++) m = fminf(m, s_d[i]);
-    s_min = m;
+    int w = 0;
+    for(int i = 1; i < nw; i++)
+      if(s_d[i] < s_d[w] || (s_d[i] == s_d[w] && s_f[i] < s_f[w])) w = i;
+    s_min = s_d[w];
+    s_argmin = s_f[w];
   }
   __syncthreads();
   // pass 2: lowest face id within the tie band
   const float thr = s_min * (1.0f + 1e-6f) + 1e-12f;
-  int bf = 0x7fffffff;
+  int cf = 0x7fffffff;
   for(int64_t f = threadIdx.x; f < F; f += blockDim.x)
   {
     float c[3];
-    if(tri_sqdist_dev(verts, faces, f, p, c) <= thr && (int)f < bf) bf = (int)f;
+    if(tri_sqdist_dev(verts, faces, f, p, c) <= thr && (int)f < cf) cf = (int)f;
   }
   for(int off = 32; off > 0; off >>= 1)
   {
-    const int of = __shfl_down(bf, off, 64);
-    bf = of < bf ? of : bf;
+    const int of = __shfl_down(cf, off, 64);
+    cf = of < cf ? of : cf;
   }
-  if((threadIdx.x & 63) == 0) s_f[wave] = bf;
+  __syncthreads(); // s_f is reused
+  if((threadIdx.x & 63) == 0) s_f[wave] = cf;
   __syncthreads();
   if(threadIdx.x == 0)
   {
     int b = s_f[0];
     for(int i = 1; i < nw; i++) b = s_f[i] < b ? s_f[i] : b;
-    s_best = b;
+    if(b < 0 || (int64_t)b >= F) b = s_argmin; // empty band: never index out of range
     float c[3];
     const float d = tri_sqdist_dev(verts, faces, b, p, c);
     if(face_out) *face_out = b;
