@@ -41,6 +41,24 @@ PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
 
 
+def usable_cpus():
+    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(model, frames, budget_s=12.0):
     """Reference libtorch-CPU FK (oracle/_ref) on this box's cores; falls back to the C port.  Checker code is only
     ever used here as the thing timed for the reported baseline — never on the GPU product path."""
@@ -53,6 +71,7 @@ def cpu_baseline(model, frames, budget_s=12.0):
 
         if ref.available():
             R = ref.RefModel(model)
+            ref.lib().ref_set_num_threads(usable_cpus())  # libtorch defaults to every core of the HOST, not our share
             cores = ref.lib().ref_get_num_threads()
             run = lambda: R.fk_launch_only(beta, theta)
             kind = "reference"
@@ -62,8 +81,8 @@ def cpu_baseline(model, frames, budget_s=12.0):
         from oracle import cpu
 
         O = cpu.OracleModel(model)
-        cores = cpu.lib().oracle_max_threads()
-        run = lambda: O.fk(beta, theta, want=("verts",))
+        cores = min(usable_cpus(), cpu.lib().oracle_max_threads())
+        run = lambda: O.fk(beta, theta, want=("verts",), threads=cores)
         kind = "port"
     run()  # warm
     t0 = time.perf_counter()
