@@ -1,0 +1,95 @@
+"""GPU parity of the VPoser decoder (src/VPoser.cpp) and of VPoser-latent IK (BASELINE config 5) through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rotmat_to_axis_angle_sweep_on_gpu():
+    """tests/src/TestVPoser.cpp:45-70 through smplpp_rotmat_to_axis_angle, and against the torch restatement."""
+    from oracle import vposer_torch as VT
+    from smplpp_amd.ik import convertRotMatToAxisAngle
+    from test_oracle_vposer import check_against_independent, sweep_matrices
+
+    mats = sweep_matrices()
+    aa = convertRotMatToAxisAngle(mats.astype(np.float32))
+    assert np.isfinite(aa).all()
+    check_against_independent(aa.astype(np.float64), mats)
+    ref = VT.convert_rotmat_to_axis_angle(torch.from_numpy(mats.astype(np.float32))).numpy()
+    # away from the pi branch the two fp32 evaluations agree closely; near pi sqrt(s + eps) amplifies rounding
+    ang = np.linalg.norm(ref, axis=1)
+    far = ang < np.pi - 0.05
+    assert np.abs(aa[far] - ref[far]).max() < 2e-4
+    assert np.abs(np.abs(aa[~far]) - np.abs(ref[~far])).max() < 5e-3
+
+
+@pytest.fixture(scope="module")
+def decoders():
+    from oracle import vposer_torch as VT
+    from smplpp_amd.ik import VPoserDecoder
+
+    params = VPoserDecoder.synthetic_params()
+    return VPoserDecoder(params), VT.VPoserDecoder(params)
+
+
+def test_decoder_forward_and_jacobian(decoders):
+    gpu, ref = decoders
+    rng = np.random.default_rng(5)
+    z = np.concatenate([rng.random((6, 32)), rng.normal(0, 1.5, (6, 32)), np.zeros((1, 32))]).astype(np.float32)
+    out, jac = gpu.forward(z, want_jac=True)
+    rout, rjac = ref.forward_with_jacobian(z)
+    assert np.abs(out - rout).max() < 1e-5  # tests/src/TestVPoser.cpp:111 uses 1e-6 on the norm for its golden
+    assert np.abs(jac - rjac).max() < 2e-4 * max(1.0, np.abs(rjac).max())
+    out2 = gpu.forward(z)
+    assert np.abs(out2 - out).max() == 0
+
+
+def test_latent_ik_eval_and_step(decoders, synth_model, oracle_synth, golden_ik_synth):
+    """node.cpp:761-772 + :895-904: theta44 = [pos3 | root3 | z32 | aa22 | aa23]; J over the latent layout is J75 pulled
+    back through d(vposer)/dz; the prior adds w_i to A_ii and w_i * theta_i to b_i."""
+    from oracle import cpu
+    from smplpp_amd.ik import IkSolver
+    from smplpp_amd.smpl import SMPL
+
+    gpu, ref = decoders
+    g = golden_ik_synth
+    K = len(g["face_idx"])
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(synth_model)
+    n = 3
+    rng = np.random.default_rng(8)
+    g44 = np.zeros((n, 44), np.float32)
+    g44[:, :3] = [0, 0, 0.05]
+    g44[:, 3:6] = rng.normal(0, 0.05, (n, 3))
+    g44[:, 6:38] = rng.normal(0, 0.7, (n, 32))
+    g44[:, 38:] = rng.normal(0, 0.05, (n, 6))
+    sol = IkSolver(s, n, K, vposer=gpu)
+    assert sol.theta_dim == 44
+    sol.setTasks(face_idx=g["face_idx"], target_pos=g["target_pos"], target_normal=g["target_normal"], phi_limit=np.zeros(K))
+    sol.setConfig(np.zeros((n, 10), np.float32), g44)
+    e, J = sol.eval()
+    assert J.shape == (n, 4 * K, 44 + 2 * K)
+    vout, vjac = ref.forward_with_jacobian(g44[:, 6:38])
+    for f in range(n):
+        th25 = np.zeros((25, 3), np.float32)
+        th25[0], th25[1] = g44[f, :3], g44[f, 3:6]
+        th25[2:23] = vout[f]
+        th25[23], th25[24] = g44[f, 38:41], g44[f, 41:44]
+        ts = cpu.TaskSet(g["face_idx"], g["target_pos"], g["target_normal"], phi_limit=np.zeros(K))
+        r = oracle_synth.ik_eval(np.zeros(10, np.float32), th25, ts)
+        J75 = r["J"]
+        Jl = np.concatenate([J75[:, :6], J75[:, 6:69] @ vjac[f].astype(np.float64), J75[:, 69:75], J75[:, 75:]], axis=1)
+        assert np.abs(r["e"] - e[f]).max() < 5e-5
+        assert np.abs(Jl - J[f]).max() < 1e-3 * max(1.0, np.abs(Jl).max())
+        # one step with the prior (node.cpp:895-904)
+        A, b = cpu.normal_equations(r["e"], Jl, 44, 2 * K, 0, vposer_theta=g44[f])
+        x = cpu.llt_solve(A, b)
+        if f == 0:
+            x0 = x
+    sol.iterate(1)
+    _, t44 = sol.getConfig()
+    assert np.abs((t44[0] - g44[0]) - x0[:44]).max() < 2e-4
+    e2 = sol.iterate(15)
+    assert np.isfinite(e2).all()
