@@ -1,0 +1,283 @@
+// smplpp::SMPL / smplpp::IkTask over the C ABI of libsmplpp_hip.so — header-only C++ shim.
+//
+// Keeps the reference's class names, method names and argument meaning
+// (/root/reference/include/smplpp/SMPL.h:241-269, include/smplpp/IkTask.h:20-84) so that node/node.cpp-style callers
+// re-link against the MI355X engine.  `torch::Tensor` is replaced by the minimal owning host array `smplpp::Tensor`;
+// errors become `smplpp::Exception` like smpl_error (include/smplpp/toolbox/Exception.h:48-49).
+// The one semantic change is the autograd seam: there is no backward(); use IkSolver::eval()/iterate().
+#ifndef SMPLPP_SHIM_SMPL_H
+#define SMPLPP_SHIM_SMPL_H
+
+#include <cctype>
+#include <cstdint>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../smplpp_hip.h"
+
+namespace smplpp
+{
+constexpr int64_t JOINT_NUM = SMPLPP_JOINT_NUM;
+constexpr int64_t SHAPE_BASIS_DIM = SMPLPP_SHAPE_BASIS_DIM;
+constexpr int64_t POSE_BASIS_DIM = SMPLPP_POSE_BASIS_DIM;
+constexpr int64_t LATENT_DIM = SMPLPP_LATENT_DIM;
+
+class Exception : public std::runtime_error
+{
+public:
+  Exception(const std::string & module, const std::string & msg) : std::runtime_error("[" + module + "] " + msg) {}
+};
+inline void check(int rc, const char * module)
+{
+  if(rc != SMPLPP_OK) throw Exception(module, smplpp_last_error());
+}
+
+// Device naming follows node/node.cpp:360-371: "CUDA"/"HIP" with an explicit index selects the GPU engine.
+struct Device
+{
+  std::string type = "CUDA";
+  int index = 0;
+  Device() = default;
+  Device(const std::string & t, int i) : type(t), index(i) {}
+  bool has_index() const { return index >= 0; }
+};
+
+// Minimal owning row-major fp32 array (stands in for torch::Tensor at this boundary).
+struct Tensor
+{
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  Tensor() = default;
+  explicit Tensor(std::vector<int64_t> s, float fill = 0.0f) : shape(std::move(s)), data((size_t)numel_of(shape), fill) {}
+  static int64_t numel_of(const std::vector<int64_t> & s)
+  {
+    int64_t n = 1;
+    for(auto d : s) n *= d;
+    return n;
+  }
+  int64_t numel() const { return numel_of(shape); }
+  int64_t size(int i) const { return shape.at(i); }
+  float * ptr() { return data.data(); }
+  const float * ptr() const { return data.data(); }
+};
+
+namespace detail
+{
+// Just enough JSON for the model files scripts/preprocess.py writes: an object of (nested) numeric arrays.
+struct JsonArrays
+{
+  std::map<std::string, std::vector<double>> values;
+  std::map<std::string, std::vector<int64_t>> shapes;
+  explicit JsonArrays(const std::string & path)
+  {
+    std::ifstream f(path, std::ios::binary);
+    if(!f) throw Exception("SMPL", "Cannot initialize a SMPL model!"); // src/SMPL.cpp:616
+    std::stringstream ss;
+    ss << f.rdbuf();
+    s_ = ss.str();
+    skip();
+    expect('{');
+    for(;;)
+    {
+      skip();
+      if(peek() == '}') break;
+      std::string key = str();
+      skip();
+      expect(':');
+      std::vector<int64_t> shape;
+      std::vector<double> vals;
+      array(vals, shape, 0);
+      values[key] = std::move(vals);
+      shapes[key] = std::move(shape);
+      skip();
+      if(peek() == ',') p_++;
+    }
+  }
+
+private:
+  std::string s_;
+  size_t p_ = 0;
+  char peek() const { return p_ < s_.size() ? s_[p_] : '\0'; }
+  void skip()
+  {
+    while(p_ < s_.size() && std::isspace((unsigned char)s_[p_])) p_++;
+  }
+  void expect(char c)
+  {
+    if(peek() != c) throw Exception("SMPL", std::string("model json: expected '") + c + "'");
+    p_++;
+  }
+  std::string str()
+  {
+    expect('"');
+    size_t b = p_;
+    while(p_ < s_.size() && s_[p_] != '"') p_++;
+    std::string r = s_.substr(b, p_ - b);
+    p_++;
+    return r;
+  }
+  void array(std::vector<double> & vals, std::vector<int64_t> & shape, size_t depth)
+  {
+    skip();
+    if(peek() != '[')
+    {
+      char * end = nullptr;
+      vals.push_back(std::strtod(s_.c_str() + p_, &end));
+      p_ = (size_t)(end - s_.c_str());
+      return;
+    }
+    p_++;
+    int64_t n = 0;
+    for(;;)
+    {
+      skip();
+      if(peek() == ']')
+      {
+        p_++;
+        break;
+      }
+      array(vals, shape, depth + 1);
+      n++;
+      skip();
+      if(peek() == ',') p_++;
+    }
+    if(shape.size() <= depth) shape.resize(depth + 1, 0);
+    shape[depth] = n;
+  }
+};
+} // namespace detail
+
+class SMPL
+{
+public:
+  SMPL() = default;
+  ~SMPL() { smplpp_model_destroy(m_); }
+  SMPL(const SMPL &) = delete;
+  SMPL & operator=(const SMPL &) = delete;
+
+  void setDevice(const Device & device)
+  {
+    if(!device.has_index()) throw Exception("SMPL", "Failed to fetch device index!"); // src/SMPL.cpp:289-297
+    if(device.type == "CPU" || device.type == "cpu") throw Exception("SMPL", "libsmplpp_hip has no CPU engine");
+    device_ = device;
+  }
+  const Device & getDevice() const { return device_; }
+  void setModelPath(const std::string & modelPath) { path_ = modelPath; }
+
+  // SMPL::init (src/SMPL.cpp:560-643): parse the .json written by scripts/preprocess.py and create the engine model.
+  void init()
+  {
+    detail::JsonArrays j(path_);
+    auto f32 = [&](const char * k) {
+      auto it = j.values.find(k);
+      if(it == j.values.end()) throw Exception("SMPL", std::string("model json lacks ") + k);
+      return std::vector<float>(it->second.begin(), it->second.end());
+    };
+    std::vector<float> vt = f32("vertices_template"), S = f32("shape_blend_shapes"), P = f32("pose_blend_shapes"),
+                       Jr = f32("joint_regressor"), W = f32("weights");
+    const auto & kv = j.values.at("kinematic_tree");
+    const auto & fv = j.values.at("face_indices");
+    std::vector<int64_t> kin(kv.begin(), kv.end());
+    std::vector<int32_t> faces(fv.begin(), fv.end());
+    initFromArrays((int64_t)vt.size() / 3, (int64_t)faces.size() / 3, vt.data(), S.data(), P.data(), Jr.data(), W.data(),
+                   kin.data(), faces.data());
+    faces1_ = faces;
+  }
+  void initFromArrays(int64_t V, int64_t F, const float * vt, const float * S, const float * P, const float * Jreg,
+                      const float * W, const int64_t * kintree, const int32_t * faces1)
+  {
+    smplpp_model_destroy(m_);
+    m_ = nullptr;
+    check(smplpp_model_create(V, F, vt, S, P, Jreg, W, kintree, faces1, device_.index, &m_), "SMPL");
+    V_ = V;
+    F_ = F;
+    faces1_.assign(faces1, faces1 + F * 3);
+  }
+
+  // SMPL::launch (src/SMPL.cpp:671-737): beta [N,10], theta [N,25,3] (row 0 = root translation)
+  void launch(const Tensor & beta, const Tensor & theta)
+  {
+    if(!m_ || beta.shape.size() != 2 || beta.size(1) != SHAPE_BASIS_DIM || theta.shape.size() != 3
+       || theta.size(0) != beta.size(0) || theta.size(1) != JOINT_NUM + 1 || theta.size(2) != 3)
+      throw Exception("SMPL", "Cannot launch a SMPL model!");
+    const int64_t n = beta.size(0);
+    verts_ = Tensor({n, V_, 3});
+    rest_ = Tensor({n, V_, 3});
+    joints_ = Tensor({n, JOINT_NUM, 3});
+    xforms_ = Tensor({n, JOINT_NUM, 4, 4});
+    check(smplpp_fk(m_, n, beta.ptr(), theta.ptr(), verts_.ptr(), joints_.ptr(), xforms_.ptr(), rest_.ptr(), SMPLPP_HOST, nullptr),
+          "SMPL");
+  }
+
+  Tensor getVertex() const { return need(verts_); }       // [N,6890,3] copy (src/SMPL.cpp:492-506)
+  Tensor getRestShape() const { return need(rest_); }
+  Tensor getRestJoint() const { return need(joints_); }   // [N,24,3]
+  Tensor getTransformation() const { return need(xforms_); }
+  // batch 0 only, like src/LinearBlendSkinning.cpp:419-427
+  Tensor getVertexRaw(int64_t idx) const
+  {
+    need(verts_);
+    Tensor t({3});
+    for(int x = 0; x < 3; x++) t.data[x] = verts_.data[(size_t)idx * 3 + x];
+    return t;
+  }
+  const std::vector<int32_t> & getFaceIndex() const { return faces1_; } // [F,3] 1-based (src/SMPL.cpp:418-433)
+  std::vector<int32_t> getFaceIndexRaw(int64_t idx) const { return {faces1_[idx * 3], faces1_[idx * 3 + 1], faces1_[idx * 3 + 2]}; }
+  Tensor calcNormal(int64_t faceIdx) const // src/SMPL.cpp:518-525 (batch 0)
+  {
+    need(verts_);
+    Tensor t({3});
+    check(smplpp_face_normals(m_, 1, verts_.ptr(), 1, &faceIdx, t.ptr(), SMPLPP_HOST, nullptr), "SMPL");
+    return t;
+  }
+  Tensor calcVertexNormal(int64_t idx) const // src/SMPL.cpp:527-535 (batch 0)
+  {
+    need(verts_);
+    Tensor t({3});
+    check(smplpp_vertex_normals(m_, 1, verts_.ptr(), 1, &idx, t.ptr(), SMPLPP_HOST, nullptr), "SMPL");
+    return t;
+  }
+  std::map<int64_t, float> getAdjacentFaces(int64_t idx) const // src/SMPL.cpp:537-540
+  {
+    int64_t faces[64], cnt = 0;
+    float w[64];
+    check(smplpp_adjacent_faces(m_, idx, 64, faces, w, &cnt), "SMPL");
+    std::map<int64_t, float> r;
+    for(int64_t i = 0; i < cnt && i < 64; i++) r[faces[i]] = w[i];
+    return r;
+  }
+  // SMPL::out (src/SMPL.cpp:757-790): Wavefront OBJ of frame `index`
+  void out(int64_t index, const std::string & path) const
+  {
+    need(verts_);
+    std::ofstream f(path);
+    for(int64_t v = 0; v < V_; v++)
+      f << "v " << verts_.data[((size_t)index * V_ + v) * 3] << " " << verts_.data[((size_t)index * V_ + v) * 3 + 1] << " "
+        << verts_.data[((size_t)index * V_ + v) * 3 + 2] << "\n";
+    for(int64_t t = 0; t < F_; t++) f << "f " << faces1_[t * 3] << " " << faces1_[t * 3 + 1] << " " << faces1_[t * 3 + 2] << "\n";
+  }
+
+  smplpp_model * handle() const { return m_; }
+  int64_t vertexNum() const { return V_; }
+
+private:
+  static const Tensor & need(const Tensor & t)
+  {
+    if(t.data.empty()) throw Exception("LinearBlendSknning", "Failed to get vertices of new pose!"); // LinearBlendSkinning.cpp:413
+    return t;
+  }
+  smplpp_model * m_ = nullptr;
+  Device device_;
+  std::string path_;
+  int64_t V_ = 0, F_ = 0;
+  std::vector<int32_t> faces1_;
+  Tensor verts_, rest_, joints_, xforms_;
+};
+} // namespace smplpp
+#endif

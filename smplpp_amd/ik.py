@@ -105,8 +105,10 @@ class VPoserDecoder:
 
     @staticmethod
     def synthetic_params(seed=3):
-        """torch::nn::Linear default init (U(-1/sqrt(in), 1/sqrt(in))) with a fixed seed: the real VPoser weights are
-        license-gated and absent."""
+        """Stand-in weights (the real VPoser parameters are license-gated and absent, SURVEY.md §8c): torch::nn::Linear
+        default init (U(-1/sqrt(in), 1/sqrt(in))) with a fixed seed, except that the last layer is scaled by 0.3 and
+        biased to the identity rotation in the 6D representation ([1,0, 0,1, 0,0] per joint) so that latents near zero
+        decode to moderate poses, like a trained pose prior does, instead of uniformly random rotations."""
         rng = np.random.default_rng(seed)
         out = {}
         for (w, b), (o, i) in zip((("decoder_net.0.weight", "decoder_net.0.bias"), ("decoder_net.3.weight", "decoder_net.3.bias"),
@@ -114,6 +116,9 @@ class VPoserDecoder:
             k = 1.0 / np.sqrt(i)
             out[w] = rng.uniform(-k, k, (o, i)).astype(np.float32)
             out[b] = rng.uniform(-k, k, (o,)).astype(np.float32)
+        out["decoder_net.5.weight"] *= np.float32(0.3)
+        out["decoder_net.5.bias"] = (np.float32(0.3) * out["decoder_net.5.bias"]
+                                     + np.tile(np.array([1, 0, 0, 1, 0, 0], np.float32), 21)).astype(np.float32)
         return out
 
     def forward(self, latent, want_jac=False):
