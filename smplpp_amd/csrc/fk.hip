@@ -261,7 +261,11 @@ __global__ __launch_bounds__(256, 2) void skin_kernel(const float * __restrict__
     jidx[i] = wIdx[v * MAXW + i];
     jw[i] = wVal[v * MAXW + i];
   }
-  const float wsum = wSum[v];
+  // cart = h[:3] / h[3] (src/LinearBlendSkinning.cpp:545-550) with h[3] = sum_j W[v,j], constant per vertex:
+  // one reciprocal per lane instead of three IEEE divisions per (frame, vertex) — differs by <= 1 ulp (6e-8 m at 1 m)
+  const float winv = 1.0f / wSum[v];
+  float * vout = verts ? verts + v * 3 : nullptr;
+  float * rout = rest ? rest + v * 3 : nullptr;
 #pragma unroll
   for(int t = 0; t < FT; t++)
 #pragma unroll
@@ -271,14 +275,14 @@ __global__ __launch_bounds__(256, 2) void skin_kernel(const float * __restrict__
       const int64_t f = f0 + fl;
       if(f >= n) continue;
       const float rx = acc[t][0][r], ry = acc[t][1][r], rz = acc[t][2][r];
-      if(rest)
+      if(rout)
       {
-        float * o = rest + (f * V + v) * 3;
+        float * o = rout + f * V * 3;
         o[0] = rx;
         o[1] = ry;
         o[2] = rz;
       }
-      if(!verts) continue;
+      if(!vout) continue;
       // M = sum_j W[v,j] G'_j (src/LinearBlendSkinning.cpp:463), rows of [A | b]
       float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0, m2 = m0;
       const float * g = sG + fl * (NJ * 12);
@@ -292,14 +296,14 @@ __global__ __launch_bounds__(256, 2) void skin_kernel(const float * __restrict__
         m1.x += w * g1.x; m1.y += w * g1.y; m1.z += w * g1.z; m1.w += w * g1.w;
         m2.x += w * g2.x; m2.y += w * g2.y; m2.z += w * g2.z; m2.w += w * g2.w;
       }
-      // h = M [rest; 1] (:465-467); cart = h[:3] / h[3] (:545-550) with h[3] = sum_j W[v,j]; + root (:475)
+      // h = M [rest; 1] (:465-467); cart = h[:3] * (1 / h[3]); + root (:475)
       const float hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
       const float hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
       const float hz = ((m2.x * rx + m2.y * ry) + m2.z * rz) + m2.w;
-      float * o = verts + (f * V + v) * 3;
-      o[0] = hx / wsum + sRoot[fl * 3 + 0];
-      o[1] = hy / wsum + sRoot[fl * 3 + 1];
-      o[2] = hz / wsum + sRoot[fl * 3 + 2];
+      float * o = vout + f * V * 3;
+      o[0] = hx * winv + sRoot[fl * 3 + 0];
+      o[1] = hy * winv + sRoot[fl * 3 + 1];
+      o[2] = hz * winv + sRoot[fl * 3 + 2];
     }
 }
 

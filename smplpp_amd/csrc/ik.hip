@@ -5,8 +5,9 @@
 //                    forward-mode Jacobian of only the vertices the tasks touch: per frame the chain
 //                    derivatives dG'_i/dtheta_{j,k} of all 72 rotation columns are built once in LDS (83 KB), then every
 //                    task reads them for its face vertices (and their 1-rings when a normal is involved).
-//  ik_solve_kernel   node.cpp:883-968: A = J^T J + damping in fp64, Cholesky (packed lower-triangular in LDS, fp64) or
-//                    the box QP by a primal active set, config update, query points for the re-projection.
+//  ik_solve_kernel   node.cpp:883-968: A = J^T J + damping in fp64 built straight from J staged through LDS, right-looking
+//                    Cholesky of the packed lower-triangular augmented system in LDS (fp64) or the box QP by a primal
+//                    active set around it, config update, query points for the re-projection.
 //  ik_project_kernel node.cpp:970-1001: closest point on the posed mesh (brute force over 13776 faces, one workgroup
 //                    per query), new face id and area-ratio weights.
 // All fp32 where the reference is fp32 (FK, task geometry, autograd gradients), fp64 where it is fp64 (Eigen).
@@ -626,40 +627,43 @@ __device__ inline int tri_idx(int i, int j)
 {
   return i * (i + 1) / 2 + j; // i >= j
 }
+__device__ inline void tri_unpack(int item, int & i, int & j)
+{
+  i = (int)((sqrt(8.0 * (double)item + 1.0) - 1.0) * 0.5);
+  while(tri_idx(i + 1, 0) <= item) i++;
+  while(tri_idx(i, 0) > item) i--;
+  j = item - tri_idx(i, 0);
+}
 
-// In-place Cholesky of the packed lower-triangular (nf+1)x(nf+1) augmented matrix [A b; b' *] held in LDS:
-// the last row becomes y = L^-1 b.  Left-looking, one barrier per column.  Returns non-zero pivot failure via *bad.
+// In-place right-looking Cholesky of the packed lower-triangular (nf+1)x(nf+1) augmented matrix [A b; b' *] held in
+// LDS (fp64): the last row becomes y = L^-1 b, so forward substitution is free.  Every thread of the workgroup
+// updates the trailing sub-matrix; two barriers per column.
 __device__ inline void chol_aug(double * M, int nf, int * bad)
 {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
   for(int j = 0; j < nf; j++)
   {
     double d = M[tri_idx(j, j)];
-    for(int k = 0; k < j; k++)
-    {
-      const double l = M[tri_idx(j, k)];
-      d -= l * l;
-    }
     if(!(d > 0.0))
     {
       if(tid == 0) *bad = 1;
       d = 1.0;
     }
     const double piv = sqrt(d);
-    double mine[1];
-    int rows[1];
-    int cnt = 0;
-    for(int i = j + 1 + tid; i <= nf; i += blockDim.x) // nf + 1 rows: at most one row per thread when nf < blockDim
+    __syncthreads(); // everyone has read the pivot
+    for(int i = j + tid; i <= nf; i += nt) M[tri_idx(i, j)] = (i == j) ? piv : M[tri_idx(i, j)] / piv;
+    __syncthreads();
+    // trailing update: rows i in (j, nf], columns k in (j, i]
+    const int m = nf - j; // rows below j
+    const int cnt = m * (m + 1) / 2;
+    for(int item = tid; item < cnt; item += nt)
     {
-      double s = M[tri_idx(i, j)];
-      for(int k = 0; k < j; k++) s -= M[tri_idx(i, k)] * M[tri_idx(j, k)];
-      mine[0] = s / piv;
-      rows[0] = i;
-      cnt = 1;
+      int a, b;
+      tri_unpack(item, a, b);
+      const int i = j + 1 + a, k = j + 1 + b;
+      if(k == nf) continue; // the (nf, nf) corner is never used
+      M[tri_idx(i, k)] -= M[tri_idx(i, j)] * M[tri_idx(k, j)];
     }
-    __syncthreads(); // every read of column j's old content and of row j is done
-    if(cnt) M[tri_idx(rows[0], j)] = mine[0];
-    if(tid == 0) M[tri_idx(j, j)] = piv;
     __syncthreads();
   }
 }
@@ -680,27 +684,31 @@ __device__ inline void back_subst(const double * M, int nf, double * xs)
   }
 }
 
-// One workgroup per frame.  LDS: packed (MAXD+1)(MAXD+2)/2 doubles + vectors.
+// One workgroup per frame.  Everything is built from J (staged through LDS in row chunks) — no D x D matrix in HBM.
+// LDS (doubles): M packed (D+1)(D+2)/2 | Jc [chunk][D] | xs, xfull, diag, bpri, lo, hi [D each] | rowv [rows] ; ints idx, state [D].
 __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const double * __restrict__ e_all, const double * __restrict__ J_all,
-                                                       double * __restrict__ Afull_all, float * __restrict__ theta, float * __restrict__ beta,
-                                                       float * __restrict__ pts, int K, int theta_dim, int beta_dim, int phi_live,
-                                                       int enable_qp, int use_prior, const int * __restrict__ skip,
-                                                       double * __restrict__ e2_out, int * __restrict__ status, double * __restrict__ x_out)
+                                                       float * __restrict__ theta, float * __restrict__ beta, float * __restrict__ pts,
+                                                       int K, int theta_dim, int beta_dim, int phi_live, int enable_qp, int use_prior,
+                                                       int chunk_rows, const int * __restrict__ skip, double * __restrict__ e2_out,
+                                                       int * __restrict__ status, double * __restrict__ x_out)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int64_t f = blockIdx.x;
   const int tid = threadIdx.x;
   const int D = theta_dim + 2 * K + beta_dim, rows = 4 * K;
   const int64_t tb = f * K;
-  double * M = sm;                                   // packed augmented matrix
-  double * xs = sm + (MAXD + 1) * (MAXD + 2) / 2;    // [MAXD] solution on the free set
-  double * xfull = xs + MAXD;                        // [MAXD]
-  double * bfull = xfull + MAXD;                     // [MAXD]
-  double * lo = bfull + MAXD;                        // [MAXD]
-  double * hi = lo + MAXD;                           // [MAXD]
-  int * idx = reinterpret_cast<int *>(hi + MAXD);    // [MAXD] free-set -> full index
-  int * state = idx + MAXD;                          // [MAXD] 0 free, -1 at lo, +1 at hi, 2 pinned
-  __shared__ int s_bad, s_nf, s_block, s_bside, s_rel, s_done;
+  double * M = sm;
+  double * Jc = M + (D + 1) * (D + 2) / 2;
+  double * xs = Jc + chunk_rows * D;
+  double * xfull = xs + D;
+  double * diag = xfull + D;
+  double * bpri = diag + D;
+  double * lo = bpri + D;
+  double * hi = lo + D;
+  double * rowv = hi + D;
+  int * idx = reinterpret_cast<int *>(rowv + rows);
+  int * state = idx + D; // 0 free, -1 at lo, +1 at hi, 2 pinned (empty box)
+  __shared__ int s_bad, s_nf, s_block, s_bside, s_done, s_anybound;
   __shared__ double s_alpha, s_e2;
   if(skip[f])
   {
@@ -710,44 +718,30 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   }
   const double * e = e_all + f * rows;
   const double * J = J_all + f * rows * (int64_t)D;
-  double * Af = Afull_all + f * (int64_t)D * D;
 
-  // A = J^T J, b = J^T e (node.cpp:884-885), fp64
-  for(int item = tid; item < D * D; item += 256)
-  {
-    const int i = item / D, j = item % D;
-    if(j > i) continue;
-    double s = 0.0;
-    for(int r = 0; r < rows; r++) s += J[(int64_t)r * D + i] * J[(int64_t)r * D + j];
-    Af[(int64_t)i * D + j] = s;
-    Af[(int64_t)j * D + i] = s;
-  }
-  for(int i = tid; i < D; i += 256)
-  {
-    double s = 0.0;
-    for(int r = 0; r < rows; r++) s += J[(int64_t)r * D + i] * e[r];
-    bfull[i] = s;
-  }
   if(tid == 0)
   {
     double s = 0.0;
     for(int r = 0; r < rows; r++) s += e[r] * e[r];
     s_e2 = s;
     s_bad = 0;
+    s_done = 0;
     if(e2_out) e2_out[f] = s;
   }
   __syncthreads();
   for(int i = tid; i < D; i += 256)
   {
     const double reg = (i < theta_dim) ? 1e-3 : (i < theta_dim + 2 * K ? 1e-1 : 1e-3); // node.cpp:887-892
-    double a = Af[(int64_t)i * D + i] + reg + s_e2;                                       // :893
+    double dg = reg + s_e2;                                                               // :893
+    double bp = 0.0;
     if(use_prior && i < theta_dim) // :895-904 (VPoser latent layout)
     {
       const double w = (i < 6) ? 0.0 : (i >= theta_dim - 6 ? 1e3 : 1e-5);
-      a += w;
-      bfull[i] += w * (double)theta[f * theta_dim + i];
+      dg += w;
+      bp = w * (double)theta[f * theta_dim + i];
     }
-    Af[(int64_t)i * D + i] = a;
+    diag[i] = dg;
+    bpri[i] = bp;
     // bounds (node.cpp:916-928); theta is free
     double l = -1e30, h = 1e30;
     int st = 0;
@@ -785,105 +779,139 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   {
     if(tid == 0)
     {
-      int nf = 0;
+      int nf = 0, anyb = 0;
       for(int i = 0; i < D; i++)
+      {
         if(state[i] == 0) idx[nf++] = i;
+        if((state[i] == -1 || state[i] == 1) && xfull[i] != 0.0) anyb = 1;
+      }
       s_nf = nf;
+      s_anybound = anyb;
       s_alpha = 1.0;
       s_block = -1;
-      s_rel = -1;
-      s_done = 0;
     }
     __syncthreads();
     const int nf = s_nf;
-    // gather the free-set system; rhs = b_F + A_FB x_B
-    for(int item = tid; item < (nf + 1) * (nf + 2) / 2; item += 256)
+    const int nitem = (nf + 1) * (nf + 2) / 2;
+    // rowv = e + J_B x_B  (b_F + A_FB x_B = J_F^T rowv); A = J^T J, b = J^T e (node.cpp:884-885), fp64
+    for(int r = tid; r < rows; r += 256)
     {
-      // invert tri_idx
-      int i = (int)((sqrt(8.0 * item + 1.0) - 1.0) * 0.5);
-      while(tri_idx(i + 1, 0) <= item) i++;
-      while(tri_idx(i, 0) > item) i--;
-      const int j = item - tri_idx(i, 0);
-      double v;
-      if(i < nf)
-        v = Af[(int64_t)idx[i] * D + idx[j]];
-      else if(j < nf)
-      {
-        double r = bfull[idx[j]];
+      double s = e[r];
+      if(s_anybound)
         for(int q = 0; q < D; q++)
-          if(state[q] == -1 || state[q] == 1) r += Af[(int64_t)idx[j] * D + q] * xfull[q];
-        v = r;
+          if(state[q] == -1 || state[q] == 1) s += J[(int64_t)r * D + q] * xfull[q];
+      rowv[r] = s;
+    }
+    for(int item = tid; item < nitem; item += 256) M[item] = 0.0;
+    for(int c0 = 0; c0 < rows; c0 += chunk_rows)
+    {
+      const int cr = (rows - c0 < chunk_rows) ? rows - c0 : chunk_rows;
+      __syncthreads();
+      for(int q = tid; q < cr * D; q += 256) Jc[q] = J[(int64_t)c0 * D + q];
+      __syncthreads();
+      for(int item = tid; item < nitem - 1; item += 256) // the (nf, nf) corner is not needed
+      {
+        int i, j;
+        tri_unpack(item, i, j);
+        const int cj = idx[j];
+        double s = 0.0;
+        if(i < nf)
+        {
+          const int ci = idx[i];
+          for(int r = 0; r < cr; r++) s += Jc[r * D + ci] * Jc[r * D + cj];
+        }
+        else
+          for(int r = 0; r < cr; r++) s += Jc[r * D + cj] * rowv[c0 + r];
+        M[item] += s;
       }
-      else
-        v = 0.0;
-      M[item] = v;
+    }
+    __syncthreads();
+    for(int a = tid; a < nf; a += 256)
+    {
+      M[tri_idx(a, a)] += diag[idx[a]];
+      M[tri_idx(nf, a)] += bpri[idx[a]];
     }
     __syncthreads();
     chol_aug(M, nf, &s_bad);
     back_subst(M, nf, xs);
-    // candidate x_F = -xs ; ratio test against the box
-    if(enable_qp)
-    {
-      if(tid == 0)
-      {
-        double alpha = 1.0;
-        int block = -1, bside = 0;
-        for(int a = 0; a < nf; a++)
-        {
-          const int i = idx[a];
-          const double xn = -xs[a], dx = xn - xfull[i];
-          if(xn > hi[i] + 1e-14 && dx > 0)
-          {
-            const double al = (hi[i] - xfull[i]) / dx;
-            if(al < alpha) { alpha = al; block = a; bside = 1; }
-          }
-          else if(xn < lo[i] - 1e-14 && dx < 0)
-          {
-            const double al = (lo[i] - xfull[i]) / dx;
-            if(al < alpha) { alpha = al; block = a; bside = -1; }
-          }
-        }
-        s_alpha = alpha;
-        s_block = block;
-        s_bside = bside;
-      }
-      __syncthreads();
-      for(int a = tid; a < nf; a += 256) xfull[idx[a]] += s_alpha * (-xs[a] - xfull[idx[a]]);
-      __syncthreads();
-      if(tid == 0)
-      {
-        if(s_block >= 0)
-        {
-          const int i = idx[s_block];
-          state[i] = s_bside;
-          xfull[i] = s_bside > 0 ? hi[i] : lo[i];
-        }
-        else
-        {
-          double worst = 1e-12;
-          int rel = -1;
-          for(int i = 0; i < D; i++)
-          {
-            if(state[i] != -1 && state[i] != 1) continue;
-            double g = bfull[i];
-            for(int q = 0; q < D; q++) g += Af[(int64_t)i * D + q] * xfull[q];
-            const double viol = (state[i] < 0) ? -g : g;
-            if(viol > worst) { worst = viol; rel = i; }
-          }
-          if(rel < 0)
-            s_done = 1;
-          else
-            state[rel] = 0;
-        }
-      }
-      __syncthreads();
-      if(s_done) break;
-    }
-    else
+    if(!enable_qp)
     {
       for(int a = tid; a < nf; a += 256) xfull[idx[a]] = -xs[a]; // x = -LLT(A)^-1 b (node.cpp:938)
       __syncthreads();
+      break;
     }
+    // candidate x_F = -xs ; ratio test against the box
+    if(tid == 0)
+    {
+      double alpha = 1.0;
+      int block = -1, bside = 0;
+      for(int a = 0; a < nf; a++)
+      {
+        const int i = idx[a];
+        const double xn = -xs[a], dx = xn - xfull[i];
+        if(xn > hi[i] + 1e-14 && dx > 0)
+        {
+          const double al = (hi[i] - xfull[i]) / dx;
+          if(al < alpha) { alpha = al; block = a; bside = 1; }
+        }
+        else if(xn < lo[i] - 1e-14 && dx < 0)
+        {
+          const double al = (lo[i] - xfull[i]) / dx;
+          if(al < alpha) { alpha = al; block = a; bside = -1; }
+        }
+      }
+      s_alpha = alpha;
+      s_block = block;
+      s_bside = bside;
+    }
+    __syncthreads();
+    for(int a = tid; a < nf; a += 256) xfull[idx[a]] += s_alpha * (-xs[a] - xfull[idx[a]]);
+    __syncthreads();
+    if(s_block >= 0)
+    {
+      if(tid == 0)
+      {
+        const int i = idx[s_block];
+        state[i] = s_bside;
+        xfull[i] = s_bside > 0 ? hi[i] : lo[i];
+      }
+      __syncthreads();
+      continue;
+    }
+    // multipliers of the bound variables: g = A x + b = J^T (e + J x) + diag x + bpri
+    for(int r = tid; r < rows; r += 256)
+    {
+      double s = e[r];
+      for(int q = 0; q < D; q++)
+        if(state[q] != 2) s += J[(int64_t)r * D + q] * xfull[q];
+      rowv[r] = s;
+    }
+    __syncthreads();
+    for(int i = tid; i < D; i += 256)
+    {
+      double viol = 0.0;
+      if(state[i] == -1 || state[i] == 1)
+      {
+        double g = diag[i] * xfull[i] + bpri[i];
+        for(int r = 0; r < rows; r++) g += J[(int64_t)r * D + i] * rowv[r];
+        viol = (state[i] < 0) ? -g : g; // at lo need g >= 0; at hi need g <= 0
+      }
+      xs[i] = viol; // xs is free between solves
+    }
+    __syncthreads();
+    if(tid == 0)
+    {
+      double worst = 1e-12;
+      int rel = -1;
+      for(int i = 0; i < D; i++)
+        if(xs[i] > worst) { worst = xs[i]; rel = i; }
+      if(rel < 0)
+        s_done = 1;
+      else
+        state[rel] = 0;
+    }
+    __syncthreads();
+    if(s_done) break;
   }
   if(tid == 0) status[f] = s_bad ? 1 : ((enable_qp && !s_done) ? 2 : 0);
   const bool ok = !s_bad;
@@ -911,7 +939,7 @@ __global__ __launch_bounds__(256) void ik_project_kernel(ModelView mv, TaskArray
   const float * verts = verts_all + f * mv.V * 3;
   __shared__ int64_t s_face;
   __shared__ float s_cl[3];
-  closest_point_block(verts, mv.faces, F, pts + (int64_t)blockIdx.x * 3, &s_face, s_cl, nullptr);
+  closest_point_block(verts, mv.faces, F, pts + (int64_t)blockIdx.x * 3, &s_face, s_cl, nullptr, ta.face[blockIdx.x]);
   if(threadIdx.x == 0)
   {
     const int face = (int)s_face;
@@ -962,7 +990,7 @@ struct smplpp_ik
   TaskArrays ta{};
   float *theta = nullptr, *beta = nullptr, *theta25 = nullptr, *vout = nullptr, *vjac = nullptr;
   float *verts = nullptr, *rest = nullptr, *joints = nullptr, *poserot = nullptr, *pts = nullptr;
-  double *e = nullptr, *J = nullptr, *Jl = nullptr, *Afull = nullptr, *e2 = nullptr, *xout = nullptr;
+  double *e = nullptr, *J = nullptr, *Jl = nullptr, *e2 = nullptr, *xout = nullptr;
   int32_t * ring = nullptr;
   uint8_t * map = nullptr;
   int *skip = nullptr, *status = nullptr;
@@ -1056,7 +1084,6 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   A_(pts, nk * 3);
   A_(e, nk * 4);
   A_(J, nk * 4 * Dmax);
-  A_(Afull, (size_t)n * Dmax * Dmax);
   A_(e2, (size_t)n);
   A_(xout, (size_t)n * Dmax);
   A_(ring, nk * (MAXRING + 1));
@@ -1244,11 +1271,10 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int K = (int)s->K;
-  const size_t solve_shmem = sizeof(double) * ((size_t)(MAXD + 1) * (MAXD + 2) / 2 + 5 * MAXD) + sizeof(int) * 2 * MAXD;
   static bool attr = false;
   if(!attr)
   {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ik_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_shmem));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ik_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     attr = true;
   }
   const bool dbg = getenv("SMPLPP_DEBUG_SYNC") != nullptr;
@@ -1267,9 +1293,17 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
     if(rc) return rc;
     DBG_SYNC("forward+eval");
     const int beta_dim = opt_beta ? NB : 0;
-    ik_solve_kernel<<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(s->ta, s->e, s->vp ? s->Jl : s->J, s->Afull, s->theta, s->beta,
-                                                                        s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp,
-                                                                        s->vp ? 1 : 0, s->skip, s->e2, s->status, s->xout);
+    // LDS plan: packed system + vectors, the rest (up to a 150 KB total) for the J row chunk
+    const int D = s->theta_dim + 2 * K + beta_dim, rows = 4 * K;
+    const size_t fixed = sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 6 * (size_t)D + rows) + sizeof(int) * 2 * (size_t)D;
+    const size_t budget = 150 * 1024;
+    int chunk_rows = (int)((budget - fixed) / (sizeof(double) * (size_t)D));
+    if(chunk_rows > rows) chunk_rows = rows;
+    if(chunk_rows < 4) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_iterate: system too large for the in-LDS solver");
+    const size_t solve_shmem = fixed + sizeof(double) * (size_t)chunk_rows * D;
+    ik_solve_kernel<<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, s->pts, K,
+                                                                        s->theta_dim, beta_dim, phi_live, enable_qp, s->vp ? 1 : 0,
+                                                                        chunk_rows, s->skip, s->e2, s->status, s->xout);
     HIP_TRY(hipGetLastError());
     DBG_SYNC("solve");
     ik_project_kernel<<<dim3((unsigned)(s->n * K)), dim3(256), 0, st>>>(view_of(m), s->ta, s->verts, s->pts, m->F, K, s->skip);

@@ -147,8 +147,26 @@ __device__ __attribute__((noinline)) inline float tri_sqdist_dev(const float * v
   return dx * dx + dy * dy + dz * dz;
 }
 
+// Conservative cull: every point of triangle f is at least |p - v0| - max(|v1 - v0|, |v2 - v0|) from p, so the face
+// cannot beat the bound `lim` (a squared distance) when |p - v0| > sqrt(lim) + r.  1e-5 relative slack keeps the test
+// on the safe side of rounding; culled faces are never the minimum nor inside the tie band.
+__device__ inline bool tri_culled(const float * verts, const int32_t * faces, int64_t f, const float * p, float sqrt_lim)
+{
+  const float * a = verts + 3 * faces[f * 3];
+  const float * b = verts + 3 * faces[f * 3 + 1];
+  const float * c = verts + 3 * faces[f * 3 + 2];
+  const float e1 = (b[0] - a[0]) * (b[0] - a[0]) + (b[1] - a[1]) * (b[1] - a[1]) + (b[2] - a[2]) * (b[2] - a[2]);
+  const float e2 = (c[0] - a[0]) * (c[0] - a[0]) + (c[1] - a[1]) * (c[1] - a[1]) + (c[2] - a[2]) * (c[2] - a[2]);
+  const float r = sqrtf(fmaxf(e1, e2));
+  const float d0 = (p[0] - a[0]) * (p[0] - a[0]) + (p[1] - a[1]) * (p[1] - a[1]) + (p[2] - a[2]) * (p[2] - a[2]);
+  const float reach = (sqrt_lim + r) * 1.00001f + 1e-7f;
+  return d0 > reach * reach;
+}
+
+// `hint_face` (>= 0): a face known to be near the query (the task's current face); its exact distance seeds the bound
+// so that almost every other face is culled by the sphere test.
 __device__ inline void closest_point_block(const float * verts, const int32_t * faces, int64_t F, const float * point,
-                                           int64_t * face_out, float * closest_out, float * sq_out)
+                                           int64_t * face_out, float * closest_out, float * sq_out, int hint_face = -1)
 {
   const float p[3] = {point[0], point[1], point[2]};
   __shared__ float s_d[4];
@@ -159,14 +177,27 @@ __device__ inline void closest_point_block(const float * verts, const int32_t * 
   // pass 1: minimum squared distance (and its face, the fallback if the tie band comes up empty, e.g. NaN input)
   float best = INFINITY;
   int bf = 0;
-  for(int64_t f = threadIdx.x; f < F; f += blockDim.x)
+  if(hint_face >= 0 && (int64_t)hint_face < F)
   {
     float c[3];
+    const float d = tri_sqdist_dev(verts, faces, hint_face, p, c);
+    if(d == d) // not NaN
+    {
+      best = d;
+      bf = hint_face;
+    }
+  }
+  float sq = sqrtf(best);
+  for(int64_t f = threadIdx.x; f < F; f += blockDim.x)
+  {
+    if(best < INFINITY && tri_culled(verts, faces, f, p, sq)) continue;
+    float c[3];
     const float d = tri_sqdist_dev(verts, faces, f, p, c);
-    if(d < best)
+    if(d < best || (d == best && (int)f < bf))
     {
       best = d;
       bf = (int)f;
+      sq = sqrtf(best);
     }
   }
   for(int off = 32; off > 0; off >>= 1)
@@ -196,11 +227,14 @@ __device__ inline void closest_point_block(const float * verts, const int32_t * 
   __syncthreads();
   // pass 2: lowest face id within the tie band
   const float thr = s_min * (1.0f + 1e-6f) + 1e-12f;
+  const float sq_thr = sqrtf(thr);
   int cf = 0x7fffffff;
   for(int64_t f = threadIdx.x; f < F; f += blockDim.x)
   {
+    if((int)f >= cf) break; // ids ascend within a thread
+    if(thr < INFINITY && tri_culled(verts, faces, f, p, sq_thr)) continue;
     float c[3];
-    if(tri_sqdist_dev(verts, faces, f, p, c) <= thr && (int)f < cf) cf = (int)f;
+    if(tri_sqdist_dev(verts, faces, f, p, c) <= thr) cf = (int)f;
   }
   for(int off = 32; off > 0; off >>= 1)
   {
