@@ -8,8 +8,9 @@
 //  ik_solve_kernel   node.cpp:883-968: A = J^T J + damping in fp64 built straight from J staged through LDS, right-looking
 //                    Cholesky of the packed lower-triangular augmented system in LDS (fp64) or the box QP by a primal
 //                    active set around it, config update, query points for the re-projection.
-//  ik_project_kernel node.cpp:970-1001: closest point on the posed mesh (brute force over 13776 faces, one workgroup
-//                    per query), new face id and area-ratio weights.
+//  proj_scan/finish  node.cpp:970-1001: exact closest point on the posed mesh (all 13776 faces, sphere-culled against the
+//                    distance to each task's current face; each face gathered once per frame for all K queries), new
+//                    face id and area-ratio weights.
 // All fp32 where the reference is fp32 (FK, task geometry, autograd gradients), fp64 where it is fp64 (Eigen).
 #include "mesh_device.h"
 #include "staging.h"
@@ -638,7 +639,7 @@ __device__ inline void tri_unpack(int item, int & i, int & j)
 // In-place right-looking Cholesky of the packed lower-triangular (nf+1)x(nf+1) augmented matrix [A b; b' *] held in
 // LDS (fp64): the last row becomes y = L^-1 b, so forward substitution is free.  Every thread of the workgroup
 // updates the trailing sub-matrix; two barriers per column.
-__device__ inline void chol_aug(double * M, int nf, int * bad)
+__device__ inline void chol_aug(double * M, int nf, int * bad, double * dinv)
 {
   const int tid = threadIdx.x, nt = blockDim.x;
   for(int j = 0; j < nf; j++)
@@ -651,32 +652,32 @@ __device__ inline void chol_aug(double * M, int nf, int * bad)
     }
     const double piv = sqrt(d);
     __syncthreads(); // everyone has read the pivot
+    if(tid == 0) dinv[j] = 1.0 / piv;
     for(int i = j + tid; i <= nf; i += nt) M[tri_idx(i, j)] = (i == j) ? piv : M[tri_idx(i, j)] / piv;
     __syncthreads();
-    // trailing update: rows i in (j, nf], columns k in (j, i]
-    const int m = nf - j; // rows below j
-    const int cnt = m * (m + 1) / 2;
-    for(int item = tid; item < cnt; item += nt)
+    // trailing update: rows i in (j, nf], columns k in (j, i]; the 256 threads tile the square as 16 x 16
     {
-      int a, b;
-      tri_unpack(item, a, b);
-      const int i = j + 1 + a, k = j + 1 + b;
-      if(k == nf) continue; // the (nf, nf) corner is never used
-      M[tri_idx(i, k)] -= M[tri_idx(i, j)] * M[tri_idx(k, j)];
+      const int ty = tid >> 4, tx = tid & 15;
+      for(int i = j + 1 + ty; i <= nf; i += 16)
+      {
+        const double lij = M[tri_idx(i, j)];
+        const int kend = (i < nf) ? i : nf - 1; // the (nf, nf) corner is never used
+        for(int k = j + 1 + tx; k <= kend; k += 16) M[tri_idx(i, k)] -= lij * M[tri_idx(k, j)];
+      }
     }
     __syncthreads();
   }
 }
 
-// back substitution L^T x = y (y = row nf of M), x returned in xs[0..nf)
-__device__ inline void back_subst(const double * M, int nf, double * xs)
+// back substitution L^T x = y (y = row nf of M), x returned in xs[0..nf); dinv[j] = 1 / L[j][j]
+__device__ inline void back_subst(const double * M, int nf, double * xs, const double * dinv)
 {
   const int tid = threadIdx.x;
   for(int i = tid; i < nf; i += blockDim.x) xs[i] = M[tri_idx(nf, i)];
   __syncthreads();
   for(int j = nf - 1; j >= 0; j--)
   {
-    const double xj = xs[j] / M[tri_idx(j, j)];
+    const double xj = xs[j] * dinv[j];
     __syncthreads();
     for(int k = tid; k < j; k += blockDim.x) xs[k] -= M[tri_idx(j, k)] * xj;
     if(tid == 0) xs[j] = xj;
@@ -684,8 +685,135 @@ __device__ inline void back_subst(const double * M, int nf, double * xs)
   }
 }
 
+// 1/sqrt(d) in fp64: hardware estimate (v_rsq_f64) + two Newton steps (relative error ~1e-16), an order of magnitude
+// cheaper than sqrt() + a division on the pivot's critical path.
+__device__ inline double fast_rsqrt(double d)
+{
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - 0.5 * d * y * y);
+  y = y * (1.5 - 0.5 * d * y * y);
+  return y;
+}
+
+// Register-tiled build + factorisation of the augmented free-set system for nf + 1 <= 16 * NT: thread (ty, tx) of the
+// 16 x 16 workgroup owns the elements (ty + 16a, tx + 16b), b <= a, in registers.  Per column ONE barrier: the column's
+// holders publish its raw entries (and the pivot entry) to LDS, every thread then applies the rank-1 update to its own
+// registers as acc -= raw_i * raw_k / d.  The scaled column is also written to the packed LDS matrix M for back_subst.
+template<int NT>
+__device__ inline void build_and_factor_reg(double * M, const double * __restrict__ J, const double * __restrict__ rowv, double * Jc,
+                                            const double * diag, const double * bpri, const int * idx, int nf, int D, int rows,
+                                            int chunk_rows, double * lraw /*[2][16*NT]*/, double * ldiag /*[4]*/, double * dinv /*[nf]*/, int * bad)
+{
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  double acc[NT][NT];
+  int colI[NT], colK[NT];
+#pragma unroll
+  for(int a = 0; a < NT; a++)
+  {
+    const int i = ty + 16 * a, k = tx + 16 * a;
+    colI[a] = (i < nf) ? idx[i] : (i == nf ? -1 : -2); // -1: the rhs row, -2: outside
+    colK[a] = (k < nf) ? idx[k] : -2;
+#pragma unroll
+    for(int b = 0; b < NT; b++) acc[a][b] = 0.0;
+  }
+  // A_FF = J_F^T J_F and the rhs row J_F^T rowv, accumulated over row chunks of J staged in LDS
+  for(int c0 = 0; c0 < rows; c0 += chunk_rows)
+  {
+    const int cr = (rows - c0 < chunk_rows) ? rows - c0 : chunk_rows;
+    __syncthreads();
+    for(int q = tid; q < cr * D; q += 256) Jc[q] = J[(int64_t)c0 * D + q];
+    __syncthreads();
+    for(int r = 0; r < cr; r++)
+    {
+      double vi[NT], vk[NT];
+#pragma unroll
+      for(int a = 0; a < NT; a++)
+      {
+        vi[a] = (colI[a] >= 0) ? Jc[r * D + colI[a]] : (colI[a] == -1 ? rowv[c0 + r] : 0.0);
+        vk[a] = (colK[a] >= 0) ? Jc[r * D + colK[a]] : 0.0;
+      }
+#pragma unroll
+      for(int a = 0; a < NT; a++)
+#pragma unroll
+        for(int b = 0; b <= a; b++) acc[a][b] += vi[a] * vk[b];
+    }
+  }
+#pragma unroll
+  for(int a = 0; a < NT; a++)
+#pragma unroll
+    for(int b = 0; b <= a; b++)
+    {
+      const int i = ty + 16 * a, k = tx + 16 * b;
+      if(i < nf && i == k) acc[a][b] += diag[idx[i]];
+      if(i == nf && k < nf) acc[a][b] += bpri[idx[k]];
+    }
+  // factorisation
+#pragma unroll
+  for(int bj = 0; bj < NT; bj++)
+  {
+    for(int jj = 0; jj < 16; jj++)
+    {
+      const int j = 16 * bj + jj;
+      if(j >= nf) break; // uniform
+      double * lr = lraw + (j & 1) * (16 * NT);
+      if(tx == jj) // this thread holds column j for rows ty + 16a
+      {
+#pragma unroll
+        for(int a = bj; a < NT; a++)
+        {
+          const int i = ty + 16 * a;
+          if(i >= j && i <= nf)
+          {
+            lr[i] = acc[a][bj];
+            if(i == j) // the pivot's owner also publishes 1/sqrt(d) (computed before the barrier, off everyone else's path)
+            {
+              double d = acc[a][bj];
+              if(!(d > 0.0))
+              {
+                *bad = 1;
+                d = 1.0;
+              }
+              const double y = fast_rsqrt(d);
+              ldiag[(j & 1) * 2] = y;         // 1 / piv
+              ldiag[(j & 1) * 2 + 1] = d * y; // piv
+              dinv[j] = y;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const double inv_piv = ldiag[(j & 1) * 2];
+      const double inv_d = inv_piv * inv_piv;
+      if(tx == jj)
+      {
+        const double piv = ldiag[(j & 1) * 2 + 1];
+#pragma unroll
+        for(int a = bj; a < NT; a++)
+        {
+          const int i = ty + 16 * a;
+          if(i >= j && i <= nf) M[tri_idx(i, j)] = (i == j) ? piv : acc[a][bj] * inv_piv;
+        }
+      }
+      double li[NT], lk[NT];
+#pragma unroll
+      for(int a = bj; a < NT; a++)
+      {
+        const int i = ty + 16 * a, k = tx + 16 * a;
+        li[a] = (i > j && i <= nf) ? lr[i] : 0.0;
+        lk[a] = (k > j && k < nf) ? lr[k] * inv_d : 0.0;
+      }
+#pragma unroll
+      for(int a = bj; a < NT; a++)
+#pragma unroll
+        for(int b = bj; b <= a; b++) acc[a][b] -= li[a] * lk[b];
+    }
+  }
+  __syncthreads();
+}
+
 // One workgroup per frame.  Everything is built from J (staged through LDS in row chunks) — no D x D matrix in HBM.
-// LDS (doubles): M packed (D+1)(D+2)/2 | Jc [chunk][D] | xs, xfull, diag, bpri, lo, hi [D each] | rowv [rows] ; ints idx, state [D].
+// LDS (doubles): M packed (D+1)(D+2)/2 | Jc [chunk][D] | xs, xfull, diag, bpri, lo, hi [D each] | rowv [rows] | lraw [2][96],
+// ldiag [2] ; ints idx, state [D].
 __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const double * __restrict__ e_all, const double * __restrict__ J_all,
                                                        float * __restrict__ theta, float * __restrict__ beta, float * __restrict__ pts,
                                                        int K, int theta_dim, int beta_dim, int phi_live, int enable_qp, int use_prior,
@@ -706,7 +834,10 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   double * lo = bpri + D;
   double * hi = lo + D;
   double * rowv = hi + D;
-  int * idx = reinterpret_cast<int *>(rowv + rows);
+  double * lraw = rowv + rows; // [2][96] published column of the register-tiled factorisation
+  double * ldiag = lraw + 192; // [2][2]  1/pivot, pivot
+  double * dinv = ldiag + 4;   // [D] reciprocal pivots for the back substitution
+  int * idx = reinterpret_cast<int *>(dinv + D);
   int * state = idx + D; // 0 free, -1 at lo, +1 at hi, 2 pinned (empty box)
   __shared__ int s_bad, s_nf, s_block, s_bside, s_done, s_anybound;
   __shared__ double s_alpha, s_e2;
@@ -802,38 +933,50 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
           if(state[q] == -1 || state[q] == 1) s += J[(int64_t)r * D + q] * xfull[q];
       rowv[r] = s;
     }
-    for(int item = tid; item < nitem; item += 256) M[item] = 0.0;
-    for(int c0 = 0; c0 < rows; c0 += chunk_rows)
+    if(nf + 1 <= 96)
     {
-      const int cr = (rows - c0 < chunk_rows) ? rows - c0 : chunk_rows;
+      // small systems (every mode except the 41-marker body solve): registers, one barrier per column
       __syncthreads();
-      for(int q = tid; q < cr * D; q += 256) Jc[q] = J[(int64_t)c0 * D + q];
-      __syncthreads();
-      for(int item = tid; item < nitem - 1; item += 256) // the (nf, nf) corner is not needed
+      build_and_factor_reg<6>(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, chunk_rows, lraw, ldiag, dinv, &s_bad);
+    }
+    else
+    {
+      for(int item = tid; item < nitem; item += 256) M[item] = 0.0;
+      for(int c0 = 0; c0 < rows; c0 += chunk_rows)
       {
-        int i, j;
-        tri_unpack(item, i, j);
-        const int cj = idx[j];
-        double s = 0.0;
-        if(i < nf)
+        const int cr = (rows - c0 < chunk_rows) ? rows - c0 : chunk_rows;
+        __syncthreads();
+        for(int q = tid; q < cr * D; q += 256) Jc[q] = J[(int64_t)c0 * D + q];
+        __syncthreads();
         {
-          const int ci = idx[i];
-          for(int r = 0; r < cr; r++) s += Jc[r * D + ci] * Jc[r * D + cj];
+          const int ty = tid >> 4, tx = tid & 15; // 16 x 16 tiling of the lower triangle (+ the rhs row i == nf)
+          for(int i = ty; i <= nf; i += 16)
+          {
+            const int ci = (i < nf) ? idx[i] : 0;
+            const int jend = (i < nf) ? i : nf - 1;
+            for(int j = tx; j <= jend; j += 16)
+            {
+              const int cj = idx[j];
+              double s = 0.0;
+              if(i < nf)
+                for(int r = 0; r < cr; r++) s += Jc[r * D + ci] * Jc[r * D + cj];
+              else
+                for(int r = 0; r < cr; r++) s += Jc[r * D + cj] * rowv[c0 + r];
+              M[tri_idx(i, j)] += s;
+            }
+          }
         }
-        else
-          for(int r = 0; r < cr; r++) s += Jc[r * D + cj] * rowv[c0 + r];
-        M[item] += s;
       }
+      __syncthreads();
+      for(int a = tid; a < nf; a += 256)
+      {
+        M[tri_idx(a, a)] += diag[idx[a]];
+        M[tri_idx(nf, a)] += bpri[idx[a]];
+      }
+      __syncthreads();
+      chol_aug(M, nf, &s_bad, dinv);
     }
-    __syncthreads();
-    for(int a = tid; a < nf; a += 256)
-    {
-      M[tri_idx(a, a)] += diag[idx[a]];
-      M[tri_idx(nf, a)] += bpri[idx[a]];
-    }
-    __syncthreads();
-    chol_aug(M, nf, &s_bad);
-    back_subst(M, nf, xs);
+    back_subst(M, nf, xs, dinv);
     if(!enable_qp)
     {
       for(int a = tid; a < nf; a += 256) xfull[idx[a]] = -xs[a]; // x = -LLT(A)^-1 b (node.cpp:938)
@@ -930,25 +1073,143 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     for(int i = tid; i < D; i += 256) x_out[f * D + i] = xfull[i];
 }
 
-// node.cpp:970-1001: one workgroup per (frame, task)
-__global__ __launch_bounds__(256) void ik_project_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all,
-                                                          const float * __restrict__ pts, int64_t F, int K, const int * __restrict__ skip)
+// node.cpp:970-1001 — re-projection of the K query points of every frame onto that frame's posed mesh.
+//
+// Uncoalesced 12-byte vertex gathers bound this step (every face needs three), so a face is gathered ONCE per frame and
+// tested against all K queries: proj_scan_kernel (one workgroup per frame x face chunk) culls with the bounding-sphere
+// test against each query's hint distance (exact distance to the task's current face), evaluates the exact distance of
+// the few survivors and appends (distance, face) to a short per-(frame, task) list; proj_finish_kernel (one workgroup per
+// frame) takes the minimum of each list, applies the tie rule (lowest face id within 1e-6 relative of the minimum — every
+// face in that band passes the cull, whose slack is larger) and writes the new face id and area-ratio weights.  A list
+// that overflows (a far-off hint, e.g. the very first iteration) falls back to the exhaustive block scan.
+constexpr int PROJ_LIST = 256;
+constexpr int PROJ_MAXK = 48;
+
+__global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all,
+                                                         const float * __restrict__ pts, int64_t F, int K, int chunks,
+                                                         const int * __restrict__ skip, int * __restrict__ list_cnt,
+                                                         float * __restrict__ list_d, int * __restrict__ list_f)
 {
-  const int64_t f = blockIdx.x / K;
+  const int64_t f = blockIdx.x / chunks;
+  const int chunk = blockIdx.x % chunks;
   if(skip[f]) return;
   const float * verts = verts_all + f * mv.V * 3;
-  __shared__ int64_t s_face;
-  __shared__ float s_cl[3];
-  closest_point_block(verts, mv.faces, F, pts + (int64_t)blockIdx.x * 3, &s_face, s_cl, nullptr, ta.face[blockIdx.x]);
-  if(threadIdx.x == 0)
+  __shared__ float sp[PROJ_MAXK][3];
+  __shared__ float sreach[PROJ_MAXK]; // sqrt of the hint distance: the cull radius of query k
+  const int64_t tb = f * K;
+  if((int)threadIdx.x < K)
   {
-    const int face = (int)s_face;
-    float tri[9], w[3];
+    const int k = threadIdx.x;
+    const float * p = pts + (tb + k) * 3;
+    sp[k][0] = p[0];
+    sp[k][1] = p[1];
+    sp[k][2] = p[2];
+    float c[3];
+    const float d = tri_sqdist_dev(verts, mv.faces, ta.face[tb + k], p, c);
+    sreach[k] = (d == d) ? sqrtf(d) : INFINITY;
+  }
+  __syncthreads();
+  const int64_t per = (F + chunks - 1) / chunks;
+  const int64_t f_lo = chunk * per, f_hi = (f_lo + per < F) ? f_lo + per : F;
+  for(int64_t base = f_lo + threadIdx.x; base < f_hi; base += (int64_t)blockDim.x * CP_BATCH)
+  {
+    TriBatch t;
+    load_tri_batch(verts, mv.faces, f_hi, base, blockDim.x, t);
+#pragma unroll
+    for(int b = 0; b < CP_BATCH; b++)
+    {
+      if(!t.valid[b]) continue;
+      const int64_t face = base + (int64_t)b * blockDim.x;
+      const float * a = t.v[b];
+      // bounding sphere about the centroid (tighter than the one about v0 used by the exhaustive scan)
+      const float g[3] = {(a[0] + a[3] + a[6]) * (1.0f / 3.0f), (a[1] + a[4] + a[7]) * (1.0f / 3.0f), (a[2] + a[5] + a[8]) * (1.0f / 3.0f)};
+      float r2 = 0.0f;
+#pragma unroll
+      for(int c = 0; c < 3; c++)
+      {
+        const float dx = a[c * 3] - g[0], dy = a[c * 3 + 1] - g[1], dz = a[c * 3 + 2] - g[2];
+        r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
+      }
+      const float r = sqrtf(r2);
+      for(int k = 0; k < K; k++)
+      {
+        const float d0 = (sp[k][0] - g[0]) * (sp[k][0] - g[0]) + (sp[k][1] - g[1]) * (sp[k][1] - g[1]) + (sp[k][2] - g[2]) * (sp[k][2] - g[2]);
+        const float reach = (sreach[k] + r) * 1.00001f + 2e-6f;
+        if(d0 > reach * reach) continue;
+        float c[3];
+        const float d = tri_sqdist_dev(verts, mv.faces, face, sp[k], c);
+        const int slot = atomicAdd(&list_cnt[tb + k], 1);
+        if(slot < PROJ_LIST)
+        {
+          list_d[(tb + k) * PROJ_LIST + slot] = d;
+          list_f[(tb + k) * PROJ_LIST + slot] = (int)face;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all,
+                                                           const float * __restrict__ pts, int64_t F, int K,
+                                                           const int * __restrict__ skip, int * __restrict__ list_cnt,
+                                                           const float * __restrict__ list_d, const int * __restrict__ list_f,
+                                                           int * __restrict__ dbg)
+{
+  const int64_t f = blockIdx.x;
+  const int64_t tb = f * K;
+  if(skip[f]) return;
+  const float * verts = verts_all + f * mv.V * 3;
+  __shared__ int s_face[PROJ_MAXK];
+  __shared__ int s_slow[PROJ_MAXK];
+  if((int)threadIdx.x < K)
+  {
+    const int k = threadIdx.x;
+    const int cnt = list_cnt[tb + k];
+    list_cnt[tb + k] = 0; // ready for the next iteration
+    int face = -1;
+    if(cnt >= 1 && cnt <= PROJ_LIST)
+    {
+      const float * ld = list_d + (tb + k) * PROJ_LIST;
+      const int * lf = list_f + (tb + k) * PROJ_LIST;
+      float mn = INFINITY;
+      for(int q = 0; q < cnt; q++) mn = fminf(mn, ld[q]);
+      const float thr = mn * (1.0f + 1e-6f) + 1e-12f;
+      int best = 0x7fffffff;
+      for(int q = 0; q < cnt; q++)
+        if(ld[q] <= thr && lf[q] < best) best = lf[q];
+      if(best != 0x7fffffff) face = best;
+    }
+    s_face[k] = face;
+    s_slow[k] = (face < 0) ? 1 : 0;
+    if(dbg)
+    {
+      atomicAdd(&dbg[0], 1);
+      if(cnt == 0) atomicAdd(&dbg[1], 1);
+      if(cnt > PROJ_LIST) atomicAdd(&dbg[2], 1);
+      if(face < 0 && cnt >= 1 && cnt <= PROJ_LIST) atomicAdd(&dbg[3], 1);
+      atomicMax(&dbg[4], cnt);
+    }
+  }
+  __syncthreads();
+  for(int k = 0; k < K; k++) // rare: exhaustive scan for the tasks whose list overflowed (or was empty / NaN)
+  {
+    if(!s_slow[k]) continue; // uniform across the workgroup
+    __shared__ int64_t s_f64;
+    closest_point_block(verts, mv.faces, F, pts + (tb + k) * 3, &s_f64, nullptr, nullptr, ta.face[tb + k]);
+    if(threadIdx.x == 0) s_face[k] = (int)s_f64;
+    __syncthreads();
+  }
+  if((int)threadIdx.x < K)
+  {
+    const int k = threadIdx.x;
+    const int face = s_face[k];
+    float tri[9], w[3], c[3];
     for(int i = 0; i < 3; i++)
       for(int x = 0; x < 3; x++) tri[i * 3 + x] = verts[3 * mv.faces[face * 3 + i] + x];
-    triangle_weights_dev(s_cl, tri, w); // calcVertexWeights(closest point), phi_ == 0 (:997-998)
-    ta.face[blockIdx.x] = face;
-    for(int i = 0; i < 3; i++) ta.vw[(int64_t)blockIdx.x * 3 + i] = w[i];
+    (void)tri_sqdist_dev(verts, mv.faces, face, pts + (tb + k) * 3, c);
+    triangle_weights_dev(c, tri, w); // calcVertexWeights(closest point), phi_ == 0 (:997-998)
+    ta.face[tb + k] = face;
+    for(int i = 0; i < 3; i++) ta.vw[(tb + k) * 3 + i] = w[i];
   }
 }
 
@@ -993,7 +1254,8 @@ struct smplpp_ik
   double *e = nullptr, *J = nullptr, *Jl = nullptr, *e2 = nullptr, *xout = nullptr;
   int32_t * ring = nullptr;
   uint8_t * map = nullptr;
-  int *skip = nullptr, *status = nullptr;
+  int *skip = nullptr, *status = nullptr, *list_cnt = nullptr, *list_f = nullptr;
+  float * list_d = nullptr;
   std::vector<void *> owned;
   bool have_eval = false;
 };
@@ -1038,6 +1300,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   if(!m || !out || n <= 0 || K <= 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: bad argument");
   *out = nullptr;
   if(m->F <= 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: the model has no faces");
+  if(K > PROJ_MAXK) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: at most 48 tasks per frame are supported");
   if(TD75 + 2 * K + NB > MAXD)
     return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: too many tasks for the in-LDS solver (75 + 2K + 10 must be <= 170)");
   int maxadj = 0;
@@ -1088,6 +1351,9 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   A_(xout, (size_t)n * Dmax);
   A_(ring, nk * (MAXRING + 1));
   A_(map, nk * 3 * MAXADJ * 3);
+  A_(list_cnt, nk);
+  A_(list_d, nk * PROJ_LIST);
+  A_(list_f, nk * PROJ_LIST);
   A_(skip, (size_t)n);
   A_(status, (size_t)n);
   if(vposer)
@@ -1111,6 +1377,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   HIP_TRY(hipMemset(s->theta, 0, sizeof(float) * n * s->theta_dim));
   HIP_TRY(hipMemset(s->beta, 0, sizeof(float) * n * NB));
   HIP_TRY(hipMemset(s->skip, 0, sizeof(int) * n));
+  HIP_TRY(hipMemset(s->list_cnt, 0, sizeof(int) * nk));
   HIP_TRY(hipMemset(s->status, 0, sizeof(int) * n));
   HIP_TRY(hipDeviceSynchronize());
   *out = s;
@@ -1295,7 +1562,7 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
     const int beta_dim = opt_beta ? NB : 0;
     // LDS plan: packed system + vectors, the rest (up to a 150 KB total) for the J row chunk
     const int D = s->theta_dim + 2 * K + beta_dim, rows = 4 * K;
-    const size_t fixed = sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 6 * (size_t)D + rows) + sizeof(int) * 2 * (size_t)D;
+    const size_t fixed = sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 7 * (size_t)D + rows + 196) + sizeof(int) * 2 * (size_t)D;
     const size_t budget = 150 * 1024;
     int chunk_rows = (int)((budget - fixed) / (sizeof(double) * (size_t)D));
     if(chunk_rows > rows) chunk_rows = rows;
@@ -1306,8 +1573,25 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
                                                                         chunk_rows, s->skip, s->e2, s->status, s->xout);
     HIP_TRY(hipGetLastError());
     DBG_SYNC("solve");
-    ik_project_kernel<<<dim3((unsigned)(s->n * K)), dim3(256), 0, st>>>(view_of(m), s->ta, s->verts, s->pts, m->F, K, s->skip);
-    HIP_TRY(hipGetLastError());
+    {
+      int chunks = (int)(1536 / s->n);
+      chunks = chunks < 1 ? 1 : (chunks > 32 ? 32 : chunks);
+      proj_scan_kernel<<<dim3((unsigned)(s->n * chunks)), dim3(256), 0, st>>>(view_of(m), s->ta, s->verts, s->pts, m->F, K, chunks, s->skip,
+                                                                            s->list_cnt, s->list_d, s->list_f);
+      HIP_TRY(hipGetLastError());
+      static int * dbg_buf = nullptr;
+      if(dbg && !dbg_buf) HIP_TRY(hipMalloc((void **)&dbg_buf, sizeof(int) * 8));
+      if(dbg) HIP_TRY(hipMemsetAsync(dbg_buf, 0, sizeof(int) * 8, st));
+      proj_finish_kernel<<<dim3((unsigned)s->n), dim3(256), 0, st>>>(view_of(m), s->ta, s->verts, s->pts, m->F, K, s->skip, s->list_cnt,
+                                                                   s->list_d, s->list_f, dbg ? dbg_buf : nullptr);
+      HIP_TRY(hipGetLastError());
+      if(dbg)
+      {
+        int h[8];
+        HIP_TRY(hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[smplpp dbg] it %d: project lists: tasks %d, empty %d, overflow %d, nan %d, max cnt %d\n", it, h[0], h[1], h[2], h[3], h[4]);
+      }
+    }
     DBG_SYNC("project");
   }
 #undef DBG_SYNC

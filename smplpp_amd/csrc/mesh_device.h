@@ -147,20 +147,50 @@ __device__ __attribute__((noinline)) inline float tri_sqdist_dev(const float * v
   return dx * dx + dy * dy + dz * dz;
 }
 
-// Conservative cull: every point of triangle f is at least |p - v0| - max(|v1 - v0|, |v2 - v0|) from p, so the face
+// Conservative cull: every point of a triangle is at least |p - v0| - max(|v1 - v0|, |v2 - v0|) from p, so the face
 // cannot beat the bound `lim` (a squared distance) when |p - v0| > sqrt(lim) + r.  1e-5 relative slack keeps the test
 // on the safe side of rounding; culled faces are never the minimum nor inside the tie band.
-__device__ inline bool tri_culled(const float * verts, const int32_t * faces, int64_t f, const float * p, float sqrt_lim)
+__device__ inline bool tri_culled_v(const float * a, const float * b, const float * c, const float * p, float sqrt_lim)
 {
-  const float * a = verts + 3 * faces[f * 3];
-  const float * b = verts + 3 * faces[f * 3 + 1];
-  const float * c = verts + 3 * faces[f * 3 + 2];
   const float e1 = (b[0] - a[0]) * (b[0] - a[0]) + (b[1] - a[1]) * (b[1] - a[1]) + (b[2] - a[2]) * (b[2] - a[2]);
   const float e2 = (c[0] - a[0]) * (c[0] - a[0]) + (c[1] - a[1]) * (c[1] - a[1]) + (c[2] - a[2]) * (c[2] - a[2]);
   const float r = sqrtf(fmaxf(e1, e2));
   const float d0 = (p[0] - a[0]) * (p[0] - a[0]) + (p[1] - a[1]) * (p[1] - a[1]) + (p[2] - a[2]) * (p[2] - a[2]);
   const float reach = (sqrt_lim + r) * 1.00001f + 1e-7f;
   return d0 > reach * reach;
+}
+
+// The scan is latency-bound (index load -> dependent vertex gathers), so faces are taken CP_BATCH at a time with all
+// of a batch's loads issued before any of its tests.
+constexpr int CP_BATCH = 6;
+struct TriBatch
+{
+  float v[CP_BATCH][9];
+  bool valid[CP_BATCH];
+};
+__device__ inline void load_tri_batch(const float * verts, const int32_t * faces, int64_t F, int64_t base, int stride, TriBatch & t)
+{
+  int id[CP_BATCH][3];
+#pragma unroll
+  for(int b = 0; b < CP_BATCH; b++)
+  {
+    const int64_t f = base + (int64_t)b * stride;
+    t.valid[b] = f < F;
+    const int64_t ff = t.valid[b] ? f : 0;
+    id[b][0] = faces[ff * 3];
+    id[b][1] = faces[ff * 3 + 1];
+    id[b][2] = faces[ff * 3 + 2];
+  }
+#pragma unroll
+  for(int b = 0; b < CP_BATCH; b++)
+#pragma unroll
+    for(int c = 0; c < 3; c++)
+    {
+      const float * src = verts + 3 * id[b][c];
+      t.v[b][c * 3] = src[0];
+      t.v[b][c * 3 + 1] = src[1];
+      t.v[b][c * 3 + 2] = src[2];
+    }
 }
 
 // `hint_face` (>= 0): a face known to be near the query (the task's current face); its exact distance seeds the bound
@@ -188,16 +218,24 @@ __device__ inline void closest_point_block(const float * verts, const int32_t * 
     }
   }
   float sq = sqrtf(best);
-  for(int64_t f = threadIdx.x; f < F; f += blockDim.x)
+  for(int64_t base = threadIdx.x; base < F; base += (int64_t)blockDim.x * CP_BATCH)
   {
-    if(best < INFINITY && tri_culled(verts, faces, f, p, sq)) continue;
-    float c[3];
-    const float d = tri_sqdist_dev(verts, faces, f, p, c);
-    if(d < best || (d == best && (int)f < bf))
+    TriBatch t;
+    load_tri_batch(verts, faces, F, base, blockDim.x, t);
+#pragma unroll
+    for(int b = 0; b < CP_BATCH; b++)
     {
-      best = d;
-      bf = (int)f;
-      sq = sqrtf(best);
+      const int64_t f = base + (int64_t)b * blockDim.x;
+      if(!t.valid[b]) continue;
+      if(best < INFINITY && tri_culled_v(t.v[b], t.v[b] + 3, t.v[b] + 6, p, sq)) continue;
+      float c[3];
+      const float d = tri_sqdist_dev(verts, faces, f, p, c);
+      if(d < best || (d == best && (int)f < bf))
+      {
+        best = d;
+        bf = (int)f;
+        sq = sqrtf(best);
+      }
     }
   }
   for(int off = 32; off > 0; off >>= 1)
@@ -229,12 +267,19 @@ __device__ inline void closest_point_block(const float * verts, const int32_t * 
   const float thr = s_min * (1.0f + 1e-6f) + 1e-12f;
   const float sq_thr = sqrtf(thr);
   int cf = 0x7fffffff;
-  for(int64_t f = threadIdx.x; f < F; f += blockDim.x)
+  for(int64_t base = threadIdx.x; base < F && (int)base < cf; base += (int64_t)blockDim.x * CP_BATCH)
   {
-    if((int)f >= cf) break; // ids ascend within a thread
-    if(thr < INFINITY && tri_culled(verts, faces, f, p, sq_thr)) continue;
-    float c[3];
-    if(tri_sqdist_dev(verts, faces, f, p, c) <= thr) cf = (int)f;
+    TriBatch t;
+    load_tri_batch(verts, faces, F, base, blockDim.x, t);
+#pragma unroll
+    for(int b = 0; b < CP_BATCH; b++)
+    {
+      const int64_t f = base + (int64_t)b * blockDim.x;
+      if(!t.valid[b] || (int)f >= cf) continue; // ids ascend within a thread
+      if(thr < INFINITY && tri_culled_v(t.v[b], t.v[b] + 3, t.v[b] + 6, p, sq_thr)) continue;
+      float c[3];
+      if(tri_sqdist_dev(verts, faces, f, p, c) <= thr) cf = (int)f;
+    }
   }
   for(int off = 32; off > 0; off >>= 1)
   {
