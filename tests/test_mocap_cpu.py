@@ -1,0 +1,62 @@
+"""Mocap-side formats: C3D reader/writer round trip, Baseline-41 label matching, result writers."""
+import os
+
+import numpy as np
+import pytest
+
+from smplpp_amd import mocap
+
+from conftest import GOLDEN
+
+
+def test_c3d_roundtrip_with_missing_markers(tmp_path):
+    rng = np.random.default_rng(0)
+    names = sorted(mocap.BASELINE41)
+    labels = ["Skeleton0:" + n for n in names] + ["Unlabeled_1", "Unlabeled_2"]
+    pts = rng.normal(0, 1, (37, len(labels), 3)).astype(np.float32)
+    valid = rng.random((37, len(labels))) > 0.1
+    p = str(tmp_path / "t.c3d")
+    mocap.write_c3d(p, labels, pts, valid, rate=120.0)
+    c = mocap.read_c3d(p)
+    assert c["labels"] == labels and c["rate"] == 120.0 and c["points"].shape == pts.shape
+    assert np.array_equal(c["valid"], valid)
+    assert np.array_equal(c["points"][valid], pts[valid])
+    idx = mocap.match_markers(c["labels"], names)  # suffix match, node.cpp:587-593
+    assert idx == list(range(len(names)))
+    with pytest.raises(KeyError):
+        mocap.match_markers(c["labels"], ["NoSuchMarker"])
+
+
+def test_reference_sample_excerpt_matches_reader():
+    """tests/golden/sample_walk_excerpt.npz was cut from the reference's data/sample_walk.c3d with this reader; when the
+    reference tree is present the reader is re-run on the original file."""
+    g = np.load(os.path.join(GOLDEN, "sample_walk_excerpt.npz"))
+    assert g["points"].shape == (32, 41, 3) and int(g["n_frames"]) == 3163 and int(g["n_points"]) == 49
+    assert int(g["missing_labelled"]) == 4420 and int(g["frames_any_missing"]) == 619
+    assert (g["valid"][16:].sum(axis=1) < 20).any()  # the excerpt contains frames that must skip the solve (node.cpp:785)
+    path = "/root/reference/data/sample_walk.c3d"
+    if os.path.exists(path):
+        c = mocap.read_c3d(path)
+        idx = mocap.match_markers(c["labels"], list(g["task_names"]))
+        assert np.array_equal(c["points"][g["frame_ids"]][:, idx], g["points"])
+        assert np.array_equal(c["valid"][g["frame_ids"]][:, idx], g["valid"])
+        assert c["rate"] == 120.0
+
+
+def test_baseline41_table():
+    assert len(mocap.BASELINE41) == 41 and mocap.BASELINE41["HeadTop"] == 7324 and mocap.BASELINE41["RHeel"] == 12705
+    assert max(mocap.BASELINE41.values()) < 13776
+
+
+def test_result_writers(tmp_path):
+    th = np.arange(2 * 75, dtype=np.float32).reshape(2, 25, 3) / 7
+    p = str(tmp_path / "m.txt")
+    mocap.write_motion_text(p, th)
+    rows = [list(map(float, ln.split())) for ln in open(p)]
+    assert len(rows) == 2 and len(rows[0]) == 75 and np.allclose(rows, th.reshape(2, 75).astype(np.float64))
+    y = str(tmp_path / "MocapBody.yaml")
+    names = ["Chest", "HeadTop"]
+    mocap.write_mocap_body_yaml(y, np.linspace(-1, 1, 10), names, [6842, 7324], [[0.2, 0.3, 0.5], [1 / 3, 1 / 3, 1 / 3]])
+    beta, n2, faces, w = mocap.read_mocap_body_yaml(y)
+    assert n2 == names and faces.tolist() == [6842, 7324] and np.allclose(beta, np.linspace(-1, 1, 10), atol=1e-6)
+    assert np.allclose(w, [[0.2, 0.3, 0.5], [1 / 3, 1 / 3, 1 / 3]], atol=1e-6)

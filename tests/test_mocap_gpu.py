@@ -1,0 +1,94 @@
+"""BASELINE config 4 in miniature: MoSh-style sequence fit (node.cpp:1362-1412) — R restarts in lock step on one GPU,
+31 warm-up iterations then one iteration per frame, missing markers, skipped frames."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def smpl(synth_model):
+    from smplpp_amd.smpl import SMPL
+
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(synth_model)
+    return s
+
+
+def _synthetic_sequence(smpl, synth_model, T, K=41, seed=0):
+    """Markers generated from the synthetic model itself: a smooth hidden motion, surface points 15 mm off the skin."""
+    from smplpp_amd import mocap
+
+    rng = np.random.default_rng(seed)
+    names = sorted(mocap.BASELINE41)[:K]
+    faces = np.array([mocap.BASELINE41[n] for n in names], np.int64)
+    amp = rng.normal(0, 0.15, (25, 3)).astype(np.float32)
+    ph = rng.uniform(0, 6.28, (25, 3)).astype(np.float32)
+    t = np.arange(T, dtype=np.float32)[:, None, None]
+    hid = amp * np.sin(0.05 * t + ph)
+    hid[:, 0, :] = [0.0, 0.0, 0.1] + 0.05 * np.sin(0.03 * t[:, 0] + np.array([0, 1, 2], np.float32))
+    smpl.launch(np.zeros((T, 10), np.float32), hid, want=("verts",))
+    f0 = synth_model["face_indices"].astype(np.int64)[faces] - 1
+    verts = smpl.getVertex()
+    pts = verts[:, f0].mean(axis=2)
+    vn = smpl.calcVertexNormalBatch(f0.reshape(-1)).reshape(T, K, 3, 3).mean(axis=2)
+    vn /= np.linalg.norm(vn, axis=-1, keepdims=True)
+    return names, faces, hid, (pts + 0.015 * vn).astype(np.float32)
+
+
+def test_sequence_fit_tracks_hidden_motion(smpl, synth_model):
+    from smplpp_amd import mocap
+
+    T, K, R = 24, 41, 3
+    names, faces, hid, markers = _synthetic_sequence(smpl, synth_model, T, K)
+    valid = np.ones((T, K), bool)
+    valid[5, :3] = False  # a few missing markers
+    valid[9, : K - 10] = False  # < K/2 valid -> this frame must skip the solve
+    rng = np.random.default_rng(1)
+    theta0 = np.tile(hid[0], (R, 1, 1)) + rng.normal(0, 0.03, (R, 25, 3)).astype(np.float32)
+    ms = mocap.MocapMotionSolver(smpl, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R)
+    th, frames = ms.solve(markers, valid, np.zeros(10, np.float32), theta0)
+    assert th.shape == (R, T, 75) and frames == list(range(T)) and np.isfinite(th).all()
+    th = ms.decode_theta(th)
+    assert np.abs(th[:, 9] - th[:, 8]).max() == 0  # skipped frame keeps the previous configuration (node.cpp:785)
+    assert np.abs(th[:, 10] - th[:, 9]).max() > 0
+    # marker residual of the fitted frames: re-evaluate FK and compare task points (+15 mm normal) with the markers
+    fit = th[0]
+    smpl.launch(np.zeros((T, 10), np.float32), fit, want=("verts",))
+    f0 = synth_model["face_indices"].astype(np.int64)[faces] - 1
+    verts = smpl.getVertex()
+    err = np.linalg.norm(verts[:, f0].mean(axis=2) - (markers - 0), axis=-1)  # centroid vs marker: ~15 mm offset + fit error
+    assert np.median(err[10:]) < 0.03
+    # every restart reaches the same marker fit (joint angles of unobserved joints are free to differ)
+    for r in range(1, R):
+        smpl.launch(np.zeros((T, 10), np.float32), th[r], want=("verts",))
+        err_r = np.linalg.norm(smpl.getVertex()[:, f0].mean(axis=2) - markers, axis=-1)
+        assert abs(np.median(err_r[10:]) - np.median(err[10:])) < 5e-3
+
+
+def test_reference_capture_excerpt_runs(smpl, tmp_path):
+    """The real capture (excerpt of data/sample_walk.c3d): the synthetic body is not a human, so only mechanics are
+    checked — finite results, the < K/2 skip rule on the frames that trigger it, writers."""
+    from smplpp_amd import mocap
+
+    g = np.load(os.path.join(GOLDEN, "sample_walk_excerpt.npz"))
+    names = list(g["task_names"])
+    faces = np.array([mocap.BASELINE41[n] for n in names], np.int64)
+    K = len(names)
+    pts = g["points"] - g["points"][0][g["valid"][0]].mean(axis=0) + np.array([0, -0.3, 0], np.float32)
+    ms = mocap.MocapMotionSolver(smpl, faces, np.full((K, 3), 1 / 3, np.float32), restarts=2)
+    theta0 = np.zeros((2, 25, 3), np.float32)
+    th, frames = ms.solve(pts, g["valid"], np.zeros(10, np.float32), theta0)
+    assert np.isfinite(th).all()
+    skipped = np.nonzero(g["valid"].sum(axis=1) < K // 2)[0]
+    assert len(skipped) > 0
+    for t in skipped:
+        if t > 0:
+            assert np.abs(th[:, t] - th[:, t - 1]).max() == 0
+    mocap.write_motion_text(str(tmp_path / "motion.txt"), ms.decode_theta(th[0]))
+    assert len(open(str(tmp_path / "motion.txt")).read().splitlines()) == len(frames)
