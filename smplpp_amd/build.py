@@ -11,6 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsmplpp_hip.so")
 ARCH = "gfx950"
+# skin_p.hip places its VALU work by hand in MFMA shadows: SLP-packing adjacent f32 FMAs into v_pk_fma_f32 (+ the v_mov
+# shuffles that feeds them) is an anti-lever beside MFMAs (cdna_hip_programming.md, per-instruction constants).
+PER_FILE_FLAGS = {"skin_p.hip": ["-fno-slp-vectorize"], "skin_q.hip": ["-fno-slp-vectorize"], "fk.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -47,7 +50,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs):
             continue
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        extra = PER_FILE_FLAGS.get(os.path.basename(src), [])
+        cmd = [hipcc] + flags + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

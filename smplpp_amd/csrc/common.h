@@ -76,6 +76,10 @@ struct Workspace
   DevBuf poserot; // [n][24][9]
   DevBuf beta, theta, verts, rest, xf44; // staging for host-pointer calls
   int64_t ldA = 0;
+  // work queues of the persistent fused kernel (skin_q.hip)
+  DevBuf q_ctr, q_desc, dummy; // dummy: write-only sink for masked-off lanes of branch-free epilogues
+  int64_t q_n = -1;
+  int q_grid = 0;
 };
 } // namespace smplpp_hip
 

@@ -17,6 +17,8 @@
 // given to one XCD, consecutively, so each 338 KB slice of Bm is pulled into that XCD's L2 once per launch.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace smplpp_hip
 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void skin_kernel(const float * __restrict__
                                                    int64_t ldB, const float * __restrict__ Gp, const float * __restrict__ theta,
                                                    const uint8_t * __restrict__ wIdx, const float * __restrict__ wVal,
                                                    const float * __restrict__ wSum, float * __restrict__ verts,
-                                                   float * __restrict__ rest, int64_t n, int64_t V, int VGn, int nft)
+                                                   float * __restrict__ rest, int64_t n, int64_t V, int VGn, int nft, int dbg_mode)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[]; // [32*FT][24][12] G' + [32*FT][3] root translation
   constexpr int FRAMES = 32 * FT;
@@ -202,49 +204,58 @@ __global__ __launch_bounds__(256, 2) void skin_kernel(const float * __restrict__
 #pragma unroll
       for(int r = 0; r < 16; r++) acc[t][x][r] = 0.0f;
 
-  if(vg < VGn)
+  if(vg < VGn && dbg_mode != 2)
   {
     // operand pointers: lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31]
     const float * Ap = AT + (int64_t)(lane >> 5) * ldA + f0 + (lane & 31);
     const float * Bp = Bm + (int64_t)(lane >> 5) * ldB + (int64_t)vg * (3 * VG) + (lane & 31);
-    float a_cur[UNR][FT], b_cur[UNR][3], a_nxt[UNR][FT], b_nxt[UNR][3];
-#pragma unroll
-    for(int u = 0; u < UNR; u++)
+    if(dbg_mode == 3) // timing experiment: every wavefront reads the same operand rows (pure L1 hits)
     {
-#pragma unroll
-      for(int t = 0; t < FT; t++) a_cur[u][t] = Ap[(int64_t)(2 * u) * ldA + 32 * t];
-#pragma unroll
-      for(int x = 0; x < 3; x++) b_cur[u][x] = Bp[(int64_t)(2 * u) * ldB + VG * x];
+      Ap = AT + (int64_t)(lane >> 5) * ldA + (lane & 31);
+      Bp = Bm + (int64_t)(lane >> 5) * ldB + (lane & 31);
     }
-    for(int c = 0; c < KSTEPS / UNR; c++)
-    {
-      if(c + 1 < KSTEPS / UNR)
+    // Ping-pong operand buffers P/Q, each one chunk (UNR k-steps) deep, loop unrolled by two chunks so that no register
+    // copies exist for the compiler to fold the two buffers back into one: the loads of a chunk are issued a full chunk
+    // of MFMAs (UNR * FT * 3 * 64 cycles) before their first use.
+    float aP[UNR][FT], bP[UNR][3], aQ[UNR][FT], bQ[UNR][3];
+    auto load_chunk = [&](int c, float (&a)[UNR][FT], float (&b)[UNR][3]) {
+      const float * An = Ap + (int64_t)(2 * UNR) * c * ldA;
+      const float * Bn = Bp + (int64_t)(2 * UNR) * c * ldB;
+#pragma unroll
+      for(int u = 0; u < UNR; u++)
       {
-        const float * An = Ap + (int64_t)(2 * UNR) * (c + 1) * ldA;
-        const float * Bn = Bp + (int64_t)(2 * UNR) * (c + 1) * ldB;
 #pragma unroll
-        for(int u = 0; u < UNR; u++)
-        {
+        for(int t = 0; t < FT; t++) a[u][t] = An[(int64_t)(2 * u) * ldA + 32 * t];
 #pragma unroll
-          for(int t = 0; t < FT; t++) a_nxt[u][t] = An[(int64_t)(2 * u) * ldA + 32 * t];
-#pragma unroll
-          for(int x = 0; x < 3; x++) b_nxt[u][x] = Bn[(int64_t)(2 * u) * ldB + VG * x];
-        }
+        for(int x = 0; x < 3; x++) b[u][x] = Bn[(int64_t)(2 * u) * ldB + VG * x];
       }
+    };
+    auto mfma_chunk = [&](const float (&a)[UNR][FT], const float (&b)[UNR][3]) {
 #pragma unroll
       for(int u = 0; u < UNR; u++)
 #pragma unroll
         for(int t = 0; t < FT; t++)
 #pragma unroll
-          for(int x = 0; x < 3; x++) acc[t][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][t], b_cur[u][x], acc[t][x], 0, 0, 0);
-#pragma unroll
-      for(int u = 0; u < UNR; u++)
+          for(int x = 0; x < 3; x++) acc[t][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u][x], acc[t][x], 0, 0, 0);
+    };
+    constexpr int NCH = KSTEPS / UNR; // 22 (even)
+    load_chunk(0, aP, bP);
+    if(dbg_mode == 4) // timing experiment: no operand loads inside the loop at all
+    {
+      load_chunk(1, aQ, bQ);
+      for(int c = 0; c < NCH; c += 2)
       {
-#pragma unroll
-        for(int t = 0; t < FT; t++) a_cur[u][t] = a_nxt[u][t];
-#pragma unroll
-        for(int x = 0; x < 3; x++) b_cur[u][x] = b_nxt[u][x];
+        mfma_chunk(aP, bP);
+        mfma_chunk(aQ, bQ);
       }
+    }
+    else
+    for(int c = 0; c < NCH; c += 2)
+    {
+      load_chunk(c + 1, aQ, bQ);
+      mfma_chunk(aP, bP);
+      if(c + 2 < NCH) load_chunk(c + 2, aP, bP);
+      mfma_chunk(aQ, bQ);
     }
   }
   __syncthreads(); // G' staged
@@ -252,6 +263,14 @@ __global__ __launch_bounds__(256, 2) void skin_kernel(const float * __restrict__
   if(vg >= VGn) return;
   const int64_t v = (int64_t)vg * VG + (lane & 31);
   if(v >= V) return;
+  if(dbg_mode == 1 || dbg_mode == 3 || dbg_mode == 4) // timing experiment: MFMA loop only (keep the accumulators alive)
+  {
+    float s = 0.f;
+    for(int t = 0; t < FT; t++)
+      for(int x = 0; x < 3; x++) s += acc[t][x][0] + acc[t][x][15];
+    if(s == 12345.678f) verts[0] = s;
+    return;
+  }
   // this lane's skinning weights
   int jidx[MAXW];
   float jw[MAXW];
@@ -314,7 +333,8 @@ static hipError_t launch_skin(const smplpp_model * m, int64_t n, const float * t
   const int nft = (int)((n + 32 * FT - 1) / (32 * FT));
   const int nq = (int)((m->VGn + 3) / 4);
   const int grid = 8 * ((nq + 7) / 8) * nft;
-  const size_t shmem = sizeof(float) * (size_t)(32 * FT) * (NJ * 12 + 3);
+  size_t shmem = sizeof(float) * (size_t)(32 * FT) * (NJ * 12 + 3);
+  if(getenv("SMPLPP_SKIN_ONE_PER_CU")) shmem = 100 * 1024; // timing experiment: one workgroup per CU
   static bool attr_set = false;
   if(!attr_set)
   {
@@ -325,7 +345,7 @@ static hipError_t launch_skin(const smplpp_model * m, int64_t n, const float * t
   }
   skin_kernel<FT, MAXW><<<dim3(grid), dim3(256), shmem, st>>>(m->ws.AT.as<float>(), m->ws.ldA, m->Bm, m->ldB,
                                                               m->ws.Gp.as<float>(), theta, m->wIdx, m->wVal, m->wSum, verts,
-                                                              rest, n, m->V, (int)m->VGn, nft);
+                                                              rest, n, m->V, (int)m->VGn, nft, getenv("SMPLPP_SKIN_DBG") ? atoi(getenv("SMPLPP_SKIN_DBG")) : 0);
   return hipGetLastError();
 }
 
@@ -344,6 +364,10 @@ static hipError_t launch_skin_w(const smplpp_model * m, int64_t n, const float *
   }
 }
 
+hipError_t launch_skin_persistent(const smplpp_model * m, int64_t n, const float * theta, const float * Gp_padded, float * verts,
+                                  float * rest, hipStream_t st); // skin_p.hip (experimental: one wave/SIMD, epilogue in the MFMA shadow)
+hipError_t launch_skin_queue(smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st); // skin_q.hip
+
 // Device-pointer FK (enqueue only).  Used by smplpp_fk and by the IK solver.
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
               float * xforms44, float * rest, float * poserot, hipStream_t st)
@@ -352,7 +376,9 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
   const int64_t ldA = ((n + 63) / 64) * 64;
   const bool relaid = (ldA != ws.ldA);
   HIP_TRY(ws.AT.reserve(sizeof(float) * (size_t)KP * ldA));
-  HIP_TRY(ws.Gp.reserve(sizeof(float) * (size_t)n * NJ * 12));
+  const int64_t n32 = ((n + 31) / 32) * 32; // the persistent kernel stages whole 32-frame tiles of G'
+  HIP_TRY(ws.Gp.reserve(sizeof(float) * (size_t)n32 * NJ * 12));
+  if(n32 > n) HIP_TRY(hipMemsetAsync(ws.Gp.as<float>() + n * NJ * 12, 0, sizeof(float) * (size_t)(n32 - n) * NJ * 12, st));
   ws.ldA = ldA;
   (void)relaid;
   if(ldA > n)
@@ -372,7 +398,16 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
       HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, st));
     }
-    if(n <= 32)
+    // SMPLPP_SKIN = v1 | p | q selects the form of the fused kernel for A/B runs.  Default p (skin_p.hip): one wavefront
+    // per SIMD, persistent, skinning rows issued in MFMA shadows — measured fastest; q (skin_q.hip, staggered work queue)
+    // and v1 (skin_kernel above) are kept for comparison.
+    static const char * form_env = getenv("SMPLPP_SKIN");
+    static const char form = form_env ? form_env[0] : 'p';
+    if(m->maxw <= 8 && form == 'q')
+      HIP_TRY(launch_skin_queue(m, n, theta, verts, rest, st));
+    else if(m->maxw <= 8 && form == 'p' && ws.dummy.reserve(4096) == hipSuccess)
+      HIP_TRY(launch_skin_persistent(m, n, theta, ws.Gp.as<float>(), verts, rest, st));
+    else if(n <= 32)
       HIP_TRY(launch_skin_w<1>(m, n, theta, verts, rest, st));
     else
       HIP_TRY(launch_skin_w<2>(m, n, theta, verts, rest, st));

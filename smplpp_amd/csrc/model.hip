@@ -135,7 +135,7 @@ extern "C" int smplpp_model_destroy(smplpp_model * m)
   for(void * p : ptrs)
     if(p) (void)hipFree(p);
   Workspace & w = m->ws;
-  for(DevBuf * b : {&w.AT, &w.Gp, &w.joints, &w.poserot, &w.beta, &w.theta, &w.verts, &w.rest, &w.xf44}) b->release();
+  for(DevBuf * b : {&w.AT, &w.Gp, &w.joints, &w.poserot, &w.beta, &w.theta, &w.verts, &w.rest, &w.xf44, &w.q_ctr, &w.q_desc, &w.dummy}) b->release();
   delete m;
   return SMPLPP_OK;
 }
