@@ -60,8 +60,13 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
   float * sG = lds + wave * P_LDS_WAVE;
   float * sRoot = sG + P_GWAVE;
   const int total = VGn * nft;
-  const int t_begin = blockIdx.x * items_per_block + wave;
-  int t_end = (blockIdx.x + 1) * items_per_block;
+  // XCD-aware run assignment: workgroups b and b + 8 share an XCD (round-robin dispatch), so give XCD x the x-th
+  // CONTIGUOUS eighth of the item list: every 84 KB slice of Bm is then streamed by one XCD's L2 only.
+  // (A wrong placement guess costs speed, never correctness: the runs tile the item list either way.)
+  const int nb = gridDim.x, per_x = (nb + 7) >> 3;
+  const int vb = (int)(blockIdx.x & 7) * per_x + (int)(blockIdx.x >> 3); // bijective when nb % 8 == 0
+  const int t_begin = vb * items_per_block + wave;
+  int t_end = (vb + 1) * items_per_block;
   if(t_end > total) t_end = total;
   if(t_begin >= t_end) return;
 
@@ -348,8 +353,8 @@ static hipError_t launch_p(const smplpp_model * m, int64_t n, const float * thet
   }
   int blocks = (total + 3) / 4;
   if(blocks > cus) blocks = cus;
+  blocks = (blocks + 7) & ~7; // the XCD-aware run assignment wants a multiple of 8 (idle runs exit at once)
   const int ipb = (total + blocks - 1) / blocks;
-  blocks = (total + ipb - 1) / ipb;
   const size_t shmem = sizeof(float) * 4 * P_LDS_WAVE;
   static bool attr_set = false;
   if(!attr_set)
