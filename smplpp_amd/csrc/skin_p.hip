@@ -20,6 +20,7 @@
 namespace smplpp_hip
 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v3f __attribute__((ext_vector_type(3), aligned(4)));
 typedef float v4f __attribute__((ext_vector_type(4))); // first-class vector: an array of these is promoted to registers
 
 constexpr int P_KSTEPS = KP / 2;          // 110
@@ -76,30 +77,32 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
   float jw[MAXW], jwp[MAXW];
   ItemCtx cur, prev;
 
-  // Operand addressing: wave-uniform row base (SGPR pair: AT / Bm + k * ld) + a per-lane 32-bit BYTE offset that is
-  // constant for a whole item -> `global_load_dword v, v_off, s[base]` with immediate column offsets; no 64-bit
-  // per-load address registers.
-  auto item_offs = [&](int t, unsigned & offA, unsigned & offB) {
-    const int vg = t / nft, ft = t % nft;
-    offA = (unsigned)(((int64_t)half * ldA + (int64_t)ft * 32 + l31) * 4);
-    offB = (unsigned)(((int64_t)half * ldB + (int64_t)vg * (3 * VG) + l31) * 4);
+  // Operand addressing: wave-uniform base of the item's tile (SGPR pair, recomputed per item so that the compiler does
+  // not hoist 110 row bases out of the item loop and spill them) + a per-lane 32-bit BYTE offset that never changes.
+  const unsigned laneA = (unsigned)(((int64_t)half * ldA + l31) * 4);
+  const unsigned laneB = (unsigned)(((int64_t)half * ldB + l31) * 4);
+  auto item_bases = [&](int t, const float *& Ab, const float *& Bb) {
+    const int tu = __builtin_amdgcn_readfirstlane(t); // t is wave-uniform; say so
+    const int vg = tu / nft, ft = tu % nft;
+    Ab = AT + (int64_t)ft * 32;
+    Bb = Bm + (int64_t)vg * (3 * VG);
   };
-  auto load_chunk = [&](unsigned offA, unsigned offB, int c, float (&a)[P_UNR], float (&b)[P_UNR][3]) {
+  auto load_chunk = [&](const float * Ab, const float * Bb, int c, float (&a)[P_UNR], float (&b)[P_UNR][3]) {
 #pragma unroll
     for(int u = 0; u < P_UNR; u++)
     {
       const int64_t k2 = 2 * (c * P_UNR + u);
-      const char * rowA = reinterpret_cast<const char *>(AT + k2 * ldA); // uniform
-      const char * rowB = reinterpret_cast<const char *>(Bm + k2 * ldB); // uniform
-      a[u] = *reinterpret_cast<const float *>(rowA + offA);
+      const char * rowA = reinterpret_cast<const char *>(Ab + k2 * ldA); // uniform
+      const char * rowB = reinterpret_cast<const char *>(Bb + k2 * ldB); // uniform
+      a[u] = *reinterpret_cast<const float *>(rowA + laneA);
 #pragma unroll
-      for(int x = 0; x < 3; x++) b[u][x] = *reinterpret_cast<const float *>(rowB + offB + VG * 4 * x);
+      for(int x = 0; x < 3; x++) b[u][x] = *reinterpret_cast<const float *>(rowB + laneB + VG * 4 * x);
     }
   };
 
-  unsigned offA, offB;
-  item_offs(t_begin, offA, offB);
-  load_chunk(offA, offB, 0, abuf[0], bbuf[0]);
+  const float * Abase, * Bbase;
+  item_bases(t_begin, Abase, Bbase);
+  load_chunk(Abase, Bbase, 0, abuf[0], bbuf[0]);
 
   // one work item; HP (compile time) = there is a previous item whose epilogue rides in this item's MFMA shadow.
   // Everything inside a chunk is straight-line code (stores of masked-off lanes go to a dummy line) so that the
@@ -123,8 +126,8 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
       cur.winv = 1.0f / wSum[vv]; // one reciprocal per lane instead of IEEE divisions (<= 1 ulp: 6e-8 m at 1 m)
     }
     const int tn = (t + 4 < t_end) ? t + 4 : t; // next item (or this one again: harmless extra prefetch)
-    unsigned offAn, offBn;
-    item_offs(tn, offAn, offBn);
+    const float * Abn, * Bbn;
+    item_bases(tn, Abn, Bbn);
 #pragma unroll
     for(int x = 0; x < 3; x++)
 #pragma unroll
@@ -173,12 +176,12 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
         {
           const int u = l / 4, w = l % 4; // per k-step: A, B.x, B.y, B.z
           const int cn = (C + 1 < P_CHUNKS) ? C + 1 : 0;
-          const unsigned oA = (C + 1 < P_CHUNKS) ? offA : offAn, oB = (C + 1 < P_CHUNKS) ? offB : offBn;
+          const float * Ab = (C + 1 < P_CHUNKS) ? Abase : Abn, * Bb = (C + 1 < P_CHUNKS) ? Bbase : Bbn;
           const int64_t k2 = 2 * (cn * P_UNR + u);
           if(w == 0)
-            abuf[(C + 1) & 1][u] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(AT + k2 * ldA) + oA);
+            abuf[(C + 1) & 1][u] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(Ab + k2 * ldA) + laneA);
           else
-            bbuf[(C + 1) & 1][u][w - 1] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(Bm + k2 * ldB) + oB + VG * 4 * (w - 1));
+            bbuf[(C + 1) & 1][u][w - 1] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(Bb + k2 * ldB) + laneB + VG * 4 * (w - 1));
         }
         // ---- one piece of row R of the PREVIOUS item (branch-free: dead lanes store to a dummy line)
         if constexpr(HP && C < 16)
@@ -191,9 +194,8 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
             if constexpr(WANT_REST)
             {
               float * o = (live && prev.rout) ? prev.rout + fprev * V * 3 : dummy + lane * 4;
-              o[0] = rx;
-              o[1] = ry;
-              o[2] = rz;
+              v3f ov = {rx, ry, rz};
+              __builtin_nontemporal_store(ov, reinterpret_cast<v3f *>(o));
             }
           }
           if constexpr(MAXW == 4)
@@ -233,9 +235,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
             if constexpr(S == 14)
             {
               float * o = (live && prev.vout) ? prev.vout + fprev * V * 3 : dummy + lane * 4;
-              o[0] = rx * prev.winv + rt0;
-              o[1] = ry * prev.winv + rt1;
-              o[2] = rz * prev.winv + rt2;
+              // write-once output: non-temporal, so 85 MB of vertices do not evict the Bm slices from this XCD's L2
+              v3f ov = {rx * prev.winv + rt0, ry * prev.winv + rt1, rz * prev.winv + rt2};
+              __builtin_nontemporal_store(ov, reinterpret_cast<v3f *>(o));
             }
           }
           else
@@ -286,8 +288,8 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
       jwp[i] = jw[i];
     }
     prev = cur;
-    offA = offAn;
-    offB = offBn;
+    Abase = Abn;
+    Bbase = Bbn;
   };
 
   do_item(t_begin, std::false_type{});
