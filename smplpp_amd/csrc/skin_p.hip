@@ -14,6 +14,7 @@
 // Operands go L2 -> VGPR directly (one dword per lane per MFMA), double-buffered one k-chunk (960 MFMA-cycles) ahead.
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
                                                         const uint8_t * __restrict__ wIdx, const float * __restrict__ wVal,
                                                         const float * __restrict__ wSum, float * __restrict__ verts,
                                                         float * __restrict__ rest, float * __restrict__ dummy, int64_t n, int64_t V, int VGn,
-                                                        int nft, int items_per_block)
+                                                        int nft, int items_per_block, int dbg_mode)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
@@ -86,6 +87,11 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
     const int vg = tu / nft, ft = tu % nft;
     Ab = AT + (int64_t)ft * 32;
     Bb = Bm + (int64_t)vg * (3 * VG);
+    if(dbg_mode == 1) // timing experiment: every item streams the same operand tile (pure L1/L2 hits)
+    {
+      Ab = AT;
+      Bb = Bm;
+    }
   };
   auto load_chunk = [&](const float * Ab, const float * Bb, int c, float (&a)[P_UNR], float (&b)[P_UNR][3]) {
 #pragma unroll
@@ -368,7 +374,7 @@ static hipError_t launch_p(const smplpp_model * m, int64_t n, const float * thet
   }
   skin_kernel_p<MAXW, WANT_REST><<<dim3(blocks), dim3(256), shmem, st>>>(m->ws.AT.as<float>(), m->ws.ldA, m->Bm, m->ldB, Gp_padded, theta,
                                                                         m->wIdx, m->wVal, m->wSum, verts, rest, m->ws.dummy.as<float>(), n, m->V,
-                                                                        (int)m->VGn, nft, ipb);
+                                                                        (int)m->VGn, nft, ipb, getenv("SMPLPP_SKIN_DBG") ? atoi(getenv("SMPLPP_SKIN_DBG")) : 0);
   return hipGetLastError();
 }
 
