@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--no-ik", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time one final RCCL gather of all vertices to rank 0")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses GPU 0 (use with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -123,8 +126,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    if args.all_ranks_on_device0:
+        local = 0
     torch.cuda.set_device(local)
-    D.init_process_group("nccl" if world > 1 else None)
+    D.init_process_group((args.backend or "nccl") if world > 1 else None)
 
     model = model_io.synthetic_model()
     smpl = SMPL()
@@ -237,13 +242,15 @@ def main():
             "frames_per_gpu": n, "parallelism": "frames sharded x%d, no data-path collective" % world,
         },
         "roofline": {
-            "kernel": "skin_kernel<2,4> (fused blend-shape GEMM + linear blend skinning)",
+            "kernel": "skin_kernel_p<4,false> (fused blend-shape GEMM + linear blend skinning, persistent)",
             "bound": "mfma", "achieved": mfma_tflops, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
             "frac": mfma_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": traffic,
             "kernel_ms": skin_ms, "launches_timed": launches,
             "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
                     "algorithmic_bytes_per_launch": ALG_BYTES_CONST + ALG_BYTES_PER_FRAME * n},
-            "note": "batch 1024 in exact fp32 has 152 FLOP/B: the fp32 MFMA pipe binds before HBM (ridge ~20 FLOP/B)",
+            "note": "batch 1024 in exact fp32 has 152 FLOP/B: the fp32 MFMA pipe binds before HBM (ridge ~20 FLOP/B); "
+                    "peak is the 157.3 TF datasheet figure at 2.4 GHz — under sustained fp32 MFMA the chip holds ~1.7 GHz "
+                    "(profiles/README.md), i.e. a practical ceiling near 110 TF",
         },
     }
     if ik is not None:

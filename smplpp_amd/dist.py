@@ -81,7 +81,7 @@ def max_over_ranks(value: float) -> float:
 
     if not (dist.is_available() and dist.is_initialized()):
         return value
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"  # gloo reduces host tensors
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
