@@ -78,35 +78,41 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
   float jw[MAXW], jwp[MAXW];
   ItemCtx cur, prev;
 
-  // Operand addressing: wave-uniform base of the item's tile (SGPR pair, recomputed per item so that the compiler does
-  // not hoist 110 row bases out of the item loop and spill them) + a per-lane 32-bit BYTE offset that never changes.
-  const unsigned laneA = (unsigned)(((int64_t)half * ldA + l31) * 4);
-  const unsigned laneB = (unsigned)(((int64_t)half * ldB + l31) * 4);
-  auto item_bases = [&](int t, const float *& Ab, const float *& Bb) {
+  // Operand addressing: buffer loads (T8) — a 128-bit buffer descriptor per operand in SGPRs, a per-lane byte offset
+  // that never changes (VGPR) and a wave-uniform byte offset per (item, k-row) in an SGPR: no per-load VALU address
+  // arithmetic and no 64-bit address registers.
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(AT), 0, (int)(KP * ldA * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Bm), 0, (int)(KP * ldB * 4), 0x00020000);
+  const int laneA = (int)(((int64_t)half * ldA + l31) * 4);
+  const int laneB = (int)(((int64_t)half * ldB + l31) * 4);
+  const int rowA = (int)(ldA * 4), rowB = (int)(ldB * 4); // bytes per k-row
+  auto item_bases = [&](int t, int & Ab, int & Bb) {
     const int tu = __builtin_amdgcn_readfirstlane(t); // t is wave-uniform; say so
     const int vg = tu / nft, ft = tu % nft;
-    Ab = AT + (int64_t)ft * 32;
-    Bb = Bm + (int64_t)vg * (3 * VG);
+    Ab = ft * 32 * 4;
+    Bb = vg * (3 * VG) * 4;
     if(dbg_mode == 1) // timing experiment: every item streams the same operand tile (pure L1/L2 hits)
     {
-      Ab = AT;
-      Bb = Bm;
+      Ab = 0;
+      Bb = 0;
     }
   };
-  auto load_chunk = [&](const float * Ab, const float * Bb, int c, float (&a)[P_UNR], float (&b)[P_UNR][3]) {
+  auto ldA_ = [&](int Ab, int k2) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, laneA, Ab + k2 * rowA, 0)); };
+  auto ldB_ = [&](int Bb, int k2, int x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, laneB + VG * 4 * x, Bb + k2 * rowB, 0));
+  };
+  auto load_chunk = [&](int Ab, int Bb, int c, float (&a)[P_UNR], float (&b)[P_UNR][3]) {
 #pragma unroll
     for(int u = 0; u < P_UNR; u++)
     {
-      const int64_t k2 = 2 * (c * P_UNR + u);
-      const char * rowA = reinterpret_cast<const char *>(Ab + k2 * ldA); // uniform
-      const char * rowB = reinterpret_cast<const char *>(Bb + k2 * ldB); // uniform
-      a[u] = *reinterpret_cast<const float *>(rowA + laneA);
+      const int k2 = 2 * (c * P_UNR + u);
+      a[u] = ldA_(Ab, k2);
 #pragma unroll
-      for(int x = 0; x < 3; x++) b[u][x] = *reinterpret_cast<const float *>(rowB + laneB + VG * 4 * x);
+      for(int x = 0; x < 3; x++) b[u][x] = ldB_(Bb, k2, x);
     }
   };
 
-  const float * Abase, * Bbase;
+  int Abase, Bbase;
   item_bases(t_begin, Abase, Bbase);
   load_chunk(Abase, Bbase, 0, abuf[0], bbuf[0]);
 
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
       cur.winv = 1.0f / wSum[vv]; // one reciprocal per lane instead of IEEE divisions (<= 1 ulp: 6e-8 m at 1 m)
     }
     const int tn = (t + 4 < t_end) ? t + 4 : t; // next item (or this one again: harmless extra prefetch)
-    const float * Abn, * Bbn;
+    int Abn, Bbn;
     item_bases(tn, Abn, Bbn);
 #pragma unroll
     for(int x = 0; x < 3; x++)
@@ -182,12 +188,12 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
         {
           const int u = l / 4, w = l % 4; // per k-step: A, B.x, B.y, B.z
           const int cn = (C + 1 < P_CHUNKS) ? C + 1 : 0;
-          const float * Ab = (C + 1 < P_CHUNKS) ? Abase : Abn, * Bb = (C + 1 < P_CHUNKS) ? Bbase : Bbn;
-          const int64_t k2 = 2 * (cn * P_UNR + u);
+          const int Ab = (C + 1 < P_CHUNKS) ? Abase : Abn, Bb = (C + 1 < P_CHUNKS) ? Bbase : Bbn;
+          const int k2 = 2 * (cn * P_UNR + u);
           if(w == 0)
-            abuf[(C + 1) & 1][u] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(Ab + k2 * ldA) + laneA);
+            abuf[(C + 1) & 1][u] = ldA_(Ab, k2);
           else
-            bbuf[(C + 1) & 1][u][w - 1] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(Bb + k2 * ldB) + laneB + VG * 4 * (w - 1));
+            bbuf[(C + 1) & 1][u][w - 1] = ldB_(Bb, k2, w - 1);
         }
         // ---- one piece of row R of the PREVIOUS item (branch-free: dead lanes store to a dummy line)
         if constexpr(HP && C < 16)
