@@ -9,7 +9,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsmplpp_hip.so")
+LIB_PATH = os.environ.get("SMPLPP_HIP_LIB") or os.path.join(HERE, "libsmplpp_hip.so")  # override: A/B of two builds on one box
 HEADER = os.path.join(os.path.dirname(HERE), "include", "smplpp_hip.h")
 
 HOST, DEVICE = 0, 1

@@ -405,7 +405,7 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
     static const char form = form_env ? form_env[0] : 'p';
     if(m->maxw <= 8 && form == 'q')
       HIP_TRY(launch_skin_queue(m, n, theta, verts, rest, st));
-    else if(m->maxw <= 8 && form == 'p' && ws.dummy.reserve(4096) == hipSuccess)
+    else if(m->maxw <= 8 && form == 'p' && n * m->V * 12 < 0x7fffff00LL && ws.dummy.reserve(4096) == hipSuccess)
       HIP_TRY(launch_skin_persistent(m, n, theta, ws.Gp.as<float>(), verts, rest, st));
     else if(n <= 32)
       HIP_TRY(launch_skin_w<1>(m, n, theta, verts, rest, st));

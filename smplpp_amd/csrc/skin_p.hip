@@ -22,6 +22,7 @@ namespace smplpp_hip
 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v3f __attribute__((ext_vector_type(3), aligned(4)));
+typedef unsigned v3u __attribute__((ext_vector_type(3)));
 typedef float v4f __attribute__((ext_vector_type(4))); // first-class vector: an array of these is promoted to registers
 
 constexpr int P_KSTEPS = KP / 2;          // 110
@@ -47,6 +48,7 @@ struct ItemCtx // everything the epilogue of an item needs after its MFMAs are d
   float * vout; // verts + v * 3 (nullptr: lane has no vertex)
   float * rout;
   float winv;
+  int voff;     // byte offset of (frame f0 + 4 * half, vertex v) in an output array; out of range when the lane has no vertex
 };
 
 template<int MAXW, bool WANT_REST>
@@ -83,6 +85,12 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
   // arithmetic and no 64-bit address registers.
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(AT), 0, (int)(KP * ldA * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Bm), 0, (int)(KP * ldB * 4), 0x00020000);
+  // outputs: same scheme; the range check of the descriptor (num_records = n * V * 12 bytes) drops the stores of frames
+  // >= n and of lanes without a vertex (offset forced out of range), so the epilogue needs neither branches nor a dummy line
+  // (the launcher only picks this form while n * V * 12 fits the 32-bit num_records)
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(verts, 0, (int)(verts ? n * V * 12 : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(rest, 0, (int)(rest ? n * V * 12 : 0), 0x00020000);
+  const int frameB = (int)(V * 12); // bytes per frame of output
   const int laneA = (int)(((int64_t)half * ldA + l31) * 4);
   const int laneB = (int)(((int64_t)half * ldB + l31) * 4);
   const int rowA = (int)(ldA * 4), rowB = (int)(ldB * 4); // bytes per k-row
@@ -127,6 +135,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
     cur.f0 = (int64_t)ft * 32;
     cur.vout = (has_v && verts) ? verts + v * 3 : nullptr;
     cur.rout = (has_v && WANT_REST && rest) ? rest + v * 3 : nullptr;
+    cur.voff = has_v ? (int)(v * 12 + (int64_t)(4 * half) * frameB) : 0x7fffff00;
     {
       const int64_t vv = has_v ? v : 0;
 #pragma unroll
@@ -158,8 +167,6 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
       float rstage[2] = {0.f, 0.f};
       constexpr int R = C < 16 ? C : 0;
       const int fl = (R & 3) + 8 * (R >> 2) + 4 * half; // accumulator row -> frame in tile
-      const int64_t fprev = prev.f0 + fl;
-      const bool live = fprev < n;
       const float * gfr = sG + fl * (NJ * 12);
       static_for<P_UNR * 3>([&](auto ss) {
         constexpr int S = decltype(ss)::value;
@@ -205,9 +212,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
             rz = accp[2][R];
             if constexpr(WANT_REST)
             {
-              float * o = (live && prev.rout) ? prev.rout + fprev * V * 3 : dummy + lane * 4;
               v3f ov = {rx, ry, rz};
-              __builtin_nontemporal_store(ov, reinterpret_cast<v3f *>(o));
+              __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsR, prev.voff,
+                                                    __builtin_amdgcn_readfirstlane((int)(prev.f0 + ((R & 3) + 8 * (R >> 2))) * frameB), 2);
             }
           }
           if constexpr(MAXW == 4)
@@ -246,10 +253,10 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
             }
             if constexpr(S == 14)
             {
-              float * o = (live && prev.vout) ? prev.vout + fprev * V * 3 : dummy + lane * 4;
-              // write-once output: non-temporal, so 85 MB of vertices do not evict the Bm slices from this XCD's L2
+              // write-once output: non-temporal (aux = 2), so 85 MB of vertices do not evict the Bm slices from this XCD's L2
               v3f ov = {rx * prev.winv + rt0, ry * prev.winv + rt1, rz * prev.winv + rt2};
-              __builtin_nontemporal_store(ov, reinterpret_cast<v3f *>(o));
+              __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsV, prev.voff,
+                                                    __builtin_amdgcn_readfirstlane((int)(prev.f0 + ((R & 3) + 8 * (R >> 2))) * frameB), 2);
             }
           }
           else
@@ -279,10 +286,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_p(const float * __restrict
               const float hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
               const float hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
               const float hz = ((m2.x * rx + m2.y * ry) + m2.z * rz) + m2.w;
-              float * o = (live && prev.vout) ? prev.vout + fprev * V * 3 : dummy + lane * 4;
-              o[0] = hx * prev.winv + rt0;
-              o[1] = hy * prev.winv + rt1;
-              o[2] = hz * prev.winv + rt2;
+              v3f ov = {hx * prev.winv + rt0, hy * prev.winv + rt1, hz * prev.winv + rt2};
+              __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsV, prev.voff,
+                                                    __builtin_amdgcn_readfirstlane((int)(prev.f0 + ((R & 3) + 8 * (R >> 2))) * frameB), 2);
             }
           }
         }

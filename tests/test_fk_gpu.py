@@ -120,6 +120,23 @@ def test_fk_device_pointers_torch(smpl, oracle_synth):
     assert np.abs(o["joints"].cpu().numpy() - r["joints"]).max() < VERT_TOL
 
 
+@pytest.mark.parametrize("n", [1, 5, 33, 100])
+def test_fk_writes_only_its_frames(smpl, n):
+    """The fused kernel computes whole 32-frame tiles; frames >= n must be dropped, not stored.  The outputs are
+    views into a larger canary-filled allocation, so a stray store is detected instead of faulting."""
+    import torch
+    from smplpp_amd import model_io
+
+    beta, theta = model_io.synthetic_inputs(n, seed=n)
+    big = {k: torch.full((n + 64, 6890, 3), 777.0, device="cuda") for k in ("verts", "rest")}
+    smpl.launch(torch.from_numpy(beta).cuda(), torch.from_numpy(theta).cuda(), want=("verts", "rest"),
+                out={k: big[k][:n] for k in big})
+    torch.cuda.synchronize()
+    for k in big:
+        assert bool((big[k][n:] == 777.0).all()), k
+        assert bool((big[k][:n] != 777.0).all()), k
+
+
 def test_stage_kats_on_gpu(kats):
     """The reference's own stage KATs (src/toolbox/Tester.cpp) through the stage-level entry points."""
     from smplpp_amd import smpl as S
