@@ -28,6 +28,38 @@ __host__ __device__ inline int64_t bcol(int64_t v, int x)
   return (v / VG) * (3 * VG) + x * VG + (v % VG);
 }
 
+// ---- bf16x3 form of the fused kernel (skin_b.hip): operands in MFMA fragment order, three bf16 pieces per fp32 value.
+// A "piece" = the 1 KiB one wavefront feeds to one v_mfma_f32_32x32x16_bf16: lane l = 32 h + r holds k = 16 ks + 8 h + j,
+// j = 0..7, of row (frame) / column (vertex coordinate) r.
+//   A3 [ceil(n/64)][BB_KS][fh 2][piece s 3][64 lanes][8 bf16]           frame = 64 ftp + 32 fh + r
+//   B3 [ceil(V/64)][BB_KS][vh 2][coordinate x 3][piece s 3][64][8]      vertex = 64 vgp + 32 vh + r
+constexpr int BB_KS = 14;                 // k-steps of 16 (K = 220 padded to 224)
+constexpr int BB_A_BYTES = 6 * 1024;      // A pieces of one (frame-tile pair, k-step)
+constexpr int BB_B_BYTES = 18 * 1024;     // B pieces of one (vertex-group pair, k-step)
+constexpr int BB_KSTEP_BYTES = BB_A_BYTES + BB_B_BYTES;
+// x = p0 + p1 + p2 exactly (round-to-nearest-even pieces; finite inputs)
+__host__ __device__ inline uint16_t bf16_rn_bits(float x)
+{
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__host__ __device__ inline float bf16_bits_to_float(uint16_t b)
+{
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+__host__ __device__ inline void split_bf16x3(float x, uint16_t & p0, uint16_t & p1, uint16_t & p2)
+{
+  p0 = bf16_rn_bits(x);
+  const float r1 = x - bf16_bits_to_float(p0);
+  p1 = bf16_rn_bits(r1);
+  const float r2 = r1 - bf16_bits_to_float(p1);
+  p2 = bf16_rn_bits(r2);
+}
+
 void set_error(const std::string & msg);
 int fail(int code, const std::string & msg);
 int hip_fail(hipError_t e, const char * what, const char * file, int line);
@@ -71,6 +103,7 @@ struct DevBuf
 struct Workspace
 {
   DevBuf AT;      // [KP][ldA] fp32, K-major A operand (pose coefficients | beta | 1)
+  DevBuf A3;      // the same coefficients as bf16x3 pieces in fragment order (skin_b.hip)
   DevBuf Gp;      // [n][24][12] relative transforms, 3x4 row-major
   DevBuf joints;  // [n][24][3]
   DevBuf poserot; // [n][24][9]
@@ -92,6 +125,8 @@ struct smplpp_model
   int maxw = 0;     // skinning weights kept per vertex: 4, 8 or 24
   // device arrays
   float * Bm = nullptr;        // [KP][ldB]
+  uint8_t * B3 = nullptr;      // Bm as bf16x3 pieces in MFMA fragment order (layout above)
+  int64_t VGPn = 0;            // vertex-group pairs: ceil(V / 64)
   uint8_t * wIdx = nullptr;    // [VGn*32][maxw]
   float * wVal = nullptr;      // [VGn*32][maxw]
   float * wSum = nullptr;      // [VGn*32]  sum_j W[v,j] in ascending j (the blended homogeneous w)

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void pose_kernel(const float * __restrict__ bet
                                                   float * __restrict__ Gp, float * __restrict__ joints_out,
                                                   float * __restrict__ rot_out, float * __restrict__ xf44_out,
                                                   const float * __restrict__ rot_in, const float * __restrict__ joints_in,
-                                                  int64_t n)
+                                                  int64_t n, uint16_t * __restrict__ A3 = nullptr)
 {
   const int64_t f = blockIdx.x;
   const int lane = threadIdx.x;
@@ -91,6 +91,42 @@ __global__ __launch_bounds__(64) void pose_kernel(const float * __restrict__ bet
     if(lane == NB) AT[(int64_t)K_ONE * ldA + f] = 1.0f;
     if(lane == NB + 1) AT[(int64_t)(K_ONE + 1) * ldA + f] = 0.0f;
     if(lane == NB + 2) AT[(int64_t)(K_ONE + 2) * ldA + f] = 0.0f;
+  }
+  if(A3 && lane < 28)
+  {
+    // the same 220 coefficients (padded to 224) as bf16x3 pieces in MFMA fragment order (layout: common.h): lane c owns
+    // k = 8 c .. 8 c + 7 = element j of MFMA lane 32 h + r in k-step ks, three 16-byte stores
+    const int ks = lane >> 1, h = lane & 1;
+    const int64_t ftp = f >> 6;
+    const int fh = (int)((f >> 5) & 1), r = (int)(f & 31);
+    uint16_t pc[3][8];
+#pragma unroll
+    for(int j = 0; j < 8; j++)
+    {
+      const int k = 8 * lane + j;
+      float a = 0.0f;
+      if(k < NP)
+      {
+        const int q = k % 9;
+        a = sR[1 + k / 9][q] - ((q == 0 || q == 4 || q == 8) ? 1.0f : 0.0f);
+      }
+      else if(k < NP + NB)
+        a = sBeta[k - NP];
+      else if(k == K_ONE)
+        a = 1.0f;
+      split_bf16x3(a, pc[0][j], pc[1][j], pc[2][j]);
+    }
+#pragma unroll
+    for(int s = 0; s < 3; s++)
+    {
+      uint16_t * dst = A3 + ((((ftp * BB_KS + ks) * 2 + fh) * 3 + s) * 64 + (32 * h + r)) * 8;
+      uint4 w;
+      w.x = pc[s][0] | ((uint32_t)pc[s][1] << 16);
+      w.y = pc[s][2] | ((uint32_t)pc[s][3] << 16);
+      w.z = pc[s][4] | ((uint32_t)pc[s][5] << 16);
+      w.w = pc[s][6] | ((uint32_t)pc[s][7] << 16);
+      *reinterpret_cast<uint4 *>(dst) = w;
+    }
   }
   for(int e = lane; e < NJ * 3; e += 64) // joints (src/JointRegression.cpp:588-590 through the folded regressor)
   {
@@ -366,6 +402,7 @@ static hipError_t launch_skin_w(const smplpp_model * m, int64_t n, const float *
 
 hipError_t launch_skin_persistent(const smplpp_model * m, int64_t n, const float * theta, const float * Gp_padded, float * verts,
                                   float * rest, hipStream_t st); // skin_p.hip (experimental: one wave/SIMD, epilogue in the MFMA shadow)
+hipError_t launch_skin_bf16x3(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st); // skin_b.hip
 hipError_t launch_skin_queue(smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st); // skin_q.hip
 
 // Device-pointer FK (enqueue only).  Used by smplpp_fk and by the IK solver.
@@ -373,21 +410,36 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
               float * xforms44, float * rest, float * poserot, hipStream_t st)
 {
   Workspace & ws = m->ws;
-  const int64_t ldA = ((n + 63) / 64) * 64;
-  const bool relaid = (ldA != ws.ldA);
-  HIP_TRY(ws.AT.reserve(sizeof(float) * (size_t)KP * ldA));
-  const int64_t n32 = ((n + 31) / 32) * 32; // the persistent kernel stages whole 32-frame tiles of G'
-  HIP_TRY(ws.Gp.reserve(sizeof(float) * (size_t)n32 * NJ * 12));
-  if(n32 > n) HIP_TRY(hipMemsetAsync(ws.Gp.as<float>() + n * NJ * 12, 0, sizeof(float) * (size_t)(n32 - n) * NJ * 12, st));
-  ws.ldA = ldA;
-  (void)relaid;
-  if(ldA > n)
+  // SMPLPP_SKIN = b | p | q | v1 selects the form of the fused kernel for A/B runs.  Default b (skin_b.hip): bf16x3
+  // operand pieces on the bf16 matrix pipe, fp32-exact; p (skin_p.hip): fp32 MFMA, one wavefront per SIMD, persistent,
+  // skinning rows issued in MFMA shadows; q (skin_q.hip, staggered work queue) and v1 (skin_kernel above) are kept for
+  // comparison.  Forms with 32-bit output offsets fall back to v1 for outputs of 2 GiB and more.
+  static const char * form_env = getenv("SMPLPP_SKIN");
+  char form = form_env ? form_env[0] : 'b';
+  if(m->maxw > 8) form = 'v';
+  if((form == 'b' || form == 'p') && n * m->V * 12 >= 0x7fffff00LL) form = 'v';
+  const int64_t n64 = ((n + 63) / 64) * 64;
+  HIP_TRY(ws.Gp.reserve(sizeof(float) * (size_t)n64 * NJ * 12)); // b / p stage whole frame tiles of G' (padding never stored)
+  if(form == 'b')
   {
-    int64_t cnt = (int64_t)KP * (ldA - n);
-    zero_pad_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(ws.AT.as<float>(), ldA, n);
+    HIP_TRY(ws.A3.reserve((size_t)(n64 / 64) * BB_KS * BB_A_BYTES));
+    pose_kernel<<<dim3((unsigned)n), dim3(64), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, nullptr, 0, ws.Gp.as<float>(), joints,
+                                                        poserot, xforms44, nullptr, nullptr, n, ws.A3.as<uint16_t>());
   }
-  pose_kernel<<<dim3((unsigned)n), dim3(64), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, ws.AT.as<float>(), ldA,
-                                                      ws.Gp.as<float>(), joints, poserot, xforms44, nullptr, nullptr, n);
+  else
+  {
+    const int64_t ldA = n64;
+    HIP_TRY(ws.AT.reserve(sizeof(float) * (size_t)KP * ldA));
+    if(n64 > n) HIP_TRY(hipMemsetAsync(ws.Gp.as<float>() + n * NJ * 12, 0, sizeof(float) * (size_t)(n64 - n) * NJ * 12, st));
+    ws.ldA = ldA;
+    if(ldA > n)
+    {
+      int64_t cnt = (int64_t)KP * (ldA - n);
+      zero_pad_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(ws.AT.as<float>(), ldA, n);
+    }
+    pose_kernel<<<dim3((unsigned)n), dim3(64), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, ws.AT.as<float>(), ldA,
+                                                        ws.Gp.as<float>(), joints, poserot, xforms44, nullptr, nullptr, n);
+  }
   HIP_TRY(hipGetLastError());
   if(verts || rest)
   {
@@ -398,14 +450,11 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
       HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, st));
     }
-    // SMPLPP_SKIN = v1 | p | q selects the form of the fused kernel for A/B runs.  Default p (skin_p.hip): one wavefront
-    // per SIMD, persistent, skinning rows issued in MFMA shadows — measured fastest; q (skin_q.hip, staggered work queue)
-    // and v1 (skin_kernel above) are kept for comparison.
-    static const char * form_env = getenv("SMPLPP_SKIN");
-    static const char form = form_env ? form_env[0] : 'p';
-    if(m->maxw <= 8 && form == 'q')
+    if(form == 'b')
+      HIP_TRY(launch_skin_bf16x3(m, n, theta, verts, rest, st));
+    else if(form == 'q')
       HIP_TRY(launch_skin_queue(m, n, theta, verts, rest, st));
-    else if(m->maxw <= 8 && form == 'p' && n * m->V * 12 < 0x7fffff00LL && ws.dummy.reserve(4096) == hipSuccess)
+    else if(form == 'p' && ws.dummy.reserve(4096) == hipSuccess)
       HIP_TRY(launch_skin_persistent(m, n, theta, ws.Gp.as<float>(), verts, rest, st));
     else if(n <= 32)
       HIP_TRY(launch_skin_w<1>(m, n, theta, verts, rest, st));

@@ -65,6 +65,32 @@ __global__ void relayout_basis_kernel(const float * __restrict__ P, const float 
   }
 }
 
+// B3 <- Bm as bf16x3 pieces in MFMA fragment order (layout: common.h).  One thread per (vertex-group pair, k-step,
+// piece, lane): 8 consecutive k of one column.
+__global__ void relayout_basis_bf16x3_kernel(const float * __restrict__ Bm, int64_t ldB, int64_t V, int64_t nvgp,
+                                             uint16_t * __restrict__ B3)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // ((vgp * KS + ks) * 6 + vh * 3 + x) * 64 + lane
+  if(i >= nvgp * BB_KS * 6 * 64) return;
+  const int lane = (int)(i % 64), h = lane >> 5, r = lane & 31;
+  const int vx = (int)((i / 64) % 6), vh = vx / 3, x = vx % 3;
+  const int ks = (int)((i / (64 * 6)) % BB_KS);
+  const int64_t vgp = i / (64 * 6 * BB_KS);
+  const int64_t v = vgp * 64 + vh * 32 + r;
+  uint16_t pc[3][8];
+  for(int j = 0; j < 8; j++)
+  {
+    const int k = ks * 16 + 8 * h + j;
+    const float val = (v < V && k < KP) ? Bm[(int64_t)k * ldB + bcol(v, x)] : 0.0f;
+    split_bf16x3(val, pc[0][j], pc[1][j], pc[2][j]);
+  }
+  for(int s = 0; s < 3; s++)
+  {
+    uint16_t * dst = B3 + ((((vgp * BB_KS + ks) * 6 + vx) * 3 + s) * 64 + lane) * 8;
+    for(int j = 0; j < 8; j++) dst[j] = pc[s][j];
+  }
+}
+
 // One block per (joint j, coordinate x, term t): t < 10 -> JS[j][x][t] = sum_v Jreg[j,v] S[v,x,t];
 // t == 10 -> J0[j][x] = sum_v Jreg[j,v] T[v,x].  Wavefront (64-lane) shuffle reduction, then across the 4 waves.
 __global__ __launch_bounds__(256) void fold_regressor_kernel(const float * __restrict__ Jreg, const float * __restrict__ S,
@@ -131,11 +157,11 @@ extern "C" int smplpp_model_destroy(smplpp_model * m)
 {
   if(!m) return SMPLPP_OK;
   (void)hipSetDevice(m->device);
-  void * ptrs[] = {m->Bm, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm};
+  void * ptrs[] = {m->Bm, m->B3, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm};
   for(void * p : ptrs)
     if(p) (void)hipFree(p);
   Workspace & w = m->ws;
-  for(DevBuf * b : {&w.AT, &w.Gp, &w.joints, &w.poserot, &w.beta, &w.theta, &w.verts, &w.rest, &w.xf44, &w.q_ctr, &w.q_desc, &w.dummy}) b->release();
+  for(DevBuf * b : {&w.AT, &w.A3, &w.Gp, &w.joints, &w.poserot, &w.beta, &w.theta, &w.verts, &w.rest, &w.xf44, &w.q_ctr, &w.q_desc, &w.dummy}) b->release();
   delete m;
   return SMPLPP_OK;
 }
@@ -195,6 +221,13 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   TRY_OR_FREE(hipMalloc((void **)&m->JS, sizeof(float) * NJ * 3 * NB));
   relayout_basis_kernel<<<dim3((unsigned)((m->ldB + 255) / 256)), dim3(256)>>>(dP, dS, dT, m->Bm, V, m->ldB);
   fold_regressor_kernel<<<dim3(NJ * 3 * (NB + 1)), dim3(256)>>>(dJreg, dS, dT, m->J0, m->JS, V);
+  m->VGPn = (V + 63) / 64;
+  TRY_OR_FREE(hipMalloc((void **)&m->B3, (size_t)m->VGPn * BB_KS * BB_B_BYTES));
+  {
+    const int64_t cnt = m->VGPn * BB_KS * 6 * 64;
+    relayout_basis_bf16x3_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256)>>>(m->Bm, m->ldB, V, m->VGPn,
+                                                                                  reinterpret_cast<uint16_t *>(m->B3));
+  }
   TRY_OR_FREE(hipGetLastError());
   TRY_OR_FREE(hipDeviceSynchronize());
   m->Pvm = dP; // kept: vertex-major copies serve the sparse IK Jacobian (contiguous 2.5 KB per vertex)

@@ -1,0 +1,441 @@
+// skin_kernel_b — the fused blend-shape GEMM + linear blend skinning kernel on the bf16 matrix pipe, fp32-exact operands.
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate, and the fp32 forms of this kernel (fk.hip, skin_p.hip) are
+// bound by it.  Here every fp32 operand is carried as THREE bf16 pieces, x = x1 + x2 + x3 exactly (8 + 8 + 8 significant
+// bits), and a product a.b is evaluated as the six bf16 MFMAs a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 accumulated in
+// fp32 — the three dropped cross terms are below 2^-24 |a||b|, the size of one fp32 rounding.  6 MFMAs of 32 cycles do the
+// work of 8 fp32 MFMAs of 64 cycles: 2.6x fewer matrix-pipe cycles at fp32-level accuracy (checked against the fp64
+// oracle in tests/test_fk_gpu.py beside the fp32 forms).
+//
+// Work item: 64 frames x 64 vertices (x 3 coordinates), one 256-thread workgroup (one wavefront per SIMD, 2 x 2
+// wavefronts of 32 frames x 32 vertices each), 14 k-steps of 16.  Operands are stored in HBM in MFMA FRAGMENT ORDER — a
+// "piece" is the 1 KiB a wavefront's 64 lanes feed to one MFMA (lane l = 32 h + r holds k = 8 h .. 8 h + 7 of row/column
+// r) — so staging is a straight 24 KiB copy per k-step (6 pieces of A, 18 of B), 16 B per lane per instruction, into a
+// double-buffered LDS image that each wavefront reads back with lane-linear ds_read_b128 (conflict-free).  The four
+// wavefronts share the staged bytes: HBM/L2 traffic per MFMA is half that of per-wavefront operand streams.
+//
+// Software pipeline (as skin_p.hip): the instruction stream of an item is 252 hand-placed "slots", one per MFMA; the
+// skinning epilogue of the PREVIOUS item (16 accumulator rows x 14 slots), the staging of the operands two k-steps
+// ahead, the fragment reads of the next coordinate and the G' tile of the current item all issue in the MFMA shadows.
+// One raw s_barrier per k-step (slot 12) orders the LDS images; global loads stay in flight across it.
+#include "common.h"
+
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+namespace smplpp_hip
+{
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v3f __attribute__((ext_vector_type(3), aligned(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v3u __attribute__((ext_vector_type(3)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int B_LDS_OP = 2 * BB_KSTEP_BYTES;          // 49152: two operand images
+constexpr int B_LDS_G = 64 * NJ * 12 * 4;              // 73728: G' of 64 frames
+constexpr int B_LDS_ROOT = 64 * 16;                    // root translation of 64 frames, one (x, y, z, -) per frame
+constexpr int B_LDS_TOTAL = B_LDS_OP + B_LDS_G + B_LDS_ROOT;
+constexpr int B_SLOTS = 18;                            // MFMAs per k-step: 3 coordinates x 6 piece products
+constexpr int B_ROW_SLOTS = 14;                        // slots per epilogue row
+constexpr int B_RD_AHEAD = 2;                          // extra slots between a joint's LDS reads and their use
+constexpr int B_ROOT_KS = 11;                           // k-step whose slot 9 loads the root translations
+constexpr int B_ROW0 = 18;                             // first epilogue slot (after the first barrier of the item)
+constexpr int B_GCHUNKS = B_LDS_G / (256 * 16);        // 18 x 16 B per thread
+
+template<class F, int... I>
+__device__ __forceinline__ void bstatic_for_impl(F && f, std::integer_sequence<int, I...>)
+{
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template<int N, class F>
+__device__ __forceinline__ void bstatic_for(F && f)
+{
+  bstatic_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// piece products in issue order (index into the A pieces, index into the B pieces): small terms first
+constexpr int B_PA[6] = {2, 0, 1, 1, 0, 0};
+constexpr int B_PB[6] = {0, 2, 1, 0, 1, 0};
+
+__device__ __forceinline__ void lds_barrier()
+{
+  // LDS traffic of this wavefront done, then the workgroup barrier; vmcnt is deliberately NOT waited for (operand and G'
+  // prefetches stay in flight across it)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template<int MAXW, bool WANT_REST>
+__global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restrict__ A3, const uint8_t * __restrict__ B3,
+                                                        const float * __restrict__ Gp, const float * __restrict__ theta,
+                                                        const uint8_t * __restrict__ wIdx, const float * __restrict__ wVal,
+                                                        const float * __restrict__ wSum, float * __restrict__ verts,
+                                                        float * __restrict__ rest, int64_t n, int64_t V, int nvgp, int nftp,
+                                                        int items_per_block)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wf = wave & 1, wv = wave >> 1;
+  const int total = nvgp * nftp;
+  // XCD-aware run assignment (see skin_p.hip): XCD x gets the x-th contiguous eighth of the vertex-major item list
+  const int nb = gridDim.x, per_x = (nb + 7) >> 3;
+  const int vb = (int)(blockIdx.x & 7) * per_x + (int)(blockIdx.x >> 3);
+  const int t_begin = vb * items_per_block;
+  int t_end = t_begin + items_per_block;
+  if(t_end > total) t_end = total;
+  if(t_begin >= t_end) return; // whole workgroup leaves: no barrier is ever skipped by a subset of its wavefronts
+
+  // ---- descriptors (SGPR) and per-thread constant offsets (VGPR)
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(A3), 0, (int)(nftp * BB_KS * BB_A_BYTES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(B3), 0, (int)(nvgp * BB_KS * BB_B_BYTES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Gp), 0, (int)(nftp * B_LDS_G), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(verts, 0, (int)(verts ? n * V * 12 : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(rest, 0, (int)(rest ? n * V * 12 : 0), 0x00020000);
+  // staging: chunk q = i * 256 + tid (16 B each) of the 24 KiB k-step image; chunks [0, 384) are A, the rest B.
+  // i = 0: A for everyone; i = 1: A for wavefronts 0-1, B for 2-3 (wave-uniform choice); i >= 2: B.
+  const bool mixA = wave < 2;
+  const __amdgpu_buffer_rsrc_t rsM = mixA ? rsA : rsB;
+  const int voff0 = tid * 16;
+  const int voffM = mixA ? (256 + tid) * 16 : (tid - 128) * 16;
+  const int voffB = (tid + 128) * 16; // i >= 2: + (i - 2) * 4096
+  const int frameB = (int)(V * 12);
+  const __amdgpu_buffer_rsrc_t rsT =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(theta), 0, (int)(n * (NJ + 1) * 12), 0x00020000);
+  const int voffT = ((tid < 192 ? tid : 191) / 3) * ((NJ + 1) * 12) + ((tid < 192 ? tid : 191) % 3) * 4;
+
+  unsigned char * const opLane = lds + tid * 16;                                       // staging writes: + buf * 24576 + i * 4096
+  const unsigned char * const aLane = lds + (wf * 3 * 64 + lane) * 16;                  // A piece s: + s * 1024
+  const unsigned char * const bLane = lds + BB_A_BYTES + (wv * 9 * 64 + lane) * 16;     // B piece (x, s): + (3 x + s) * 1024
+  unsigned char * const gWr = lds + B_LDS_OP + tid * 16;                                // G' staging writes: + i * 4096
+  const unsigned char * const gLane = lds + B_LDS_OP + (wf * 32 + 4 * half) * (NJ * 48); // G' of frame row R: + rowc(R) * 1152
+  float * const sRoot = reinterpret_cast<float *>(lds + B_LDS_OP + B_LDS_G);
+  const v4f * const rootLane = reinterpret_cast<const v4f *>(sRoot) + (wf * 32 + 4 * half); // + rowc(R)
+  float * const rootWr = sRoot + ((tid < 192 ? tid : 191) / 3) * 4 + (tid < 192 ? tid % 3 : 3); // threads >= 192 hit the pad word
+
+  f32x16 acc[3], accp[3];
+  v4f afr[2][3], bfr[2][3]; // operand fragments (A: by k-step parity; B: by coordinate-sequence parity)
+  v4u stg[2][6];            // operand staging registers, two k-steps deep
+  v4u gstage[B_GCHUNKS];    // G' tile of the current item on its way to LDS
+  float rstage = 0.0f;
+
+  struct Item
+  {
+    int voff;    // byte offset of (frame 4 * half, vertex v) in an output array; out of range when the lane has no vertex
+    float winv;
+    int jofs[MAXW]; // byte offset of joint i's matrix inside a frame's G'
+    float jw[MAXW];
+  } cur, prev;
+
+  auto item_bases = [&](int t, int & Ab, int & Bb, int & Gb) {
+    const int tu = __builtin_amdgcn_readfirstlane(t);
+    const int vgp = tu / nftp, ftp = tu % nftp;
+    Ab = ftp * (BB_KS * BB_A_BYTES);
+    Bb = vgp * (BB_KS * BB_B_BYTES);
+    Gb = ftp * B_LDS_G;
+  };
+  auto load_stage = [&](v4u (&s)[6], int Ak, int Bk) { // the 6 chunks of one k-step image (Ak / Bk: byte bases of that k-step)
+    s[0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff0, Ak, 0);
+    s[1] = __builtin_amdgcn_raw_buffer_load_b128(rsM, voffM, mixA ? Ak : Bk, 0);
+#pragma unroll
+    for(int i = 2; i < 6; i++) s[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB + (i - 2) * 4096, Bk, 0);
+  };
+
+  int f0_prev = 0;
+  // ---- prologue: k-step 0 of the first item into LDS image 0, k-steps 1 and 2 into the staging registers
+  {
+    int Abase, Bbase, Gbase;
+    item_bases(t_begin, Abase, Bbase, Gbase);
+    (void)Gbase;
+    v4u s0[6];
+    load_stage(s0, Abase, Bbase);
+    load_stage(stg[1], Abase + BB_A_BYTES, Bbase + BB_B_BYTES);
+    load_stage(stg[0], Abase + 2 * BB_A_BYTES, Bbase + 2 * BB_B_BYTES);
+#pragma unroll
+    for(int i = 0; i < 6; i++) *reinterpret_cast<v4u *>(opLane + i * 4096) = s0[i];
+    lds_barrier();
+#pragma unroll
+    for(int s = 0; s < 3; s++)
+    {
+      afr[0][s] = *reinterpret_cast<const v4f *>(aLane + s * 1024);
+      bfr[0][s] = *reinterpret_cast<const v4f *>(bLane + s * 1024);
+    }
+  }
+
+  // one work item; HP (compile time) = there is a previous item whose epilogue rides in this item's MFMA shadows
+  auto do_item = [&](int t, auto hp_tag) {
+    constexpr bool HP = decltype(hp_tag)::value;
+    const int tu = __builtin_amdgcn_readfirstlane(t);
+    const int vgp = tu / nftp, ftp = tu % nftp;
+    const int64_t v = (int64_t)vgp * 64 + wv * 32 + l31;
+    const bool has_v = v < V;
+    const int f0_cur = ftp * 64 + wf * 32; // first frame of this wavefront's 32 (wave-uniform: stays in an SGPR)
+    const int sb_prev = __builtin_amdgcn_readfirstlane(f0_prev * frameB);
+    int Abase, Bbase, Gbase; // byte bases of this item's operands (recomputed, not loop-carried: keeps them scalar)
+    item_bases(t, Abase, Bbase, Gbase);
+    cur.voff = has_v ? (int)(v * 12 + (int64_t)(4 * half) * frameB) : 0x7fffff00;
+    {
+      const int64_t vv = has_v ? v : 0;
+#pragma unroll
+      for(int i = 0; i < MAXW; i++)
+      {
+        cur.jofs[i] = (int)wIdx[vv * MAXW + i] * 48;
+        cur.jw[i] = wVal[vv * MAXW + i];
+      }
+      cur.winv = 1.0f / wSum[vv];
+    }
+    const int tn = (t + 1 < t_end) ? t + 1 : t; // next item (or this one again: harmless extra prefetch)
+    int Abn, Bbn, Gbn;
+    item_bases(tn, Abn, Bbn, Gbn);
+    (void)Gbn;
+#pragma unroll
+    for(int x = 0; x < 3; x++)
+#pragma unroll
+      for(int r = 0; r < 16; r++) acc[x][r] = 0.0f;
+
+    float rx = 0.f, ry = 0.f, rz = 0.f, rt0 = 0.f, rt1 = 0.f, rt2 = 0.f, hx = 0.f, hy = 0.f;
+    v4f m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0, m2 = m0;
+    constexpr int NSET = MAXW == 4 ? 2 : 4; // register sets for the joint matrices in flight
+    v4f gq[NSET][3];
+
+    bstatic_for<BB_KS * B_SLOTS>([&](auto ss) {
+      constexpr int S = decltype(ss)::value;
+      constexpr int KS = S / B_SLOTS, M = S % B_SLOTS, X = M / 6, Q = M % 6;
+      constexpr int AP = KS & 1, BPAR = (KS * 3 + X) & 1;
+      acc[X] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[AP][B_PA[Q]]),
+                                                       __builtin_bit_cast(bf16x8, bfr[BPAR][B_PB[Q]]), acc[X], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+
+      // ---- operand fragments of the next coordinate / next k-step (LDS image KS & 1, then the other one)
+      if constexpr(M < 3) bfr[(KS * 3 + 1) & 1][M] = *reinterpret_cast<const v4f *>(bLane + AP * BB_KSTEP_BYTES + (3 + M) * 1024);
+      if constexpr(M >= 6 && M < 9)
+        bfr[(KS * 3 + 2) & 1][M - 6] = *reinterpret_cast<const v4f *>(bLane + AP * BB_KSTEP_BYTES + (6 + M - 6) * 1024);
+      if constexpr(M == 12) lds_barrier(); // image (KS + 1) & 1 is complete; everyone is done reading image KS & 1
+      if constexpr(M >= 12 && M < 15)
+      {
+        constexpr int NB_ = (KS + 1) & 1;
+        afr[NB_][M - 12] = *reinterpret_cast<const v4f *>(aLane + NB_ * BB_KSTEP_BYTES + (M - 12) * 1024);
+        bfr[((KS + 1) * 3) & 1][M - 12] = *reinterpret_cast<const v4f *>(bLane + NB_ * BB_KSTEP_BYTES + (M - 12) * 1024);
+      }
+
+      // ---- staging: write k-step KS + 1 (loaded two k-steps ago) into the other image, re-issue the registers for KS + 3
+      if constexpr(M < 6)
+      {
+        constexpr int SET = (KS + 1) & 1;
+        *reinterpret_cast<v4u *>(opLane + SET * BB_KSTEP_BYTES + M * 4096) = stg[SET][M];
+        constexpr int KN = KS + 3;
+        const int Ak = (KN < BB_KS ? Abase + KN * BB_A_BYTES : Abn + (KN - BB_KS) * BB_A_BYTES);
+        const int Bk = (KN < BB_KS ? Bbase + KN * BB_B_BYTES : Bbn + (KN - BB_KS) * BB_B_BYTES);
+        if constexpr(M == 0) stg[SET][0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff0, Ak, 0);
+        if constexpr(M == 1) stg[SET][1] = __builtin_amdgcn_raw_buffer_load_b128(rsM, voffM, mixA ? Ak : Bk, 0);
+        if constexpr(M >= 2) stg[SET][M] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB + (M - 2) * 4096, Bk, 0);
+      }
+
+      // ---- G' tile and root translations of the CURRENT item: HBM -> registers (k-steps 2..10), written to LDS by the next item
+      if constexpr(KS >= 2 && KS <= 10 && (M == 9 || M == 16))
+      {
+        constexpr int GI = (KS - 2) * 2 + (M == 16 ? 1 : 0);
+        gstage[GI] = __builtin_amdgcn_raw_buffer_load_b128(rsG, voff0 + GI * 4096, Gbase, 0);
+      }
+      if constexpr(KS == B_ROOT_KS && M == 9)
+      {
+        // root translation theta[f, 0, :] (src/SMPL.cpp:726-727) of the block's 64 frames: 192 values, one per thread.
+        // Buffer load: 32-bit offsets only (no 64-bit VALU address math in the MFMA stream); frames >= n read as 0.
+        rstage = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, voffT, ftp * (64 * (NJ + 1) * 12), 0));
+      }
+
+      if constexpr(HP)
+      {
+        // ---- G' / roots of the PREVIOUS item: registers -> LDS (its readers start after this k-step's barrier)
+        if constexpr(KS == 0 && M < 12)
+        {
+          constexpr int W0 = (M / 2) * 3 + (M & 1) * 2, WN = (M & 1) ? 1 : 2;
+#pragma unroll
+          for(int i = W0; i < W0 + WN; i++) *reinterpret_cast<v4u *>(gWr + i * 4096) = gstage[i];
+          if constexpr(M == 11) *rootWr = rstage;
+        }
+        // ---- LDS reads of joint j of row R': issued B_RD_AHEAD slots before the slot that would precede the joint's first
+        // FMA group (a slot is 32 MFMA cycles; three ds_read_b128 need ~100 to land)
+        if constexpr(S + B_RD_AHEAD >= B_ROW0 && S + B_RD_AHEAD < B_ROW0 + 16 * B_ROW_SLOTS)
+        {
+          constexpr int R2 = (S + B_RD_AHEAD - B_ROW0) / B_ROW_SLOTS, P2 = (S + B_RD_AHEAD - B_ROW0) % B_ROW_SLOTS;
+          constexpr int ROWC2 = (R2 & 3) + 8 * (R2 >> 2);
+#pragma unroll
+          for(int j = 0; j < MAXW; j++)
+            if(P2 == (3 * j) / (MAXW / 4))
+            {
+              const unsigned char * gj = gLane + ROWC2 * (NJ * 48) + prev.jofs[j];
+              gq[j % NSET][0] = *reinterpret_cast<const v4f *>(gj);
+              gq[j % NSET][1] = *reinterpret_cast<const v4f *>(gj + 16);
+              gq[j % NSET][2] = *reinterpret_cast<const v4f *>(gj + 32);
+            }
+        }
+        // ---- one piece of row R of the previous item
+        if constexpr(S >= B_ROW0 && S < B_ROW0 + 16 * B_ROW_SLOTS)
+        {
+          constexpr int R = (S - B_ROW0) / B_ROW_SLOTS, P = (S - B_ROW0) % B_ROW_SLOTS;
+          constexpr int ROWC = (R & 3) + 8 * (R >> 2); // + 4 * half: accumulator row -> frame in the wavefront's 32
+          constexpr int GPS = MAXW / 4;               // FMA groups (4 FMAs: one joint, one matrix row) per slot
+          if constexpr(P == 0)
+          {
+            rx = accp[0][R];
+            ry = accp[1][R];
+            rz = accp[2][R];
+            if constexpr(WANT_REST)
+            {
+              v3f ov = {rx, ry, rz};
+              __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsR, prev.voff,
+                                                    sb_prev + ROWC * frameB, 2);
+            }
+          }
+          if constexpr(P >= 1 && P <= 12)
+          {
+            // scalar FMAs on purpose: packed f32 VALU beside MFMAs is an anti-lever (MI355X_MICROARCH.md, cycle constants)
+#pragma unroll
+            for(int g = (P - 1) * GPS; g < P * GPS; g++)
+            {
+              const int j = g / 3, row = g % 3;
+              const float w = prev.jw[j];
+              const v4f gm = gq[j % NSET][row];
+              v4f & mm = (row == 0 ? m0 : (row == 1 ? m1 : m2));
+              if(j == 0)
+              {
+                mm.x = w * gm.x;
+                mm.y = w * gm.y;
+                mm.z = w * gm.z;
+                mm.w = w * gm.w;
+              }
+              else
+              {
+                mm.x = __builtin_fmaf(w, gm.x, mm.x);
+                mm.y = __builtin_fmaf(w, gm.y, mm.y);
+                mm.z = __builtin_fmaf(w, gm.z, mm.z);
+                mm.w = __builtin_fmaf(w, gm.w, mm.w);
+              }
+            }
+          }
+          if constexpr(P == 11)
+          {
+            const v4f rt = rootLane[ROWC];
+            rt0 = rt.x;
+            rt1 = rt.y;
+            rt2 = rt.z;
+          }
+          if constexpr(P == 12 && MAXW == 4)
+          {
+            hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
+            hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
+          }
+          if constexpr(P == 13)
+          {
+            if constexpr(MAXW != 4)
+            {
+              hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
+              hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
+            }
+            const float hz = ((m2.x * rx + m2.y * ry) + m2.z * rz) + m2.w;
+            // write-once output: non-temporal (aux = 2); the descriptor's range check drops frames >= n and vertex-less lanes
+            v3f ov = {hx * prev.winv + rt0, hy * prev.winv + rt1, hz * prev.winv + rt2};
+            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsV, prev.voff,
+                                                  sb_prev + ROWC * frameB, 2);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+
+    // the current item becomes the previous one
+#pragma unroll
+    for(int x = 0; x < 3; x++) accp[x] = acc[x];
+    prev = cur;
+    f0_prev = f0_cur;
+  };
+
+  do_item(t_begin, std::false_type{});
+  for(int t = t_begin + 1; t < t_end; t++) do_item(t, std::true_type{});
+
+  // ---- drain: G' of the last item into LDS, then its epilogue with nothing to hide behind
+  lds_barrier(); // everyone is done with the previous G' image (and with the operand images)
+#pragma unroll
+  for(int i = 0; i < B_GCHUNKS; i++) *reinterpret_cast<v4u *>(gWr + i * 4096) = gstage[i];
+  *rootWr = rstage;
+  lds_barrier();
+  bstatic_for<16>([&](auto rr) {
+    constexpr int R = decltype(rr)::value;
+    constexpr int ROWC = (R & 3) + 8 * (R >> 2);
+    const float rx = accp[0][R], ry = accp[1][R], rz = accp[2][R];
+    const int soff = __builtin_amdgcn_readfirstlane((f0_prev + ROWC) * frameB);
+    if constexpr(WANT_REST)
+    {
+      v3f ov = {rx, ry, rz};
+      __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsR, prev.voff, soff, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 1");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    v4f m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0, m2 = m0;
+#pragma unroll
+    for(int i = 0; i < MAXW; i++)
+    {
+      const unsigned char * gj = gLane + ROWC * (NJ * 48) + prev.jofs[i];
+      const v4f g0 = *reinterpret_cast<const v4f *>(gj), g1 = *reinterpret_cast<const v4f *>(gj + 16),
+                g2 = *reinterpret_cast<const v4f *>(gj + 32);
+      const float w = prev.jw[i];
+      m0 = w * g0 + m0; // (drain only: packed math is fine here)
+      m1 = w * g1 + m1;
+      m2 = w * g2 + m2;
+    }
+    const float hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
+    const float hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
+    const float hz = ((m2.x * rx + m2.y * ry) + m2.z * rz) + m2.w;
+    const v4f rt = rootLane[ROWC];
+    v3f ov = {hx * prev.winv + rt.x, hy * prev.winv + rt.y, hz * prev.winv + rt.z};
+    __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsV, prev.voff, soff, 2);
+    // HAZARD (measured on gfx950, not covered by hipcc's hazard recogniser when soffset is an SGPR): a VALU write to the
+    // data registers of a 96-bit buffer store in the very next instruction lands before the store has read dword 1 of
+    // lanes 12-15 of each 16.  In the slot stream above an MFMA always follows a store; here keep one instruction of distance.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+template<int MAXW, bool WANT_REST>
+static hipError_t launch_b(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st)
+{
+  const int nftp = (int)((n + 63) / 64);
+  const int nvgp = (int)m->VGPn;
+  const int total = nvgp * nftp;
+  static int cus = 0;
+  if(!cus)
+  {
+    hipDeviceProp_t prop;
+    cus = (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  int blocks = total < cus ? total : cus;
+  blocks = (blocks + 7) & ~7; // the XCD-aware run assignment wants a multiple of 8 (idle runs exit at once)
+  const int ipb = (total + blocks - 1) / blocks;
+  static bool attr_set = false;
+  if(!attr_set)
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&skin_kernel_b<MAXW, WANT_REST>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL);
+    if(e != hipSuccess) return e;
+    attr_set = true;
+  }
+  skin_kernel_b<MAXW, WANT_REST><<<dim3(blocks), dim3(256), B_LDS_TOTAL, st>>>(m->ws.A3.as<uint8_t>(), m->B3, m->ws.Gp.as<float>(), theta, m->wIdx,
+                                                                             m->wVal, m->wSum, verts, rest, n, m->V, nvgp, nftp, ipb);
+  return hipGetLastError();
+}
+
+// Gp must hold whole 64-frame tiles (padding content is irrelevant: the rows it feeds are never stored)
+hipError_t launch_skin_bf16x3(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st)
+{
+  if(m->maxw == 4) return rest ? launch_b<4, true>(m, n, theta, verts, rest, st) : launch_b<4, false>(m, n, theta, verts, rest, st);
+  if(m->maxw == 8) return rest ? launch_b<8, true>(m, n, theta, verts, rest, st) : launch_b<8, false>(m, n, theta, verts, rest, st);
+  return hipErrorInvalidValue; // dense weights keep the first form
+}
+} // namespace smplpp_hip
