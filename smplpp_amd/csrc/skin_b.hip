@@ -39,10 +39,18 @@ constexpr int B_LDS_ROOT = 64 * 16;                    // root translation of 64
 constexpr int B_LDS_TOTAL = B_LDS_OP + B_LDS_G + B_LDS_ROOT;
 constexpr int B_SLOTS = 18;                            // MFMAs per k-step: 3 coordinates x 6 piece products
 constexpr int B_ROW_SLOTS = 14;                        // slots per epilogue row
-constexpr int B_RD_AHEAD = 2;                          // extra slots between a joint's LDS reads and their use
+#ifndef SKINB_ABL
+#define SKINB_ABL 0 // timing ablations (development only; results are wrong when non-zero): 1 no epilogue, 2 no staging, 4 no MFMA, 8 no barrier, 16 no fragment reads, 32 staging loads without their LDS writes
+#endif
+constexpr int B_RD_AHEAD = 6;                          // extra slots between a joint's LDS reads and their use (<= 9: the first
+                                                       // read of an item must stay behind the barrier of slot 6)
 constexpr int B_ROOT_KS = 11;                           // k-step whose slot 9 loads the root translations
-constexpr int B_ROW0 = 18;                             // first epilogue slot (after the first barrier of the item)
+constexpr int B_BAR = 6;                               // slot of a k-step that carries its barrier
+constexpr int B_ROW0 = 16;                             // first epilogue slot; the 16 rows end at slot 239, before the
+                                                       // item's last barrier (slot 240), after which G' may be overwritten
 constexpr int B_GCHUNKS = B_LDS_G / (256 * 16);        // 18 x 16 B per thread
+constexpr int B_GW_TAIL = 11;                          // G' chunks written in the item's own last k-step (slots 7..17), the
+                                                       // other 7 in slots 0..5 of the next item
 
 template<class F, int... I>
 __device__ __forceinline__ void bstatic_for_impl(F && f, std::integer_sequence<int, I...>)
@@ -58,6 +66,28 @@ __device__ __forceinline__ void bstatic_for(F && f)
 // piece products in issue order (index into the A pieces, index into the B pieces): small terms first
 constexpr int B_PA[6] = {2, 0, 1, 1, 0, 0};
 constexpr int B_PB[6] = {0, 2, 1, 0, 1, 0};
+
+// LDS instructions the epilogue of the previous item issues in slot S (joint matrices: 3 ds_read_b128 per joint; root: 1)
+constexpr int B_ROOT_P = 9; // row slot that reads the root translation (used in slot 13)
+constexpr int epilogue_lds_ops(int S, int maxw)
+{
+  int c = 0;
+  const int s2 = S + B_RD_AHEAD - B_ROW0;
+  if(s2 >= 0 && s2 < 16 * B_ROW_SLOTS)
+    for(int j = 0; j < maxw; j++)
+      if(s2 % B_ROW_SLOTS == (3 * j) / (maxw / 4)) c += 3;
+  const int s1 = S - B_ROW0;
+  if(s1 >= 0 && s1 < 16 * B_ROW_SLOTS && s1 % B_ROW_SLOTS == B_ROOT_P) c += 1;
+  return c;
+}
+
+// Barrier of k-step KS (slot 12): the LDS instructions of slots <= 8 must have completed (this wavefront's staging writes
+// and its last reads of the current operand image); the N epilogue reads issued in slots 9..11 may stay in flight.
+template<int N>
+__device__ __forceinline__ void lds_barrier_counted()
+{
+  asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
 
 __device__ __forceinline__ void lds_barrier()
 {
@@ -77,14 +107,18 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wf = wave & 1, wv = wave >> 1;
-  const int total = nvgp * nftp;
-  // XCD-aware run assignment (see skin_p.hip): XCD x gets the x-th contiguous eighth of the vertex-major item list
-  const int nb = gridDim.x, per_x = (nb + 7) >> 3;
-  const int vb = (int)(blockIdx.x & 7) * per_x + (int)(blockIdx.x >> 3);
-  const int t_begin = vb * items_per_block;
-  int t_end = t_begin + items_per_block;
-  if(t_end > total) t_end = total;
-  if(t_begin >= t_end) return; // whole workgroup leaves: no barrier is ever skipped by a subset of its wavefronts
+  // Work assignment, XCD- and L2-aware.  Workgroup b runs on XCD b & 7 (round-robin dispatch).  XCD x owns a contiguous
+  // range of vertex-group pairs, i.e. a private 1/8 of B3 (each B3 byte is fetched from HBM by one XCD only), and its
+  // workgroups take the range's items (vertex-group pair major, frame-tile pair minor) INTERLEAVED: workgroup j does
+  // items j, j + nbx, j + 2 nbx, ...  So at any moment the ~32 workgroups of an XCD stream the same one or two 258 KB
+  // slices of B3 (L2 hits for all but the first) against different frame tiles; a contiguous run per workgroup instead
+  // puts 32 different slices (8 MB) through a 4 MB L2 and every staging load misses it (measured: 453 MB of L2 misses per
+  // launch for 27 MB of B3).  A wrong placement guess costs speed, never correctness: the item lists tile the work either way.
+  const int nbx = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), jb = (int)(blockIdx.x >> 3);
+  const int vg0 = (xcd * nvgp) >> 3, vg1 = ((xcd + 1) * nvgp) >> 3;
+  const int cnt = (vg1 - vg0) * nftp; // items of this XCD
+  (void)items_per_block;
+  if(jb >= cnt) return; // whole workgroup leaves: no barrier is ever skipped by a subset of its wavefronts
 
   // ---- descriptors (SGPR) and per-thread constant offsets (VGPR)
   const __amdgpu_buffer_rsrc_t rsA =
@@ -117,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
   float * const rootWr = sRoot + ((tid < 192 ? tid : 191) / 3) * 4 + (tid < 192 ? tid % 3 : 3); // threads >= 192 hit the pad word
 
   f32x16 acc[3], accp[3];
-  v4f afr[2][3], bfr[2][3]; // operand fragments (A: by k-step parity; B: by coordinate-sequence parity)
+  v4f afr[2][3], bfr[3][3]; // operand fragments (A: by k-step parity; B: by coordinate)
   v4u stg[2][6];            // operand staging registers, two k-steps deep
   v4u gstage[B_GCHUNKS];    // G' tile of the current item on its way to LDS
   float rstage = 0.0f;
@@ -130,9 +164,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
     float jw[MAXW];
   } cur, prev;
 
-  auto item_bases = [&](int t, int & Ab, int & Bb, int & Gb) {
-    const int tu = __builtin_amdgcn_readfirstlane(t);
-    const int vgp = tu / nftp, ftp = tu % nftp;
+  auto item_bases = [&](int i, int & Ab, int & Bb, int & Gb) { // i: index into this XCD's item list
+    const int iu = __builtin_amdgcn_readfirstlane(i);
+    const int vgp = vg0 + iu / nftp, ftp = iu % nftp;
     Ab = ftp * (BB_KS * BB_A_BYTES);
     Bb = vgp * (BB_KS * BB_B_BYTES);
     Gb = ftp * B_LDS_G;
@@ -148,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
   // ---- prologue: k-step 0 of the first item into LDS image 0, k-steps 1 and 2 into the staging registers
   {
     int Abase, Bbase, Gbase;
-    item_bases(t_begin, Abase, Bbase, Gbase);
+    item_bases(jb, Abase, Bbase, Gbase);
     (void)Gbase;
     v4u s0[6];
     load_stage(s0, Abase, Bbase);
@@ -169,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
   auto do_item = [&](int t, auto hp_tag) {
     constexpr bool HP = decltype(hp_tag)::value;
     const int tu = __builtin_amdgcn_readfirstlane(t);
-    const int vgp = tu / nftp, ftp = tu % nftp;
+    const int vgp = vg0 + tu / nftp, ftp = tu % nftp;
     const int64_t v = (int64_t)vgp * 64 + wv * 32 + l31;
     const bool has_v = v < V;
     const int f0_cur = ftp * 64 + wf * 32; // first frame of this wavefront's 32 (wave-uniform: stays in an SGPR)
@@ -187,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
       }
       cur.winv = 1.0f / wSum[vv];
     }
-    const int tn = (t + 1 < t_end) ? t + 1 : t; // next item (or this one again: harmless extra prefetch)
+    const int tn = (t + nbx < cnt) ? t + nbx : t; // next item (or this one again: harmless extra prefetch)
     int Abn, Bbn, Gbn;
     item_bases(tn, Abn, Bbn, Gbn);
     (void)Gbn;
@@ -198,34 +232,47 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
 
     float rx = 0.f, ry = 0.f, rz = 0.f, rt0 = 0.f, rt1 = 0.f, rt2 = 0.f, hx = 0.f, hy = 0.f;
     v4f m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0, m2 = m0;
-    constexpr int NSET = MAXW == 4 ? 2 : 4; // register sets for the joint matrices in flight
+    constexpr int NSET = 4; // register sets for the joint matrices in flight (a set is re-read 14 slots later)
     v4f gq[NSET][3];
 
     bstatic_for<BB_KS * B_SLOTS>([&](auto ss) {
       constexpr int S = decltype(ss)::value;
       constexpr int KS = S / B_SLOTS, M = S % B_SLOTS, X = M / 6, Q = M % 6;
-      constexpr int AP = KS & 1, BPAR = (KS * 3 + X) & 1;
-      acc[X] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[AP][B_PA[Q]]),
-                                                       __builtin_bit_cast(bf16x8, bfr[BPAR][B_PB[Q]]), acc[X], 0, 0, 0);
+      constexpr int AP = KS & 1;
+      if constexpr(!(SKINB_ABL & 4))
+        acc[X] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[AP][B_PA[Q]]),
+                                                         __builtin_bit_cast(bf16x8, bfr[X][B_PB[Q]]), acc[X], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 
-      // ---- operand fragments of the next coordinate / next k-step (LDS image KS & 1, then the other one)
-      if constexpr(M < 3) bfr[(KS * 3 + 1) & 1][M] = *reinterpret_cast<const v4f *>(bLane + AP * BB_KSTEP_BYTES + (3 + M) * 1024);
-      if constexpr(M >= 6 && M < 9)
-        bfr[(KS * 3 + 2) & 1][M - 6] = *reinterpret_cast<const v4f *>(bLane + AP * BB_KSTEP_BYTES + (6 + M - 6) * 1024);
-      if constexpr(M == 12) lds_barrier(); // image (KS + 1) & 1 is complete; everyone is done reading image KS & 1
-      if constexpr(M >= 12 && M < 15)
+      if constexpr(M == B_BAR && !(SKINB_ABL & 8))
+      {
+        // Barrier of the k-step: every wavefront has written its share of image (KS + 1) & 1 (slots 0..5) and has issued
+        // its last reads of image KS & 1.  Only the epilogue reads of slot 5 (issued behind its sched_barrier line) may
+        // stay in flight; k-step 0 also publishes the G' tile, and the last k-step retires every read of it.
+        constexpr int NOPS = (HP && !(SKINB_ABL & 1)) ? epilogue_lds_ops(S - 1, MAXW) : 0;
+        if constexpr(KS == BB_KS - 1 || NOPS == 0)
+          lds_barrier();
+        else
+          lds_barrier_counted<NOPS>();
+      }
+      // ---- operand fragments: coordinates 1 and 2 of this k-step early (image KS & 1), then — behind the barrier of
+      // slot 6 — the A pieces and coordinate 0 of the NEXT k-step, a dozen slots before their first MFMA
+      if constexpr(M < 3 && !(SKINB_ABL & 16)) bfr[1][M] = *reinterpret_cast<const v4f *>(bLane + AP * BB_KSTEP_BYTES + (3 + M) * 1024);
+      if constexpr(M >= 3 && M < 6 && !(SKINB_ABL & 16)) bfr[2][M - 3] = *reinterpret_cast<const v4f *>(bLane + AP * BB_KSTEP_BYTES + (6 + M - 3) * 1024);
+      if constexpr(M >= B_BAR && M < B_BAR + 3 && !(SKINB_ABL & 16))
       {
         constexpr int NB_ = (KS + 1) & 1;
-        afr[NB_][M - 12] = *reinterpret_cast<const v4f *>(aLane + NB_ * BB_KSTEP_BYTES + (M - 12) * 1024);
-        bfr[((KS + 1) * 3) & 1][M - 12] = *reinterpret_cast<const v4f *>(bLane + NB_ * BB_KSTEP_BYTES + (M - 12) * 1024);
+        afr[NB_][M - B_BAR] = *reinterpret_cast<const v4f *>(aLane + NB_ * BB_KSTEP_BYTES + (M - B_BAR) * 1024);
+        bfr[0][M - B_BAR] = *reinterpret_cast<const v4f *>(bLane + NB_ * BB_KSTEP_BYTES + (M - B_BAR) * 1024);
       }
-
       // ---- staging: write k-step KS + 1 (loaded two k-steps ago) into the other image, re-issue the registers for KS + 3
-      if constexpr(M < 6)
+      if constexpr(M < 6 && !(SKINB_ABL & 2))
       {
         constexpr int SET = (KS + 1) & 1;
-        *reinterpret_cast<v4u *>(opLane + SET * BB_KSTEP_BYTES + M * 4096) = stg[SET][M];
+        if constexpr(SKINB_ABL & 32)
+          asm volatile("" ::"v"(stg[SET][M])); // ablation: keep the load, drop the LDS write
+        else
+          *reinterpret_cast<v4u *>(opLane + SET * BB_KSTEP_BYTES + M * 4096) = stg[SET][M];
         constexpr int KN = KS + 3;
         const int Ak = (KN < BB_KS ? Abase + KN * BB_A_BYTES : Abn + (KN - BB_KS) * BB_A_BYTES);
         const int Bk = (KN < BB_KS ? Bbase + KN * BB_B_BYTES : Bbn + (KN - BB_KS) * BB_B_BYTES);
@@ -233,6 +280,19 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
         if constexpr(M == 1) stg[SET][1] = __builtin_amdgcn_raw_buffer_load_b128(rsM, voffM, mixA ? Ak : Bk, 0);
         if constexpr(M >= 2) stg[SET][M] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB + (M - 2) * 4096, Bk, 0);
       }
+
+      // ---- G' tile + root translations, registers -> LDS: chunks 0..10 of the CURRENT item's tile in its own last k-step
+      // (slots 7..17: every row of the previous item has been read by then, and the barrier of slot 6 says so for all four
+      // wavefronts); the other 7 chunks and the roots in slots 0..5 of the next item, published by its first barrier.
+      if constexpr(KS == BB_KS - 1 && M > B_BAR && !(SKINB_ABL & 1)) *reinterpret_cast<v4u *>(gWr + (M - B_BAR - 1) * 4096) = gstage[M - B_BAR - 1];
+      if constexpr(HP && KS == 0 && M < B_BAR && !(SKINB_ABL & 1))
+      {
+        constexpr int W0 = B_GW_TAIL + M + (M > 0 ? 1 : 0), WN = M == 0 ? 2 : 1; // 11,12 | 13 | 14 | 15 | 16 | 17
+#pragma unroll
+        for(int i = W0; i < W0 + WN; i++) *reinterpret_cast<v4u *>(gWr + i * 4096) = gstage[i];
+        if constexpr(M == B_BAR - 1) *rootWr = rstage;
+      }
+      __builtin_amdgcn_sched_barrier(0); // (the LDS instructions above are the ones the k-step barrier has to wait for)
 
       // ---- G' tile and root translations of the CURRENT item: HBM -> registers (k-steps 2..10), written to LDS by the next item
       if constexpr(KS >= 2 && KS <= 10 && (M == 9 || M == 16))
@@ -247,16 +307,8 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
         rstage = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, voffT, ftp * (64 * (NJ + 1) * 12), 0));
       }
 
-      if constexpr(HP)
+      if constexpr(HP && !(SKINB_ABL & 1))
       {
-        // ---- G' / roots of the PREVIOUS item: registers -> LDS (its readers start after this k-step's barrier)
-        if constexpr(KS == 0 && M < 12)
-        {
-          constexpr int W0 = (M / 2) * 3 + (M & 1) * 2, WN = (M & 1) ? 1 : 2;
-#pragma unroll
-          for(int i = W0; i < W0 + WN; i++) *reinterpret_cast<v4u *>(gWr + i * 4096) = gstage[i];
-          if constexpr(M == 11) *rootWr = rstage;
-        }
         // ---- LDS reads of joint j of row R': issued B_RD_AHEAD slots before the slot that would precede the joint's first
         // FMA group (a slot is 32 MFMA cycles; three ds_read_b128 need ~100 to land)
         if constexpr(S + B_RD_AHEAD >= B_ROW0 && S + B_RD_AHEAD < B_ROW0 + 16 * B_ROW_SLOTS)
@@ -317,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
               }
             }
           }
-          if constexpr(P == 11)
+          if constexpr(P == B_ROOT_P)
           {
             const v4f rt = rootLane[ROWC];
             rt0 = rt.x;
@@ -354,8 +406,8 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
     f0_prev = f0_cur;
   };
 
-  do_item(t_begin, std::false_type{});
-  for(int t = t_begin + 1; t < t_end; t++) do_item(t, std::true_type{});
+  do_item(jb, std::false_type{});
+  for(int t = jb + nbx; t < cnt; t += nbx) do_item(t, std::true_type{});
 
   // ---- drain: G' of the last item into LDS, then its epilogue with nothing to hide behind
   lds_barrier(); // everyone is done with the previous G' image (and with the operand images)
@@ -415,9 +467,14 @@ static hipError_t launch_b(const smplpp_model * m, int64_t n, const float * thet
     hipDeviceProp_t prop;
     cus = (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
-  int blocks = total < cus ? total : cus;
-  blocks = (blocks + 7) & ~7; // the XCD-aware run assignment wants a multiple of 8 (idle runs exit at once)
-  const int ipb = (total + blocks - 1) / blocks;
+  // per XCD: ceil(nvgp / 8) * nftp items at most; no more workgroups per XCD than that, and no more than the CUs it has
+  const int per_xcd_items = ((nvgp + 7) / 8) * nftp;
+  int nbx = cus / 8;
+  if(nbx > per_xcd_items) nbx = per_xcd_items;
+  if(nbx < 1) nbx = 1;
+  const int blocks = nbx * 8;
+  const int ipb = 0;
+  (void)total;
   static bool attr_set = false;
   if(!attr_set)
   {
