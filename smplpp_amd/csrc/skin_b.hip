@@ -10,14 +10,18 @@
 // Work item: 64 frames x 64 vertices (x 3 coordinates), one 256-thread workgroup (one wavefront per SIMD, 2 x 2
 // wavefronts of 32 frames x 32 vertices each), 14 k-steps of 16.  Operands are stored in HBM in MFMA FRAGMENT ORDER — a
 // "piece" is the 1 KiB a wavefront's 64 lanes feed to one MFMA (lane l = 32 h + r holds k = 8 h .. 8 h + 7 of row/column
-// r) — so staging is a straight 24 KiB copy per k-step (6 pieces of A, 18 of B), 16 B per lane per instruction, into a
-// double-buffered LDS image that each wavefront reads back with lane-linear ds_read_b128 (conflict-free).  The four
-// wavefronts share the staged bytes: HBM/L2 traffic per MFMA is half that of per-wavefront operand streams.
+// r) — so staging is a straight 24 KiB copy per k-step (6 pieces of A, 18 of B) into one of THREE LDS images, done by
+// LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wavefront instruction, no VGPRs, and none of the 13-cycle VGPR->LDS
+// transfer a ds_write_b128 costs — with register staging the LDS store path alone was ~40 % of the LDS's time); each
+// wavefront reads its fragments back with lane-linear ds_read_b128 (conflict-free).  The four wavefronts share the
+// staged bytes: HBM/L2 traffic per MFMA is half that of per-wavefront operand streams.  The G' tile of an item (72 KiB)
+// arrives the same way.  hipcc does not order LDS reads behind LDS-DMA writes: every barrier that publishes DMA data
+// carries an explicit counted s_waitcnt vmcnt(N), N = the vector-memory instructions issued after the last DMA it needs.
 //
 // Software pipeline (as skin_p.hip): the instruction stream of an item is 252 hand-placed "slots", one per MFMA; the
-// skinning epilogue of the PREVIOUS item (16 accumulator rows x 14 slots), the staging of the operands two k-steps
-// ahead, the fragment reads of the next coordinate and the G' tile of the current item all issue in the MFMA shadows.
-// One raw s_barrier per k-step (slot 12) orders the LDS images; global loads stay in flight across it.
+// skinning epilogue of the PREVIOUS item (16 accumulator rows at a pitch of 13 slots), the DMA of the operands three
+// k-steps ahead, the fragment reads of the next coordinates and the G' tile of the current item all issue in the MFMA
+// shadows.  One raw s_barrier per k-step (slot 6) orders the LDS images; DMAs stay in flight across it.
 #include "common.h"
 
 #include <cstdlib>
@@ -33,24 +37,27 @@ typedef unsigned v3u __attribute__((ext_vector_type(3)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int B_LDS_OP = 2 * BB_KSTEP_BYTES;          // 49152: two operand images
+constexpr int B_NIMG = 3;                              // operand images in LDS (data of k-step d lives in image d mod 3)
+constexpr int B_LDS_OP = B_NIMG * BB_KSTEP_BYTES;      // 73728
 constexpr int B_LDS_G = 64 * NJ * 12 * 4;              // 73728: G' of 64 frames
 constexpr int B_LDS_ROOT = 64 * 16;                    // root translation of 64 frames, one (x, y, z, -) per frame
 constexpr int B_LDS_TOTAL = B_LDS_OP + B_LDS_G + B_LDS_ROOT;
 constexpr int B_SLOTS = 18;                            // MFMAs per k-step: 3 coordinates x 6 piece products
-constexpr int B_ROW_SLOTS = 14;                        // slots per epilogue row
+constexpr int B_NSLOT = BB_KS * B_SLOTS;               // 252 slots per item
 #ifndef SKINB_ABL
-#define SKINB_ABL 0 // timing ablations (development only; results are wrong when non-zero): 1 no epilogue, 2 no staging, 4 no MFMA, 8 no barrier, 16 no fragment reads, 32 staging loads without their LDS writes
+#define SKINB_ABL 0 // timing ablations (development only; results are wrong when non-zero): 1 no epilogue, 2 no staging, 4 no MFMA, 8 no barrier, 16 no fragment reads
 #endif
-constexpr int B_RD_AHEAD = 6;                          // extra slots between a joint's LDS reads and their use (<= 9: the first
-                                                       // read of an item must stay behind the barrier of slot 6)
-constexpr int B_ROOT_KS = 11;                           // k-step whose slot 9 loads the root translations
 constexpr int B_BAR = 6;                               // slot of a k-step that carries its barrier
-constexpr int B_ROW0 = 16;                             // first epilogue slot; the 16 rows end at slot 239, before the
-                                                       // item's last barrier (slot 240), after which G' may be overwritten
-constexpr int B_GCHUNKS = B_LDS_G / (256 * 16);        // 18 x 16 B per thread
-constexpr int B_GW_TAIL = 11;                          // G' chunks written in the item's own last k-step (slots 7..17), the
-                                                       // other 7 in slots 0..5 of the next item
+constexpr int B_PITCH = 13;                            // slots between epilogue rows (a row takes 14: its last overlaps the next's first)
+constexpr int B_ROW0 = 12;                             // first epilogue slot; the rows end at slot 220, before the barrier of
+                                                       // k-step 12 (slot 222), after which the G' image is overwritten
+constexpr int B_ROW_END = B_ROW0 + 15 * B_PITCH + 13;  // 220: last epilogue slot
+constexpr int B_RD_AHEAD = 4;                          // extra slots between a joint's LDS reads and their use (<= 5: the first
+                                                       // read of an item must stay behind the barrier of slot 6)
+constexpr int B_ROOT_P = 9;                            // row slot that reads the root translation (used in slot 13)
+constexpr int B_ROOT_KS = 11;                          // k-step whose slot 14 loads the root translations into a register
+constexpr int B_GCHUNKS = B_LDS_G / (256 * 16);        // 18 DMAs of 1 KiB per wavefront
+constexpr int B_GDMA0 = 12 * B_SLOTS + B_BAR + 1;      // 223: first slot of the G' DMAs (one per slot, 223..240)
 
 template<class F, int... I>
 __device__ __forceinline__ void bstatic_for_impl(F && f, std::integer_sequence<int, I...>)
@@ -67,33 +74,76 @@ __device__ __forceinline__ void bstatic_for(F && f)
 constexpr int B_PA[6] = {2, 0, 1, 1, 0, 0};
 constexpr int B_PB[6] = {0, 2, 1, 0, 1, 0};
 
-// LDS instructions the epilogue of the previous item issues in slot S (joint matrices: 3 ds_read_b128 per joint; root: 1)
-constexpr int B_ROOT_P = 9; // row slot that reads the root translation (used in slot 13)
+// ---- compile-time bookkeeping of what each slot issues (the counted waits of the barriers are derived from it)
+// LDS instructions the epilogue of the previous item issues in slot S BEHIND the slot's sched_barrier line
+// (joint matrices: 3 ds_read_b128 per joint; root translation: 1)
 constexpr int epilogue_lds_ops(int S, int maxw)
 {
   int c = 0;
   const int s2 = S + B_RD_AHEAD - B_ROW0;
-  if(s2 >= 0 && s2 < 16 * B_ROW_SLOTS)
-    for(int j = 0; j < maxw; j++)
-      if(s2 % B_ROW_SLOTS == (3 * j) / (maxw / 4)) c += 3;
+  if(s2 >= 0 && s2 <= 15 * B_PITCH + 12)
+  {
+    const int r = s2 / B_PITCH < 16 ? s2 / B_PITCH : 15;
+    for(int rr = r; rr >= 0 && rr >= r - 1; rr--) // a slot can belong to row rr (slots 0..12) and to row rr - 1 (slot 13)
+    {
+      const int p = s2 - rr * B_PITCH;
+      if(p < 0 || p > 13) continue;
+      for(int j = 0; j < maxw; j++)
+        if(p == (3 * j) / (maxw / 4)) c += 3;
+    }
+  }
   const int s1 = S - B_ROW0;
-  if(s1 >= 0 && s1 < 16 * B_ROW_SLOTS && s1 % B_ROW_SLOTS == B_ROOT_P) c += 1;
+  if(s1 >= 0)
+    for(int rr = 0; rr < 16; rr++)
+      if(s1 - rr * B_PITCH == B_ROOT_P) c += 1;
+  return c;
+}
+// vector-memory instructions slot S of an item issues (hp: the item carries an epilogue; rest: it also stores `rest`)
+constexpr int vmem_ops(int S, bool hp, bool rest)
+{
+  const int m = S % B_SLOTS, ks = S / B_SLOTS;
+  int c = 0;
+  if(m > B_BAR && m <= B_BAR + 6) c += 1;                        // operand DMA
+  if(S >= B_GDMA0 && S < B_GDMA0 + B_GCHUNKS) c += 1;            // G' DMA
+  if(ks == B_ROOT_KS && m == 14) c += 1;                         // root translation load
+  if(hp && S >= B_ROW0)
+    for(int rr = 0; rr < 16; rr++)
+    {
+      if(S - B_ROW0 - rr * B_PITCH == 13) c += 1;                // vertex store of row rr
+      if(rest && S - B_ROW0 - rr * B_PITCH == 0) c += 1;         // rest store of row rr
+    }
+  return c;
+}
+// vmcnt for the barrier of k-step ks (slot 6): the operand DMAs of k-step ks + 1 were issued in slots 7..12 of k-step
+// ks - 2, the G' DMAs of the previous item in its slots 223..240; everything issued after the last of those may stay in
+// flight.  Windows reaching into the previous item use the smaller (stricter) count of the two item kinds.
+constexpr int barrier_vmcnt(int ks, bool hp, bool rest)
+{
+  int c = 0;
+  if(ks >= 2)
+  {
+    for(int S = (ks - 2) * B_SLOTS + B_BAR + 7; S < ks * B_SLOTS + B_BAR; S++) c += vmem_ops(S, hp, rest);
+    return c;
+  }
+  // k-steps 0 and 1: the window starts in the previous item (no epilogue stores counted there: stricter), and k-step 0
+  // also needs the previous item's G' DMAs, the last of which was issued in slot B_GDMA0 + 17
+  const int first = ks == 0 ? B_GDMA0 + B_GCHUNKS : (BB_KS - 1) * B_SLOTS + B_BAR + 7;
+  for(int S = first; S < B_NSLOT; S++) c += vmem_ops(S, false, false);
+  for(int S = 0; S < ks * B_SLOTS + B_BAR; S++) c += vmem_ops(S, false, false);
   return c;
 }
 
-// Barrier of k-step KS (slot 12): the LDS instructions of slots <= 8 must have completed (this wavefront's staging writes
-// and its last reads of the current operand image); the N epilogue reads issued in slots 9..11 may stay in flight.
-template<int N>
-__device__ __forceinline__ void lds_barrier_counted()
+// Barrier of a k-step: LGKM = LDS instructions of this wavefront that may stay in flight (epilogue reads issued behind
+// slot 5's sched_barrier line), VM = vector-memory instructions that may stay in flight (see barrier_vmcnt).
+template<int LGKM, int VM>
+__device__ __forceinline__ void kstep_barrier()
 {
-  asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"(VM), "n"(LGKM) : "memory");
 }
 
-__device__ __forceinline__ void lds_barrier()
+__device__ __forceinline__ void full_barrier()
 {
-  // LDS traffic of this wavefront done, then the workgroup barrier; vmcnt is deliberately NOT waited for (operand and G'
-  // prefetches stay in flight across it)
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template<int MAXW, bool WANT_REST>
@@ -141,10 +191,19 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(theta), 0, (int)(n * (NJ + 1) * 12), 0x00020000);
   const int voffT = ((tid < 192 ? tid : 191) / 3) * ((NJ + 1) * 12) + ((tid < 192 ? tid : 191) % 3) * 4;
 
-  unsigned char * const opLane = lds + tid * 16;                                       // staging writes: + buf * 24576 + i * 4096
-  const unsigned char * const aLane = lds + (wf * 3 * 64 + lane) * 16;                  // A piece s: + s * 1024
-  const unsigned char * const bLane = lds + BB_A_BYTES + (wv * 9 * 64 + lane) * 16;     // B piece (x, s): + (3 x + s) * 1024
-  unsigned char * const gWr = lds + B_LDS_OP + tid * 16;                                // G' staging writes: + i * 4096
+  typedef __attribute__((address_space(3))) void * lds_ptr_t;
+  // LDS map: [3 operand images of 24 KiB][G' tile 72 KiB][root translations 1 KiB]
+  const unsigned char * aImg[B_NIMG]; // this lane's A fragment of image k (piece s: + s * 1024); rotated at item boundaries
+  const unsigned char * bImg[B_NIMG]; // this lane's B fragment of image k (piece (x, s): + (3 x + s) * 1024)
+  int dmaImg[B_NIMG];                 // this wavefront's DMA destination in image k (chunk i: + i * 4096), LDS byte offset
+#pragma unroll
+  for(int k = 0; k < B_NIMG; k++)
+  {
+    aImg[k] = lds + k * BB_KSTEP_BYTES + (wf * 3 * 64 + lane) * 16;
+    bImg[k] = lds + k * BB_KSTEP_BYTES + BB_A_BYTES + (wv * 9 * 64 + lane) * 16;
+    dmaImg[k] = k * BB_KSTEP_BYTES + wave * 1024;
+  }
+  const int dmaG = B_LDS_OP + wave * 1024;                                                // G' tile chunk i: + i * 4096
   const unsigned char * const gLane = lds + B_LDS_OP + (wf * 32 + 4 * half) * (NJ * 48); // G' of frame row R: + rowc(R) * 1152
   float * const sRoot = reinterpret_cast<float *>(lds + B_LDS_OP + B_LDS_G);
   const v4f * const rootLane = reinterpret_cast<const v4f *>(sRoot) + (wf * 32 + 4 * half); // + rowc(R)
@@ -152,8 +211,6 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
 
   f32x16 acc[3], accp[3];
   v4f afr[2][3], bfr[3][3]; // operand fragments (A: by k-step parity; B: by coordinate)
-  v4u stg[2][6];            // operand staging registers, two k-steps deep
-  v4u gstage[B_GCHUNKS];    // G' tile of the current item on its way to LDS
   float rstage = 0.0f;
 
   struct Item
@@ -171,37 +228,41 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
     Bb = vgp * (BB_KS * BB_B_BYTES);
     Gb = ftp * B_LDS_G;
   };
-  auto load_stage = [&](v4u (&s)[6], int Ak, int Bk) { // the 6 chunks of one k-step image (Ak / Bk: byte bases of that k-step)
-    s[0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff0, Ak, 0);
-    s[1] = __builtin_amdgcn_raw_buffer_load_b128(rsM, voffM, mixA ? Ak : Bk, 0);
-#pragma unroll
-    for(int i = 2; i < 6; i++) s[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB + (i - 2) * 4096, Bk, 0);
+  // chunk i (0..5) of one k-step image, HBM/L2 -> LDS by DMA (Ak / Bk: byte bases of that k-step in A3 / B3; dst: LDS byte
+  // offset of this wavefront's share of the image)
+  auto dma_chunk = [&](int i, int Ak, int Bk, int dst) {
+    lds_ptr_t d = (lds_ptr_t)(lds + dst + i * 4096);
+    if(i == 0)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, d, 16, voff0, Ak, 0, 0);
+    else if(i == 1)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, d, 16, voffM, mixA ? Ak : Bk, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, d, 16, voffB + (i - 2) * 4096, Bk, 0, 0);
   };
 
   int f0_prev = 0;
-  // ---- prologue: k-step 0 of the first item into LDS image 0, k-steps 1 and 2 into the staging registers
+  // ---- prologue: k-steps 0, 1, 2 of the first item into images 0, 1, 2
   {
     int Abase, Bbase, Gbase;
     item_bases(jb, Abase, Bbase, Gbase);
     (void)Gbase;
-    v4u s0[6];
-    load_stage(s0, Abase, Bbase);
-    load_stage(stg[1], Abase + BB_A_BYTES, Bbase + BB_B_BYTES);
-    load_stage(stg[0], Abase + 2 * BB_A_BYTES, Bbase + 2 * BB_B_BYTES);
 #pragma unroll
-    for(int i = 0; i < 6; i++) *reinterpret_cast<v4u *>(opLane + i * 4096) = s0[i];
-    lds_barrier();
+    for(int d = 0; d < 3; d++)
 #pragma unroll
-    for(int s = 0; s < 3; s++)
+      for(int i = 0; i < 6; i++) dma_chunk(i, Abase + d * BB_A_BYTES, Bbase + d * BB_B_BYTES, dmaImg[d]);
+    full_barrier();
+#pragma unroll
+    for(int sp = 0; sp < 3; sp++)
     {
-      afr[0][s] = *reinterpret_cast<const v4f *>(aLane + s * 1024);
-      bfr[0][s] = *reinterpret_cast<const v4f *>(bLane + s * 1024);
+      afr[0][sp] = *reinterpret_cast<const v4f *>(aImg[0] + sp * 1024);
+      bfr[0][sp] = *reinterpret_cast<const v4f *>(bImg[0] + sp * 1024);
     }
   }
 
   // one work item; HP (compile time) = there is a previous item whose epilogue rides in this item's MFMA shadows
   auto do_item = [&](int t, auto hp_tag) {
     constexpr bool HP = decltype(hp_tag)::value;
+    constexpr bool EPI = HP && !(SKINB_ABL & 1);
     const int tu = __builtin_amdgcn_readfirstlane(t);
     const int vgp = vg0 + tu / nftp, ftp = tu % nftp;
     const int64_t v = (int64_t)vgp * 64 + wv * 32 + l31;
@@ -230,15 +291,103 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
 #pragma unroll
       for(int r = 0; r < 16; r++) acc[x][r] = 0.0f;
 
-    float rx = 0.f, ry = 0.f, rz = 0.f, rt0 = 0.f, rt1 = 0.f, rt2 = 0.f, hx = 0.f, hy = 0.f;
+    // epilogue state (row R of the previous item lives in rxyz[R & 1]: the last slot of a row is the first of the next)
+    float rxyz[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    float rt0 = 0.f, rt1 = 0.f, rt2 = 0.f, hx = 0.f, hy = 0.f;
     v4f m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0, m2 = m0;
-    constexpr int NSET = 4; // register sets for the joint matrices in flight (a set is re-read 14 slots later)
+    constexpr int NSET = 4; // register sets for the joint matrices in flight (a set is re-read 13 slots later)
+    constexpr int GPS = MAXW / 4; // FMA groups (4 FMAs: one joint, one matrix row) per slot
     v4f gq[NSET][3];
 
-    bstatic_for<BB_KS * B_SLOTS>([&](auto ss) {
+    // LDS reads of the joints of row R2 that belong to row slot P2 (issued B_RD_AHEAD slots early)
+    auto read_piece = [&](auto r2tag, auto p2tag) {
+      constexpr int R2 = decltype(r2tag)::value, P2 = decltype(p2tag)::value;
+      constexpr int ROWC2 = (R2 & 3) + 8 * (R2 >> 2);
+#pragma unroll
+      for(int j = 0; j < MAXW; j++)
+        if(P2 == (3 * j) / GPS)
+        {
+          const unsigned char * gj = gLane + ROWC2 * (NJ * 48) + prev.jofs[j];
+          gq[j % NSET][0] = *reinterpret_cast<const v4f *>(gj);
+          gq[j % NSET][1] = *reinterpret_cast<const v4f *>(gj + 16);
+          gq[j % NSET][2] = *reinterpret_cast<const v4f *>(gj + 32);
+        }
+    };
+    // slot P (0..13) of row R of the previous item
+    auto row_piece = [&](auto rtag, auto ptag) {
+      constexpr int R = decltype(rtag)::value, P = decltype(ptag)::value;
+      constexpr int ROWC = (R & 3) + 8 * (R >> 2); // + 4 * half: accumulator row -> frame in the wavefront's 32
+      float & rx = rxyz[R & 1][0];
+      float & ry = rxyz[R & 1][1];
+      float & rz = rxyz[R & 1][2];
+      if constexpr(P == 0)
+      {
+        rx = accp[0][R];
+        ry = accp[1][R];
+        rz = accp[2][R];
+        if constexpr(WANT_REST)
+        {
+          v3f ov = {rx, ry, rz};
+          __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsR, prev.voff, sb_prev + ROWC * frameB, 2);
+        }
+      }
+      if constexpr(P >= 1 && P <= 12)
+      {
+        // scalar FMAs on purpose: packed f32 VALU beside MFMAs is an anti-lever (MI355X_MICROARCH.md, cycle constants)
+#pragma unroll
+        for(int g = (P - 1) * GPS; g < P * GPS; g++)
+        {
+          const int j = g / 3, row = g % 3;
+          const float w = prev.jw[j];
+          const v4f gm = gq[j % NSET][row];
+          v4f & mm = (row == 0 ? m0 : (row == 1 ? m1 : m2));
+          if(j == 0)
+          {
+            mm.x = w * gm.x;
+            mm.y = w * gm.y;
+            mm.z = w * gm.z;
+            mm.w = w * gm.w;
+          }
+          else
+          {
+            mm.x = __builtin_fmaf(w, gm.x, mm.x);
+            mm.y = __builtin_fmaf(w, gm.y, mm.y);
+            mm.z = __builtin_fmaf(w, gm.z, mm.z);
+            mm.w = __builtin_fmaf(w, gm.w, mm.w);
+          }
+        }
+      }
+      if constexpr(P == B_ROOT_P)
+      {
+        const v4f rt = rootLane[ROWC];
+        rt0 = rt.x;
+        rt1 = rt.y;
+        rt2 = rt.z;
+      }
+      if constexpr(P == 12 && MAXW == 4)
+      {
+        hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
+        hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
+      }
+      if constexpr(P == 13)
+      {
+        if constexpr(MAXW != 4)
+        {
+          hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
+          hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
+        }
+        const float hz = ((m2.x * rx + m2.y * ry) + m2.z * rz) + m2.w;
+        // write-once output: non-temporal (aux = 2); the descriptor's range check drops frames >= n and vertex-less lanes.
+        // (An MFMA always follows before the next VALU write: see the store hazard note at the drain.)
+        v3f ov = {hx * prev.winv + rt0, hy * prev.winv + rt1, hz * prev.winv + rt2};
+        __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsV, prev.voff, sb_prev + ROWC * frameB, 2);
+      }
+    };
+
+    bstatic_for<B_NSLOT>([&](auto ss) {
       constexpr int S = decltype(ss)::value;
       constexpr int KS = S / B_SLOTS, M = S % B_SLOTS, X = M / 6, Q = M % 6;
-      constexpr int AP = KS & 1;
+      constexpr int AP = KS & 1, IMG = KS % B_NIMG, IMGN = (KS + 1) % B_NIMG;
       if constexpr(!(SKINB_ABL & 4))
         acc[X] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[AP][B_PA[Q]]),
                                                          __builtin_bit_cast(bf16x8, bfr[X][B_PB[Q]]), acc[X], 0, 0, 0);
@@ -246,175 +395,92 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
 
       if constexpr(M == B_BAR && !(SKINB_ABL & 8))
       {
-        // Barrier of the k-step: every wavefront has written its share of image (KS + 1) & 1 (slots 0..5) and has issued
-        // its last reads of image KS & 1.  Only the epilogue reads of slot 5 (issued behind its sched_barrier line) may
-        // stay in flight; k-step 0 also publishes the G' tile, and the last k-step retires every read of it.
-        constexpr int NOPS = (HP && !(SKINB_ABL & 1)) ? epilogue_lds_ops(S - 1, MAXW) : 0;
-        if constexpr(KS == BB_KS - 1 || NOPS == 0)
-          lds_barrier();
-        else
-          lds_barrier_counted<NOPS>();
+        // Barrier of the k-step.  After it: image (KS + 1) % 3 holds k-step KS + 1 (its DMAs have landed: vmcnt) and
+        // image KS % 3 is free for the DMAs of k-step KS + 3 (every wavefront has issued its last reads of it).  Only the
+        // epilogue reads of slot 5 (issued behind its sched_barrier line) may stay in flight in the LDS queue; k-step 0
+        // also publishes the root translations, and k-step 12 retires every read of the G' tile before its DMAs overwrite it.
+        constexpr int LG = (EPI && KS != 12) ? epilogue_lds_ops(S - 1, MAXW) : 0;
+        constexpr int VM = barrier_vmcnt(KS, EPI, WANT_REST);
+        kstep_barrier<(LG < 15 ? LG : 15), (VM < 63 ? VM : 63)>();
       }
-      // ---- operand fragments: coordinates 1 and 2 of this k-step early (image KS & 1), then — behind the barrier of
-      // slot 6 — the A pieces and coordinate 0 of the NEXT k-step, a dozen slots before their first MFMA
-      if constexpr(M < 3 && !(SKINB_ABL & 16)) bfr[1][M] = *reinterpret_cast<const v4f *>(bLane + AP * BB_KSTEP_BYTES + (3 + M) * 1024);
-      if constexpr(M >= 3 && M < 6 && !(SKINB_ABL & 16)) bfr[2][M - 3] = *reinterpret_cast<const v4f *>(bLane + AP * BB_KSTEP_BYTES + (6 + M - 3) * 1024);
+      // ---- operand fragments: coordinates 1 and 2 of this k-step early, then — behind the barrier of slot 6 — the A pieces
+      // and coordinate 0 of the NEXT k-step, a dozen slots before their first MFMA
+      if constexpr(M < 3 && !(SKINB_ABL & 16)) bfr[1][M] = *reinterpret_cast<const v4f *>(bImg[IMG] + (3 + M) * 1024);
+      if constexpr(M >= 3 && M < 6 && !(SKINB_ABL & 16)) bfr[2][M - 3] = *reinterpret_cast<const v4f *>(bImg[IMG] + (6 + M - 3) * 1024);
       if constexpr(M >= B_BAR && M < B_BAR + 3 && !(SKINB_ABL & 16))
       {
-        constexpr int NB_ = (KS + 1) & 1;
-        afr[NB_][M - B_BAR] = *reinterpret_cast<const v4f *>(aLane + NB_ * BB_KSTEP_BYTES + (M - B_BAR) * 1024);
-        bfr[0][M - B_BAR] = *reinterpret_cast<const v4f *>(bLane + NB_ * BB_KSTEP_BYTES + (M - B_BAR) * 1024);
+        afr[(KS + 1) & 1][M - B_BAR] = *reinterpret_cast<const v4f *>(aImg[IMGN] + (M - B_BAR) * 1024);
+        bfr[0][M - B_BAR] = *reinterpret_cast<const v4f *>(bImg[IMGN] + (M - B_BAR) * 1024);
       }
-      // ---- staging: write k-step KS + 1 (loaded two k-steps ago) into the other image, re-issue the registers for KS + 3
-      if constexpr(M < 6 && !(SKINB_ABL & 2))
+      // ---- root translations of the PREVIOUS item: register -> LDS, published by the barrier of k-step 0
+      if constexpr(EPI && KS == 0 && M == B_BAR - 1) *rootWr = rstage;
+      __builtin_amdgcn_sched_barrier(0); // (the LDS instructions above are the ones the k-step barrier has to wait for)
+
+      // ---- operand DMA: k-step KS + 3 into the image this k-step has just finished with (slots 7..12, one chunk each)
+      if constexpr(M > B_BAR && M <= B_BAR + 6 && !(SKINB_ABL & 2))
       {
-        constexpr int SET = (KS + 1) & 1;
-        if constexpr(SKINB_ABL & 32)
-          asm volatile("" ::"v"(stg[SET][M])); // ablation: keep the load, drop the LDS write
-        else
-          *reinterpret_cast<v4u *>(opLane + SET * BB_KSTEP_BYTES + M * 4096) = stg[SET][M];
         constexpr int KN = KS + 3;
         const int Ak = (KN < BB_KS ? Abase + KN * BB_A_BYTES : Abn + (KN - BB_KS) * BB_A_BYTES);
         const int Bk = (KN < BB_KS ? Bbase + KN * BB_B_BYTES : Bbn + (KN - BB_KS) * BB_B_BYTES);
-        if constexpr(M == 0) stg[SET][0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff0, Ak, 0);
-        if constexpr(M == 1) stg[SET][1] = __builtin_amdgcn_raw_buffer_load_b128(rsM, voffM, mixA ? Ak : Bk, 0);
-        if constexpr(M >= 2) stg[SET][M] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB + (M - 2) * 4096, Bk, 0);
+        dma_chunk(M - B_BAR - 1, Ak, Bk, dmaImg[IMG]);
       }
-
-      // ---- G' tile + root translations, registers -> LDS: chunks 0..10 of the CURRENT item's tile in its own last k-step
-      // (slots 7..17: every row of the previous item has been read by then, and the barrier of slot 6 says so for all four
-      // wavefronts); the other 7 chunks and the roots in slots 0..5 of the next item, published by its first barrier.
-      if constexpr(KS == BB_KS - 1 && M > B_BAR && !(SKINB_ABL & 1)) *reinterpret_cast<v4u *>(gWr + (M - B_BAR - 1) * 4096) = gstage[M - B_BAR - 1];
-      if constexpr(HP && KS == 0 && M < B_BAR && !(SKINB_ABL & 1))
+      // ---- G' tile of the CURRENT item: HBM -> LDS by DMA, slots 223..240 (the rows of the previous item ended in slot 220
+      // and the barrier of slot 222 said so for all four wavefronts); published by the first barrier of the next item
+      if constexpr(S >= B_GDMA0 && S < B_GDMA0 + B_GCHUNKS && !(SKINB_ABL & 1))
       {
-        constexpr int W0 = B_GW_TAIL + M + (M > 0 ? 1 : 0), WN = M == 0 ? 2 : 1; // 11,12 | 13 | 14 | 15 | 16 | 17
-#pragma unroll
-        for(int i = W0; i < W0 + WN; i++) *reinterpret_cast<v4u *>(gWr + i * 4096) = gstage[i];
-        if constexpr(M == B_BAR - 1) *rootWr = rstage;
+        constexpr int GI = S - B_GDMA0;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr_t)(lds + dmaG + GI * 4096), 16, voff0 + GI * 4096, Gbase, 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0); // (the LDS instructions above are the ones the k-step barrier has to wait for)
-
-      // ---- G' tile and root translations of the CURRENT item: HBM -> registers (k-steps 2..10), written to LDS by the next item
-      if constexpr(KS >= 2 && KS <= 10 && (M == 9 || M == 16))
-      {
-        constexpr int GI = (KS - 2) * 2 + (M == 16 ? 1 : 0);
-        gstage[GI] = __builtin_amdgcn_raw_buffer_load_b128(rsG, voff0 + GI * 4096, Gbase, 0);
-      }
-      if constexpr(KS == B_ROOT_KS && M == 9)
+      if constexpr(KS == B_ROOT_KS && M == 14)
       {
         // root translation theta[f, 0, :] (src/SMPL.cpp:726-727) of the block's 64 frames: 192 values, one per thread.
         // Buffer load: 32-bit offsets only (no 64-bit VALU address math in the MFMA stream); frames >= n read as 0.
         rstage = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, voffT, ftp * (64 * (NJ + 1) * 12), 0));
       }
 
-      if constexpr(HP && !(SKINB_ABL & 1))
+      if constexpr(EPI)
       {
-        // ---- LDS reads of joint j of row R': issued B_RD_AHEAD slots before the slot that would precede the joint's first
-        // FMA group (a slot is 32 MFMA cycles; three ds_read_b128 need ~100 to land)
-        if constexpr(S + B_RD_AHEAD >= B_ROW0 && S + B_RD_AHEAD < B_ROW0 + 16 * B_ROW_SLOTS)
+        // ---- joint matrices of the rows to come (LDS reads B_RD_AHEAD slots early)
+        constexpr int S2 = S + B_RD_AHEAD - B_ROW0;
+        if constexpr(S2 >= 0 && S2 <= 15 * B_PITCH + 12)
         {
-          constexpr int R2 = (S + B_RD_AHEAD - B_ROW0) / B_ROW_SLOTS, P2 = (S + B_RD_AHEAD - B_ROW0) % B_ROW_SLOTS;
-          constexpr int ROWC2 = (R2 & 3) + 8 * (R2 >> 2);
-#pragma unroll
-          for(int j = 0; j < MAXW; j++)
-            if(P2 == (3 * j) / (MAXW / 4))
-            {
-              const unsigned char * gj = gLane + ROWC2 * (NJ * 48) + prev.jofs[j];
-              gq[j % NSET][0] = *reinterpret_cast<const v4f *>(gj);
-              gq[j % NSET][1] = *reinterpret_cast<const v4f *>(gj + 16);
-              gq[j % NSET][2] = *reinterpret_cast<const v4f *>(gj + 32);
-            }
+          constexpr int R2 = S2 / B_PITCH < 16 ? S2 / B_PITCH : 15;
+          if constexpr(S2 - R2 * B_PITCH <= 13) read_piece(std::integral_constant<int, R2>{}, std::integral_constant<int, S2 - R2 * B_PITCH>{});
+          if constexpr(R2 >= 1 && S2 - (R2 - 1) * B_PITCH <= 13)
+            read_piece(std::integral_constant<int, R2 - 1>{}, std::integral_constant<int, S2 - (R2 - 1) * B_PITCH>{});
         }
-        // ---- one piece of row R of the previous item
-        if constexpr(S >= B_ROW0 && S < B_ROW0 + 16 * B_ROW_SLOTS)
+        // ---- this slot's piece(s) of the rows in progress (finishing slot of row R - 1 first, then the opening slot of row R)
+        constexpr int S1 = S - B_ROW0;
+        if constexpr(S1 >= 0 && S1 <= B_ROW_END - B_ROW0)
         {
-          constexpr int R = (S - B_ROW0) / B_ROW_SLOTS, P = (S - B_ROW0) % B_ROW_SLOTS;
-          constexpr int ROWC = (R & 3) + 8 * (R >> 2); // + 4 * half: accumulator row -> frame in the wavefront's 32
-          constexpr int GPS = MAXW / 4;               // FMA groups (4 FMAs: one joint, one matrix row) per slot
-          if constexpr(P == 0)
-          {
-            rx = accp[0][R];
-            ry = accp[1][R];
-            rz = accp[2][R];
-            if constexpr(WANT_REST)
-            {
-              v3f ov = {rx, ry, rz};
-              __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsR, prev.voff,
-                                                    sb_prev + ROWC * frameB, 2);
-            }
-          }
-          if constexpr(P >= 1 && P <= 12)
-          {
-            // scalar FMAs on purpose: packed f32 VALU beside MFMAs is an anti-lever (MI355X_MICROARCH.md, cycle constants)
-#pragma unroll
-            for(int g = (P - 1) * GPS; g < P * GPS; g++)
-            {
-              const int j = g / 3, row = g % 3;
-              const float w = prev.jw[j];
-              const v4f gm = gq[j % NSET][row];
-              v4f & mm = (row == 0 ? m0 : (row == 1 ? m1 : m2));
-              if(j == 0)
-              {
-                mm.x = w * gm.x;
-                mm.y = w * gm.y;
-                mm.z = w * gm.z;
-                mm.w = w * gm.w;
-              }
-              else
-              {
-                mm.x = __builtin_fmaf(w, gm.x, mm.x);
-                mm.y = __builtin_fmaf(w, gm.y, mm.y);
-                mm.z = __builtin_fmaf(w, gm.z, mm.z);
-                mm.w = __builtin_fmaf(w, gm.w, mm.w);
-              }
-            }
-          }
-          if constexpr(P == B_ROOT_P)
-          {
-            const v4f rt = rootLane[ROWC];
-            rt0 = rt.x;
-            rt1 = rt.y;
-            rt2 = rt.z;
-          }
-          if constexpr(P == 12 && MAXW == 4)
-          {
-            hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
-            hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
-          }
-          if constexpr(P == 13)
-          {
-            if constexpr(MAXW != 4)
-            {
-              hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
-              hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
-            }
-            const float hz = ((m2.x * rx + m2.y * ry) + m2.z * rz) + m2.w;
-            // write-once output: non-temporal (aux = 2); the descriptor's range check drops frames >= n and vertex-less lanes
-            v3f ov = {hx * prev.winv + rt0, hy * prev.winv + rt1, hz * prev.winv + rt2};
-            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsV, prev.voff,
-                                                  sb_prev + ROWC * frameB, 2);
-          }
+          constexpr int R = S1 / B_PITCH < 16 ? S1 / B_PITCH : 15;
+          if constexpr(R >= 1 && S1 - (R - 1) * B_PITCH == 13) row_piece(std::integral_constant<int, R - 1>{}, std::integral_constant<int, 13>{});
+          if constexpr(S1 - R * B_PITCH <= 13) row_piece(std::integral_constant<int, R>{}, std::integral_constant<int, S1 - R * B_PITCH>{});
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     });
 
-    // the current item becomes the previous one
+    // the current item becomes the previous one; the images rotate (14 k-steps per item, 14 mod 3 = 2)
 #pragma unroll
     for(int x = 0; x < 3; x++) accp[x] = acc[x];
     prev = cur;
     f0_prev = f0_cur;
+    {
+      const unsigned char * a0 = aImg[0], * b0 = bImg[0];
+      const int d0 = dmaImg[0];
+      aImg[0] = aImg[2]; bImg[0] = bImg[2]; dmaImg[0] = dmaImg[2];
+      aImg[2] = aImg[1]; bImg[2] = bImg[1]; dmaImg[2] = dmaImg[1];
+      aImg[1] = a0; bImg[1] = b0; dmaImg[1] = d0;
+    }
   };
 
   do_item(jb, std::false_type{});
   for(int t = jb + nbx; t < cnt; t += nbx) do_item(t, std::true_type{});
 
-  // ---- drain: G' of the last item into LDS, then its epilogue with nothing to hide behind
-  lds_barrier(); // everyone is done with the previous G' image (and with the operand images)
-#pragma unroll
-  for(int i = 0; i < B_GCHUNKS; i++) *reinterpret_cast<v4u *>(gWr + i * 4096) = gstage[i];
+  // ---- drain: the epilogue of the last item with nothing to hide behind (its G' tile was DMA'd in its own slots 223..240)
   *rootWr = rstage;
-  lds_barrier();
+  full_barrier();
   bstatic_for<16>([&](auto rr) {
     constexpr int R = decltype(rr)::value;
     constexpr int ROWC = (R & 3) + 8 * (R >> 2);
