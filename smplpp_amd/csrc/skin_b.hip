@@ -98,6 +98,14 @@ constexpr int epilogue_lds_ops(int S, int maxw)
       if(s1 - rr * B_PITCH == B_ROOT_P) c += 1;
   return c;
 }
+// LDS instructions issued between the last fragment read of a k-step (slot 14, ahead of that slot's sched_barrier line) and
+// the barrier in slot S = 18 ks + 6 of the next one: the epilogue reads of slots 14..17 and 0..5
+constexpr int lds_ops_since_frag_reads(int S, int maxw)
+{
+  int c = 0;
+  for(int q = S - 10; q < S; q++) c += epilogue_lds_ops(q, maxw);
+  return c;
+}
 // vector-memory instructions slot S of an item issues (hp: the item carries an epilogue; rest: it also stores `rest`)
 constexpr int vmem_ops(int S, bool hp, bool rest)
 {
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
   float * const rootWr = sRoot + ((tid < 192 ? tid : 191) / 3) * 4 + (tid < 192 ? tid % 3 : 3); // threads >= 192 hit the pad word
 
   f32x16 acc[3], accp[3];
-  v4f afr[2][3], bfr[3][3]; // operand fragments (A: by k-step parity; B: by coordinate)
+  v4f afr[2][3], bfr[2][3][3]; // operand fragments by k-step parity (B: [coordinate][piece]); a k-step's twelve are read during the one before
   float rstage = 0.0f;
 
   struct Item
@@ -255,7 +263,8 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
     for(int sp = 0; sp < 3; sp++)
     {
       afr[0][sp] = *reinterpret_cast<const v4f *>(aImg[0] + sp * 1024);
-      bfr[0][sp] = *reinterpret_cast<const v4f *>(bImg[0] + sp * 1024);
+#pragma unroll
+      for(int x = 0; x < 3; x++) bfr[0][x][sp] = *reinterpret_cast<const v4f *>(bImg[0] + (3 * x + sp) * 1024);
     }
   }
 
@@ -386,31 +395,32 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
 
     bstatic_for<B_NSLOT>([&](auto ss) {
       constexpr int S = decltype(ss)::value;
-      constexpr int KS = S / B_SLOTS, M = S % B_SLOTS, X = M / 6, Q = M % 6;
+      constexpr int KS = S / B_SLOTS, M = S % B_SLOTS;
+      constexpr int X = M / 6, Q = M % 6;
       constexpr int AP = KS & 1, IMG = KS % B_NIMG, IMGN = (KS + 1) % B_NIMG;
       if constexpr(!(SKINB_ABL & 4))
         acc[X] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[AP][B_PA[Q]]),
-                                                         __builtin_bit_cast(bf16x8, bfr[X][B_PB[Q]]), acc[X], 0, 0, 0);
+                                                         __builtin_bit_cast(bf16x8, bfr[AP][X][B_PB[Q]]), acc[X], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 
       if constexpr(M == B_BAR && !(SKINB_ABL & 8))
       {
         // Barrier of the k-step.  After it: image (KS + 1) % 3 holds k-step KS + 1 (its DMAs have landed: vmcnt) and
-        // image KS % 3 is free for the DMAs of k-step KS + 3 (every wavefront has issued its last reads of it).  Only the
-        // epilogue reads of slot 5 (issued behind its sched_barrier line) may stay in flight in the LDS queue; k-step 0
-        // also publishes the root translations, and k-step 12 retires every read of the G' tile before its DMAs overwrite it.
-        constexpr int LG = (EPI && KS != 12) ? epilogue_lds_ops(S - 1, MAXW) : 0;
+        // image KS % 3 is free for the DMAs of k-step KS + 3 (every wavefront's reads of it have completed: lgkmcnt).
+        // k-step 0 also publishes the root translations; k-step 12 retires every read of the G' tile before its DMAs overwrite it.
+        // LDS instructions that may stay in flight: those issued after this wavefront's last read of image KS % 3 (slot 14 of
+        // the previous k-step); for k-step 0 those after the root translation write of slot 5.
+        constexpr int LG = !EPI || KS == 12 ? 0 : (KS == 0 ? epilogue_lds_ops(S - 1, MAXW) : lds_ops_since_frag_reads(S, MAXW));
         constexpr int VM = barrier_vmcnt(KS, EPI, WANT_REST);
         kstep_barrier<(LG < 15 ? LG : 15), (VM < 63 ? VM : 63)>();
       }
-      // ---- operand fragments: coordinates 1 and 2 of this k-step early, then — behind the barrier of slot 6 — the A pieces
-      // and coordinate 0 of the NEXT k-step, a dozen slots before their first MFMA
-      if constexpr(M < 3 && !(SKINB_ABL & 16)) bfr[1][M] = *reinterpret_cast<const v4f *>(bImg[IMG] + (3 + M) * 1024);
-      if constexpr(M >= 3 && M < 6 && !(SKINB_ABL & 16)) bfr[2][M - 3] = *reinterpret_cast<const v4f *>(bImg[IMG] + (6 + M - 3) * 1024);
-      if constexpr(M >= B_BAR && M < B_BAR + 3 && !(SKINB_ABL & 16))
+      // ---- operand fragments of the NEXT k-step, all twelve behind this k-step's barrier (slots 6..14): their image has
+      // landed, they are >= 6 slots old at the next barrier (whose LDS wait is then free) and >= 6 slots ahead of their MFMAs
+      if constexpr(M >= B_BAR && M < B_BAR + 9 && !(SKINB_ABL & 16))
       {
-        afr[(KS + 1) & 1][M - B_BAR] = *reinterpret_cast<const v4f *>(aImg[IMGN] + (M - B_BAR) * 1024);
-        bfr[0][M - B_BAR] = *reinterpret_cast<const v4f *>(bImg[IMGN] + (M - B_BAR) * 1024);
+        constexpr int NP = (KS + 1) & 1, XX = (M - B_BAR) / 3, SP = (M - B_BAR) % 3;
+        if constexpr(XX == 0) afr[NP][SP] = *reinterpret_cast<const v4f *>(aImg[IMGN] + SP * 1024);
+        bfr[NP][XX][SP] = *reinterpret_cast<const v4f *>(bImg[IMGN] + (3 * XX + SP) * 1024);
       }
       // ---- root translations of the PREVIOUS item: register -> LDS, published by the barrier of k-step 0
       if constexpr(EPI && KS == 0 && M == B_BAR - 1) *rootWr = rstage;
