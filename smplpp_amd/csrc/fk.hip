@@ -44,6 +44,14 @@ __device__ inline void rodrigues_dev(float t0, float t1, float t2, float * R)
 
 // grid = n frames, block = 64.  rot_in (nullable): use these [n,24,3,3] matrices instead of Rodrigues(theta)
 // (stage entry point WorldTransformation::transform on arbitrary 3x3 input); joints_in likewise.
+// The block of pose_kernel is ONE wavefront: LDS traffic of a wavefront is executed in order, so its phases only need
+// the compiler to keep that order.  __syncthreads() would also wait for vmcnt(0), i.e. for every global STORE issued so
+// far (rotations, A operand, joints) to reach L2 — microseconds per phase in a kernel that is pure latency.
+__device__ __forceinline__ void wave_sync()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 __global__ __launch_bounds__(64) void pose_kernel(const float * __restrict__ beta, const float * __restrict__ theta,
                                                   const float * __restrict__ J0, const float * __restrict__ JS,
                                                   const int32_t * __restrict__ parent, float * __restrict__ AT, int64_t ldA,
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(64) void pose_kernel(const float * __restrict__ bet
 #pragma unroll
       for(int q = 0; q < 9; q++) AT[(int64_t)(9 * (lane - 1) + q) * ldA + f] = R[q] - ((q == 0 || q == 4 || q == 8) ? 1.0f : 0.0f);
   }
-  __syncthreads();
+  wave_sync();
   if(AT)
   {
     if(lane < NB) AT[(int64_t)(K_BETA + lane) * ldA + f] = sBeta[lane];
@@ -142,14 +150,14 @@ __global__ __launch_bounds__(64) void pose_kernel(const float * __restrict__ bet
     sJ[e / 3][e % 3] = s;
     if(joints_out) joints_out[f * NJ * 3 + e] = s;
   }
-  __syncthreads();
+  wave_sync();
   // chain: G_0 = L_0, G_i = G_p(i) . L_i with L_i = [R_i | j_i - j_p(i)] (src/WorldTransformation.cpp:508-610)
   if(lane < 12)
   {
     int r = lane / 4, c = lane % 4;
     sG[0][lane] = (c < 3) ? sR[0][r * 3 + c] : sJ[0][r];
   }
-  __syncthreads();
+  wave_sync();
   for(int i = 1; i < NJ; i++)
   {
     if(lane < 12)
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(64) void pose_kernel(const float * __restrict__ bet
       }
       sG[i][lane] = v;
     }
-    __syncthreads();
+    wave_sync();
   }
   // relative transforms: translation -= A_i . j_i (src/WorldTransformation.cpp:657-677)
   for(int e = lane; e < NJ * 12; e += 64)
@@ -414,7 +422,7 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
   // operand pieces on the bf16 matrix pipe, fp32-exact; p (skin_p.hip): fp32 MFMA, one wavefront per SIMD, persistent,
   // skinning rows issued in MFMA shadows; q (skin_q.hip, staggered work queue) and v1 (skin_kernel above) are kept for
   // comparison.  Forms with 32-bit output offsets fall back to v1 for outputs of 2 GiB and more.
-  static const char * form_env = getenv("SMPLPP_SKIN");
+  const char * form_env = getenv("SMPLPP_SKIN"); // read per call: the parity tests switch forms inside one process
   char form = form_env ? form_env[0] : 'b';
   if(m->maxw > 8) form = 'v';
   if((form == 'b' || form == 'p') && n * m->V * 12 >= 0x7fffff00LL) form = 'v';

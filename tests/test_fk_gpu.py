@@ -137,6 +137,26 @@ def test_fk_writes_only_its_frames(smpl, n):
         assert bool((big[k][:n] != 777.0).all()), k
 
 
+def test_fk_bf16x3_form_is_fp32_exact(smpl, oracle_synth, monkeypatch):
+    """The default fused kernel carries every fp32 operand as three bf16 pieces on the bf16 matrix pipe (skin_b.hip).
+    Its error against the fp64-accumulating oracle must be of the same size as that of the fp32-MFMA form (skin_p.hip),
+    far inside the 1e-5 m parity bar, on shaped vertices and skinned vertices alike."""
+    from smplpp_amd import model_io
+
+    beta, theta = model_io.synthetic_inputs(200, seed=11)
+    beta = (beta * 3.0).astype(np.float32)  # large shape coefficients: stresses the low pieces
+    r = oracle_synth.fk(beta, theta)
+    err = {}
+    for form in ("b", "p"):
+        monkeypatch.setenv("SMPLPP_SKIN", form)
+        o = smpl.launch(beta, theta)
+        err[form] = {k: float(np.abs(o[k] - r[k]).max()) for k in ("verts", "rest")}
+    monkeypatch.delenv("SMPLPP_SKIN")
+    for k in ("verts", "rest"):
+        assert err["b"][k] < 2e-6, err
+        assert err["b"][k] <= 3.0 * err["p"][k] + 2e-7, err
+
+
 def test_stage_kats_on_gpu(kats):
     """The reference's own stage KATs (src/toolbox/Tester.cpp) through the stage-level entry points."""
     from smplpp_amd import smpl as S
