@@ -4,8 +4,8 @@
 // bound by it.  Here every fp32 operand is carried as THREE bf16 pieces, x = x1 + x2 + x3 exactly (8 + 8 + 8 significant
 // bits), and a product a.b is evaluated as the six bf16 MFMAs a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 accumulated in
 // fp32 — the three dropped cross terms are below 2^-24 |a||b|, the size of one fp32 rounding.  6 MFMAs of 32 cycles do the
-// work of 8 fp32 MFMAs of 64 cycles: 2.6x fewer matrix-pipe cycles at fp32-level accuracy (checked against the fp64
-// oracle in tests/test_fk_gpu.py beside the fp32 forms).
+// work of 8 fp32 MFMAs of 64 cycles: 2.6x fewer matrix-pipe cycles at fp32-level accuracy (the parity tests compare it
+// with the fp32-MFMA forms against an fp64-accumulating CPU restatement: tests/test_fk_gpu.py).
 //
 // Work item: 64 frames x 64 vertices (x 3 coordinates), one 256-thread workgroup (one wavefront per SIMD, 2 x 2
 // wavefronts of 32 frames x 32 vertices each), 14 k-steps of 16.  Operands are stored in HBM in MFMA FRAGMENT ORDER — a
