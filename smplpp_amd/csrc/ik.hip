@@ -669,20 +669,57 @@ __device__ inline void chol_aug(double * M, int nf, int * bad, double * dinv)
   }
 }
 
-// back substitution L^T x = y (y = row nf of M), x returned in xs[0..nf); dinv[j] = 1 / L[j][j]
+// back substitution L^T x = y (y = row nf of M), x returned in xs[0..nf); dinv[j] = 1 / L[j][j].
+// Inside ONE wavefront: lane l keeps x[l], x[l + 64], x[l + 128] in registers, the pivot value travels by v_readlane and
+// row j of L is a contiguous LDS read that does not depend on the recurrence — no workgroup barrier per column (the
+// barrier-per-column form spent ~2 x nf barriers of four wavefronts on a strictly sequential chain).
+__device__ inline double readlane_f64(double v, int lane)
+{
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
 __device__ inline void back_subst(const double * M, int nf, double * xs, const double * dinv)
 {
   const int tid = threadIdx.x;
-  for(int i = tid; i < nf; i += blockDim.x) xs[i] = M[tri_idx(nf, i)];
-  __syncthreads();
-  for(int j = nf - 1; j >= 0; j--)
+  if(nf > 192) // (not reached by any mode of the reference: D <= 75 + 2 * 41 + 10)
   {
-    const double xj = xs[j] * dinv[j];
+    for(int i = tid; i < nf; i += blockDim.x) xs[i] = M[tri_idx(nf, i)];
     __syncthreads();
-    for(int k = tid; k < j; k += blockDim.x) xs[k] -= M[tri_idx(j, k)] * xj;
-    if(tid == 0) xs[j] = xj;
-    __syncthreads();
+    for(int j = nf - 1; j >= 0; j--)
+    {
+      const double xj = xs[j] * dinv[j];
+      __syncthreads();
+      for(int k = tid; k < j; k += blockDim.x) xs[k] -= M[tri_idx(j, k)] * xj;
+      if(tid == 0) xs[j] = xj;
+      __syncthreads();
+    }
+    return;
   }
+  __syncthreads(); // M and dinv are complete
+  if(tid < 64)
+  {
+    double x[3];
+#pragma unroll
+    for(int a = 0; a < 3; a++) x[a] = (tid + 64 * a < nf) ? M[tri_idx(nf, tid + 64 * a)] : 0.0;
+    for(int j = nf - 1; j >= 0; j--)
+    {
+      const int ja = __builtin_amdgcn_readfirstlane(j >> 6), jl = __builtin_amdgcn_readfirstlane(j & 63);
+      const double * Lj = M + tri_idx(j, 0);
+      double l[3];
+#pragma unroll
+      for(int a = 0; a < 3; a++) l[a] = (tid + 64 * a < j) ? Lj[tid + 64 * a] : 0.0;
+      const double xv = ja == 0 ? x[0] : (ja == 1 ? x[1] : x[2]);
+      const double xj = readlane_f64(xv, jl) * dinv[j];
+#pragma unroll
+      for(int a = 0; a < 3; a++) x[a] = (tid + 64 * a == j) ? xj : x[a] - l[a] * xj;
+    }
+#pragma unroll
+    for(int a = 0; a < 3; a++)
+      if(tid + 64 * a < nf) xs[tid + 64 * a] = x[a];
+  }
+  __syncthreads();
 }
 
 // 1/sqrt(d) in fp64: hardware estimate (v_rsq_f64) + two Newton steps (relative error ~1e-16), an order of magnitude
@@ -695,6 +732,29 @@ __device__ inline double fast_rsqrt(double d)
   return y;
 }
 
+// HBM -> LDS copy of cnt doubles by the 256 threads of the workgroup: eight loads in flight per thread (a one-load-per-
+// iteration loop pays the full memory latency nine times for a 24 x 87 Jacobian)
+__device__ inline void stage_rows(double * dst, const double * __restrict__ src, int cnt)
+{
+  const int tid = threadIdx.x;
+  for(int q0 = 0; q0 < cnt; q0 += 256 * 8)
+  {
+    double t[8];
+#pragma unroll
+    for(int u = 0; u < 8; u++)
+    {
+      const int q = q0 + u * 256 + tid;
+      t[u] = src[q < cnt ? q : cnt - 1];
+    }
+#pragma unroll
+    for(int u = 0; u < 8; u++)
+    {
+      const int q = q0 + u * 256 + tid;
+      if(q < cnt) dst[q] = t[u];
+    }
+  }
+}
+
 // Register-tiled build + factorisation of the augmented free-set system for nf + 1 <= 16 * NT: thread (ty, tx) of the
 // 16 x 16 workgroup owns the elements (ty + 16a, tx + 16b), b <= a, in registers.  Per column ONE barrier: the column's
 // holders publish its raw entries (and the pivot entry) to LDS, every thread then applies the rank-1 update to its own
@@ -702,7 +762,8 @@ __device__ inline double fast_rsqrt(double d)
 template<int NT>
 __device__ inline void build_and_factor_reg(double * M, const double * __restrict__ J, const double * __restrict__ rowv, double * Jc,
                                             const double * diag, const double * bpri, const int * idx, int nf, int D, int rows,
-                                            int chunk_rows, double * lraw /*[2][16*NT]*/, double * ldiag /*[4]*/, double * dinv /*[nf]*/, int * bad)
+                                            int chunk_rows, double * lraw /*[2][16*NT]*/, double * ldiag /*[4]*/, double * dinv /*[nf]*/, int * bad,
+                                            int dbg_stop = 0)
 {
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   double acc[NT][NT];
@@ -721,16 +782,22 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
   {
     const int cr = (rows - c0 < chunk_rows) ? rows - c0 : chunk_rows;
     __syncthreads();
-    for(int q = tid; q < cr * D; q += 256) Jc[q] = J[(int64_t)c0 * D + q];
+    stage_rows(Jc, J + (int64_t)c0 * D, cr * D);
     __syncthreads();
+    // branch-free: every lane loads (a clamped column, the rhs entry) unconditionally and selects afterwards, so the twelve
+    // LDS reads of a row issue back to back and the rows pipeline (conditional loads cost a branch + a full LDS round trip each)
+#pragma unroll 4
     for(int r = 0; r < cr; r++)
     {
       double vi[NT], vk[NT];
+      const double rv = rowv[c0 + r];
 #pragma unroll
       for(int a = 0; a < NT; a++)
       {
-        vi[a] = (colI[a] >= 0) ? Jc[r * D + colI[a]] : (colI[a] == -1 ? rowv[c0 + r] : 0.0);
-        vk[a] = (colK[a] >= 0) ? Jc[r * D + colK[a]] : 0.0;
+        const double ji = Jc[r * D + (colI[a] >= 0 ? colI[a] : 0)];
+        const double jk = Jc[r * D + (colK[a] >= 0 ? colK[a] : 0)];
+        vi[a] = (colI[a] >= 0) ? ji : (colI[a] == -1 ? rv : 0.0);
+        vk[a] = (colK[a] >= 0) ? jk : 0.0;
       }
 #pragma unroll
       for(int a = 0; a < NT; a++)
@@ -747,6 +814,7 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
       if(i < nf && i == k) acc[a][b] += diag[idx[i]];
       if(i == nf && k < nf) acc[a][b] += bpri[idx[k]];
     }
+  if(dbg_stop == 4) return;
   // factorisation
 #pragma unroll
   for(int bj = 0; bj < NT; bj++)
@@ -798,9 +866,10 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
 #pragma unroll
       for(int a = bj; a < NT; a++)
       {
-        const int i = ty + 16 * a, k = tx + 16 * a;
-        li[a] = (i > j && i <= nf) ? lr[i] : 0.0;
-        lk[a] = (k > j && k < nf) ? lr[k] * inv_d : 0.0;
+        const int i = ty + 16 * a, k = tx + 16 * a; // < 16 NT: inside lraw, loads are unconditional (stale entries are masked)
+        const double ri = lr[i], rk = lr[k];
+        li[a] = (i > j && i <= nf) ? ri : 0.0;
+        lk[a] = (k > j && k < nf) ? rk * inv_d : 0.0;
       }
 #pragma unroll
       for(int a = bj; a < NT; a++)
@@ -818,7 +887,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
                                                        float * __restrict__ theta, float * __restrict__ beta, float * __restrict__ pts,
                                                        int K, int theta_dim, int beta_dim, int phi_live, int enable_qp, int use_prior,
                                                        int chunk_rows, const int * __restrict__ skip, double * __restrict__ e2_out,
-                                                       int * __restrict__ status, double * __restrict__ x_out)
+                                                       int * __restrict__ status, double * __restrict__ x_out, int dbg_stop)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int64_t f = blockIdx.x;
@@ -839,7 +908,8 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   double * dinv = ldiag + 4;   // [D] reciprocal pivots for the back substitution
   int * idx = reinterpret_cast<int *>(dinv + D);
   int * state = idx + D; // 0 free, -1 at lo, +1 at hi, 2 pinned (empty box)
-  __shared__ int s_bad, s_nf, s_block, s_bside, s_done, s_anybound;
+  double * ebuf = reinterpret_cast<double *>(state + D); // [rows] the residual, read from HBM once
+  __shared__ int s_bad, s_nf, s_block, s_bside, s_done, s_anybound, s_wcnt[4];
   __shared__ double s_alpha, s_e2;
   if(skip[f])
   {
@@ -847,13 +917,14 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     for(int k = tid; k < K * 3; k += 256) pts[tb * 3 + k] = ta.apos[tb * 3 + k];
     return;
   }
-  const double * e = e_all + f * rows;
   const double * J = J_all + f * rows * (int64_t)D;
-
+  for(int r = tid; r < rows; r += 256) ebuf[r] = e_all[f * rows + r];
+  __syncthreads();
+  const double * e = ebuf;
   if(tid == 0)
   {
     double s = 0.0;
-    for(int r = 0; r < rows; r++) s += e[r] * e[r];
+    for(int r = 0; r < rows; r++) s += e[r] * e[r]; // ascending order, as the oracle sums it
     s_e2 = s;
     s_bad = 0;
     s_done = 0;
@@ -905,10 +976,33 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   }
   __syncthreads();
 
+  if(dbg_stop == 1) return; // (timing experiments only: SMPLPP_IK_DBG_STOP)
   const int max_it = enable_qp ? 4 * D + 20 : 1;
   for(int it = 0; it < max_it; it++)
   {
-    if(tid == 0)
+    if(D <= 256)
+    {
+      // free-set index list in ascending order: one variable per thread, ballot + prefix over the four wavefronts
+      // (a single thread walking `state` pays an LDS round trip per variable)
+      int st = 2;
+      if(tid < D) st = state[tid];
+      const int is_free = (st == 0), is_b = ((st == -1 || st == 1) && xfull[tid < D ? tid : 0] != 0.0);
+      const uint64_t m = __ballot(is_free);
+      const int wave = tid >> 6, lane = tid & 63;
+      if(lane == 0) s_wcnt[wave] = __popcll(m);
+      const int anyb = __syncthreads_or(is_b);
+      int base = 0;
+      for(int w = 0; w < wave; w++) base += s_wcnt[w];
+      if(is_free) idx[base + __popcll(m & ((1ull << lane) - 1ull))] = tid;
+      if(tid == 0)
+      {
+        s_nf = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        s_anybound = anyb;
+        s_alpha = 1.0;
+        s_block = -1;
+      }
+    }
+    else if(tid == 0)
     {
       int nf = 0, anyb = 0;
       for(int i = 0; i < D; i++)
@@ -937,7 +1031,8 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     {
       // small systems (every mode except the 41-marker body solve): registers, one barrier per column
       __syncthreads();
-      build_and_factor_reg<6>(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, chunk_rows, lraw, ldiag, dinv, &s_bad);
+      build_and_factor_reg<6>(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, chunk_rows, lraw, ldiag, dinv, &s_bad, dbg_stop);
+      if(dbg_stop == 4) return;
     }
     else
     {
@@ -946,7 +1041,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       {
         const int cr = (rows - c0 < chunk_rows) ? rows - c0 : chunk_rows;
         __syncthreads();
-        for(int q = tid; q < cr * D; q += 256) Jc[q] = J[(int64_t)c0 * D + q];
+        stage_rows(Jc, J + (int64_t)c0 * D, cr * D);
         __syncthreads();
         {
           const int ty = tid >> 4, tx = tid & 15; // 16 x 16 tiling of the lower triangle (+ the rhs row i == nf)
@@ -976,7 +1071,9 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       __syncthreads();
       chol_aug(M, nf, &s_bad, dinv);
     }
+    if(dbg_stop == 2) return;
     back_subst(M, nf, xs, dinv);
+    if(dbg_stop == 3) return;
     if(!enable_qp)
     {
       for(int a = tid; a < nf; a += 256) xfull[idx[a]] = -xs[a]; // x = -LLT(A)^-1 b (node.cpp:938)
@@ -1562,7 +1659,7 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
     const int beta_dim = opt_beta ? NB : 0;
     // LDS plan: packed system + vectors, the rest (up to a 150 KB total) for the J row chunk
     const int D = s->theta_dim + 2 * K + beta_dim, rows = 4 * K;
-    const size_t fixed = sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 7 * (size_t)D + rows + 196) + sizeof(int) * 2 * (size_t)D;
+    const size_t fixed = sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 7 * (size_t)D + 2 * (size_t)rows + 196) + sizeof(int) * 2 * (size_t)D;
     const size_t budget = 150 * 1024;
     int chunk_rows = (int)((budget - fixed) / (sizeof(double) * (size_t)D));
     if(chunk_rows > rows) chunk_rows = rows;
@@ -1570,7 +1667,8 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
     const size_t solve_shmem = fixed + sizeof(double) * (size_t)chunk_rows * D;
     ik_solve_kernel<<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, s->pts, K,
                                                                         s->theta_dim, beta_dim, phi_live, enable_qp, s->vp ? 1 : 0,
-                                                                        chunk_rows, s->skip, s->e2, s->status, s->xout);
+                                                                        chunk_rows, s->skip, s->e2, s->status, s->xout,
+                                                                        getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0);
     HIP_TRY(hipGetLastError());
     DBG_SYNC("solve");
     {
