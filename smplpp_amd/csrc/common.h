@@ -133,6 +133,8 @@ struct smplpp_model
   float * J0 = nullptr;        // [24][3]      Jreg . T
   float * JS = nullptr;        // [24][3][10]  Jreg . S
   int32_t * parent = nullptr;  // [24]
+  int32_t * lvl = nullptr;     // [25 + 24] kinematic tree by depth: level offsets, then the joints sorted by level
+  int nlev = 0;
   int32_t * faces = nullptr;   // [F][3] 0-based
   int32_t * adjOff = nullptr;  // [V+1]
   int32_t * adjFace = nullptr; // [adjOff[V]] ascending face id per vertex

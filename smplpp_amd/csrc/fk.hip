@@ -42,150 +42,153 @@ __device__ inline void rodrigues_dev(float t0, float t1, float t2, float * R)
     }
 }
 
-// grid = n frames, block = 64.  rot_in (nullable): use these [n,24,3,3] matrices instead of Rodrigues(theta)
-// (stage entry point WorldTransformation::transform on arbitrary 3x3 input); joints_in likewise.
-// The block of pose_kernel is ONE wavefront: LDS traffic of a wavefront is executed in order, so its phases only need
-// the compiler to keep that order.  __syncthreads() would also wait for vmcnt(0), i.e. for every global STORE issued so
-// far (rotations, A operand, joints) to reach L2 — microseconds per phase in a kernel that is pure latency.
+// LDS traffic of one wavefront is executed in order, so the phases of a single-wavefront section only need the compiler
+// to keep that order (no s_barrier, and no vmcnt(0) drain of outstanding global stores as __syncthreads() would add).
 __device__ __forceinline__ void wave_sync()
 {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(64) void pose_kernel(const float * __restrict__ beta, const float * __restrict__ theta,
-                                                  const float * __restrict__ J0, const float * __restrict__ JS,
-                                                  const int32_t * __restrict__ parent, float * __restrict__ AT, int64_t ldA,
-                                                  float * __restrict__ Gp, float * __restrict__ joints_out,
-                                                  float * __restrict__ rot_out, float * __restrict__ xf44_out,
-                                                  const float * __restrict__ rot_in, const float * __restrict__ joints_in,
-                                                  int64_t n, uint16_t * __restrict__ A3 = nullptr)
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for every global store
+// issued so far (A operand, rotations, joints) to reach L2 — microseconds per phase in a kernel that is pure latency.
+__device__ __forceinline__ void block_sync_lds()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// grid = n frames, block = 256 (four wavefronts per frame: the kernel is a chain of dependent latencies, so the work of a
+// frame is spread over as many lanes as it has independent pieces).
+//   phase 0  theta/beta in, Rodrigues x24
+//   phase 1  220 pose/shape coefficients (one per thread) -> AT (fp32 forms) / LDS (bf16x3 form); 72 joint coordinates
+//   phase 2  wavefront 0..1: the 84 bf16x3 fragment chunks of A3; wavefront 3: the kinematic chain, one tree LEVEL at a
+//            time (lane = (joint of the level, entry of its 3x4 transform); SMPL: 9 levels instead of 23 sequential joints)
+//   phase 3  relative transforms G', 4x4 outputs
+// levels: [nlev + 1] offsets into lvl_joint, then the joints sorted by depth (built at model creation).
+__global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ beta, const float * __restrict__ theta,
+                                                   const float * __restrict__ J0, const float * __restrict__ JS,
+                                                   const int32_t * __restrict__ parent, const int32_t * __restrict__ lvl_off,
+                                                   const int32_t * __restrict__ lvl_joint, int nlev, float * __restrict__ AT, int64_t ldA,
+                                                   float * __restrict__ Gp, float * __restrict__ joints_out,
+                                                   float * __restrict__ rot_out, float * __restrict__ xf44_out, int64_t n,
+                                                   uint16_t * __restrict__ A3)
 {
   const int64_t f = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   __shared__ float sR[NJ][9];
   __shared__ float sJ[NJ][3];
   __shared__ float sG[NJ][12]; // global transforms [A | g], 3x4 row-major
   __shared__ float sBeta[NB];
+  __shared__ float sCoef[224]; // the A operand row of this frame: [c(207) | beta(10) | 1 | 0...]
   __shared__ int sPar[NJ];
+  __shared__ int sLvl[NJ + 1 + NJ];
   if(f >= n) return;
-  if(lane < NB && beta) sBeta[lane] = beta[f * NB + lane];
-  if(lane < NJ) sPar[lane] = parent[lane];
-  if(lane < NJ)
+  // ---- phase 0
+  if(tid >= 64 && tid < 64 + NB) sBeta[tid - 64] = beta ? beta[f * NB + (tid - 64)] : 0.0f;
+  if(tid >= 128 && tid < 128 + NJ) sPar[tid - 128] = parent[tid - 128];
+  if(tid >= 192 && tid < 192 + nlev + 1) sLvl[tid - 192] = lvl_off[tid - 192];
+  if(tid >= 224 && tid < 224 + NJ) sLvl[NJ + 1 + tid - 224] = lvl_joint[tid - 224];
+  if(tid < NJ)
   {
     float R[9];
-    if(rot_in)
-    {
+    const float * th = theta + (f * (NJ + 1) + 1 + tid) * 3; // theta[:,1:,:] (src/SMPL.cpp:685-686)
+    rodrigues_dev(th[0], th[1], th[2], R);
 #pragma unroll
-      for(int q = 0; q < 9; q++) R[q] = rot_in[(f * NJ + lane) * 9 + q];
-    }
-    else
-    {
-      const float * th = theta + (f * (NJ + 1) + 1 + lane) * 3; // theta[:,1:,:] (src/SMPL.cpp:685-686)
-      rodrigues_dev(th[0], th[1], th[2], R);
-    }
-#pragma unroll
-    for(int q = 0; q < 9; q++) sR[lane][q] = R[q];
+    for(int q = 0; q < 9; q++) sR[tid][q] = R[q];
     if(rot_out)
 #pragma unroll
-      for(int q = 0; q < 9; q++) rot_out[(f * NJ + lane) * 9 + q] = R[q];
-    if(AT && lane >= 1) // root joint has no pose corrective (src/BlendShape.cpp:884-887)
+      for(int q = 0; q < 9; q++) rot_out[(f * NJ + tid) * 9 + q] = R[q];
+  }
+  block_sync_lds();
+  // ---- phase 1: coefficient k = tid (root joint has no pose corrective: src/BlendShape.cpp:884-887) and joint coordinate tid
+  if(tid < 224)
+  {
+    const int k = tid;
+    float a = 0.0f;
+    if(k < NP)
+    {
+      const int q = k % 9;
+      a = sR[1 + k / 9][q] - ((q == 0 || q == 4 || q == 8) ? 1.0f : 0.0f);
+    }
+    else if(k < NP + NB)
+      a = sBeta[k - NP];
+    else if(k == K_ONE)
+      a = 1.0f;
+    sCoef[k] = a;
+    if(AT && k < KP) AT[(int64_t)k * ldA + f] = a;
+  }
+  if(tid < NJ * 3) // joints (src/JointRegression.cpp:588-590 through the folded regressor)
+  {
+    float s = J0[tid];
 #pragma unroll
-      for(int q = 0; q < 9; q++) AT[(int64_t)(9 * (lane - 1) + q) * ldA + f] = R[q] - ((q == 0 || q == 4 || q == 8) ? 1.0f : 0.0f);
+    for(int k = 0; k < NB; k++) s += JS[tid * NB + k] * sBeta[k];
+    sJ[tid / 3][tid % 3] = s;
+    if(joints_out) joints_out[f * NJ * 3 + tid] = s;
   }
-  wave_sync();
-  if(AT)
+  block_sync_lds();
+  // ---- phase 2
+  if(A3 && tid < 84)
   {
-    if(lane < NB) AT[(int64_t)(K_BETA + lane) * ldA + f] = sBeta[lane];
-    if(lane == NB) AT[(int64_t)K_ONE * ldA + f] = 1.0f;
-    if(lane == NB + 1) AT[(int64_t)(K_ONE + 1) * ldA + f] = 0.0f;
-    if(lane == NB + 2) AT[(int64_t)(K_ONE + 2) * ldA + f] = 0.0f;
-  }
-  if(A3 && lane < 28)
-  {
-    // the same 220 coefficients (padded to 224) as bf16x3 pieces in MFMA fragment order (layout: common.h): lane c owns
-    // k = 8 c .. 8 c + 7 = element j of MFMA lane 32 h + r in k-step ks, three 16-byte stores
-    const int ks = lane >> 1, h = lane & 1;
+    // bf16x3 pieces in MFMA fragment order (layout: common.h): chunk c = k / 8 is element block j of MFMA lane 32 h + r in
+    // k-step ks = c / 2, h = c % 2; thread (c, s) writes the 16 bytes of piece s
+    const int c = tid % 28, sp = tid / 28, ks = c >> 1, h = c & 1;
     const int64_t ftp = f >> 6;
     const int fh = (int)((f >> 5) & 1), r = (int)(f & 31);
-    uint16_t pc[3][8];
+    uint16_t pc[8];
 #pragma unroll
     for(int j = 0; j < 8; j++)
     {
-      const int k = 8 * lane + j;
-      float a = 0.0f;
-      if(k < NP)
+      uint16_t p0, p1, p2;
+      split_bf16x3(sCoef[8 * c + j], p0, p1, p2);
+      pc[j] = sp == 0 ? p0 : (sp == 1 ? p1 : p2);
+    }
+    uint16_t * dst = A3 + ((((ftp * BB_KS + ks) * 2 + fh) * 3 + sp) * 64 + (32 * h + r)) * 8;
+    uint4 w;
+    w.x = pc[0] | ((uint32_t)pc[1] << 16);
+    w.y = pc[2] | ((uint32_t)pc[3] << 16);
+    w.z = pc[4] | ((uint32_t)pc[5] << 16);
+    w.w = pc[6] | ((uint32_t)pc[7] << 16);
+    *reinterpret_cast<uint4 *>(dst) = w;
+  }
+  if(tid >= 192)
+  {
+    // chain: G_0 = L_0, G_i = G_p(i) . L_i with L_i = [R_i | j_i - j_p(i)] (src/WorldTransformation.cpp:508-610), level by
+    // level; within a level the joints are independent (their parents are one level up)
+    const int lane = tid - 192, slot = lane / 12, e = lane % 12, r = e / 4, c = e % 4;
+    for(int L = 0; L < nlev; L++)
+    {
+      const int lo = sLvl[L], hi = sLvl[L + 1];
+      for(int q0 = lo; q0 < hi; q0 += 5)
       {
-        const int q = k % 9;
-        a = sR[1 + k / 9][q] - ((q == 0 || q == 4 || q == 8) ? 1.0f : 0.0f);
+        if(slot < 5 && q0 + slot < hi)
+        {
+          const int i = sLvl[NJ + 1 + q0 + slot], p = sPar[i];
+          float v;
+          if(p < 0)
+            v = (c < 3) ? sR[i][r * 3 + c] : sJ[i][r];
+          else if(c < 3)
+            v = sG[p][r * 4 + 0] * sR[i][0 * 3 + c] + sG[p][r * 4 + 1] * sR[i][1 * 3 + c] + sG[p][r * 4 + 2] * sR[i][2 * 3 + c];
+          else
+          {
+            const float t0 = sJ[i][0] - sJ[p][0], t1 = sJ[i][1] - sJ[p][1], t2 = sJ[i][2] - sJ[p][2];
+            v = sG[p][r * 4 + 0] * t0 + sG[p][r * 4 + 1] * t1 + sG[p][r * 4 + 2] * t2 + sG[p][r * 4 + 3];
+          }
+          sG[i][e] = v;
+        }
       }
-      else if(k < NP + NB)
-        a = sBeta[k - NP];
-      else if(k == K_ONE)
-        a = 1.0f;
-      split_bf16x3(a, pc[0][j], pc[1][j], pc[2][j]);
-    }
-#pragma unroll
-    for(int s = 0; s < 3; s++)
-    {
-      uint16_t * dst = A3 + ((((ftp * BB_KS + ks) * 2 + fh) * 3 + s) * 64 + (32 * h + r)) * 8;
-      uint4 w;
-      w.x = pc[s][0] | ((uint32_t)pc[s][1] << 16);
-      w.y = pc[s][2] | ((uint32_t)pc[s][3] << 16);
-      w.z = pc[s][4] | ((uint32_t)pc[s][5] << 16);
-      w.w = pc[s][6] | ((uint32_t)pc[s][7] << 16);
-      *reinterpret_cast<uint4 *>(dst) = w;
+      wave_sync();
     }
   }
-  for(int e = lane; e < NJ * 3; e += 64) // joints (src/JointRegression.cpp:588-590 through the folded regressor)
+  block_sync_lds();
+  // ---- phase 3: relative transforms: translation -= A_i . j_i (src/WorldTransformation.cpp:657-677)
+  for(int e = tid; e < NJ * 12; e += 256)
   {
-    float s;
-    if(joints_in)
-      s = joints_in[f * NJ * 3 + e];
-    else
-    {
-      s = J0[e];
-#pragma unroll
-      for(int k = 0; k < NB; k++) s += JS[e * NB + k] * sBeta[k];
-    }
-    sJ[e / 3][e % 3] = s;
-    if(joints_out) joints_out[f * NJ * 3 + e] = s;
-  }
-  wave_sync();
-  // chain: G_0 = L_0, G_i = G_p(i) . L_i with L_i = [R_i | j_i - j_p(i)] (src/WorldTransformation.cpp:508-610)
-  if(lane < 12)
-  {
-    int r = lane / 4, c = lane % 4;
-    sG[0][lane] = (c < 3) ? sR[0][r * 3 + c] : sJ[0][r];
-  }
-  wave_sync();
-  for(int i = 1; i < NJ; i++)
-  {
-    if(lane < 12)
-    {
-      int r = lane / 4, c = lane % 4, p = sPar[i];
-      float v;
-      if(c < 3)
-        v = sG[p][r * 4 + 0] * sR[i][0 * 3 + c] + sG[p][r * 4 + 1] * sR[i][1 * 3 + c] + sG[p][r * 4 + 2] * sR[i][2 * 3 + c];
-      else
-      {
-        float t0 = sJ[i][0] - sJ[p][0], t1 = sJ[i][1] - sJ[p][1], t2 = sJ[i][2] - sJ[p][2];
-        v = sG[p][r * 4 + 0] * t0 + sG[p][r * 4 + 1] * t1 + sG[p][r * 4 + 2] * t2 + sG[p][r * 4 + 3];
-      }
-      sG[i][lane] = v;
-    }
-    wave_sync();
-  }
-  // relative transforms: translation -= A_i . j_i (src/WorldTransformation.cpp:657-677)
-  for(int e = lane; e < NJ * 12; e += 64)
-  {
-    int i = e / 12, q = e % 12, r = q / 4, c = q % 4;
+    const int i = e / 12, q = e % 12, r = q / 4, c = q % 4;
     float v = sG[i][q];
     if(c == 3) v -= sG[i][r * 4 + 0] * sJ[i][0] + sG[i][r * 4 + 1] * sJ[i][1] + sG[i][r * 4 + 2] * sJ[i][2];
     if(Gp) Gp[(f * NJ + i) * 12 + q] = v;
     if(xf44_out) xf44_out[(f * NJ + i) * 16 + q] = v;
   }
-  if(xf44_out)
-    for(int e = lane; e < NJ * 4; e += 64) xf44_out[(f * NJ + e / 4) * 16 + 12 + e % 4] = (e % 4 == 3) ? 1.0f : 0.0f;
+  if(xf44_out && tid < NJ * 4) xf44_out[(f * NJ + tid / 4) * 16 + 12 + tid % 4] = (tid % 4 == 3) ? 1.0f : 0.0f;
 }
 
 // rows [n, ldA) of AT are padding for the last 32-frame tile: keep them zero (re-zeroed whenever n changes)
@@ -431,8 +434,8 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
   if(form == 'b')
   {
     HIP_TRY(ws.A3.reserve((size_t)(n64 / 64) * BB_KS * BB_A_BYTES));
-    pose_kernel<<<dim3((unsigned)n), dim3(64), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, nullptr, 0, ws.Gp.as<float>(), joints,
-                                                        poserot, xforms44, nullptr, nullptr, n, ws.A3.as<uint16_t>());
+    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
+                                                         ws.Gp.as<float>(), joints, poserot, xforms44, n, ws.A3.as<uint16_t>());
   }
   else
   {
@@ -445,8 +448,8 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
       int64_t cnt = (int64_t)KP * (ldA - n);
       zero_pad_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(ws.AT.as<float>(), ldA, n);
     }
-    pose_kernel<<<dim3((unsigned)n), dim3(64), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, ws.AT.as<float>(), ldA,
-                                                        ws.Gp.as<float>(), joints, poserot, xforms44, nullptr, nullptr, n);
+    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, ws.AT.as<float>(),
+                                                         ldA, ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr);
   }
   HIP_TRY(hipGetLastError());
   if(verts || rest)

@@ -157,7 +157,7 @@ extern "C" int smplpp_model_destroy(smplpp_model * m)
 {
   if(!m) return SMPLPP_OK;
   (void)hipSetDevice(m->device);
-  void * ptrs[] = {m->Bm, m->B3, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm};
+  void * ptrs[] = {m->Bm, m->B3, m->lvl, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm};
   for(void * p : ptrs)
     if(p) (void)hipFree(p);
   Workspace & w = m->ws;
@@ -274,6 +274,26 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   TRY_OR_FREE(upload(&m->wSum, hSum.data(), hSum.size()));
   TRY_OR_FREE(upload(&m->Wdense, W, (size_t)V * NJ));
   TRY_OR_FREE(upload(&m->parent, parent.data(), parent.size()));
+  {
+    // joints by depth: the FK chain advances one tree level per step (SMPL: 9 levels)
+    std::vector<int32_t> depth(NJ, 0), lv(NJ + 1 + NJ, 0);
+    int nlev = 1;
+    for(int i = 1; i < NJ; i++)
+    {
+      depth[i] = depth[parent[i]] + 1;
+      nlev = std::max(nlev, depth[i] + 1);
+    }
+    int pos = 0;
+    for(int L = 0; L < nlev; L++)
+    {
+      lv[L] = pos;
+      for(int i = 0; i < NJ; i++)
+        if(depth[i] == L) lv[NJ + 1 + pos++] = i;
+    }
+    lv[nlev] = pos;
+    m->nlev = nlev;
+    TRY_OR_FREE(upload(&m->lvl, lv.data(), lv.size()));
+  }
 
   // --- faces + adjacency (src/SMPL.cpp:620-640; emplace keeps one entry per (vertex, face)) ---
   m->h_faces.resize((size_t)F * 3);
