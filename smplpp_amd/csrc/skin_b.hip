@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
     float rxyz[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     float rt0 = 0.f, rt1 = 0.f, rt2 = 0.f, hx = 0.f, hy = 0.f;
     v4f m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0, m2 = m0;
-    constexpr int NSET = 4; // register sets for the joint matrices in flight (a set is re-read 13 slots later)
+    constexpr int NSET = MAXW; // one register set per joint of a row: a set is re-read 13 slots later, after its last use
     constexpr int GPS = MAXW / 4; // FMA groups (4 FMAs: one joint, one matrix row) per slot
     v4f gq[NSET][3];
 

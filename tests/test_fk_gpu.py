@@ -107,6 +107,36 @@ def test_fk_dense_weights_and_ragged_vertex_count():
         assert np.abs(o[k] - g[k]).max() < VERT_TOL, k
 
 
+@pytest.mark.parametrize("form", ["b", "p"])
+def test_fk_eight_weights_per_vertex(synth_model, form, monkeypatch):
+    """Models with 5..8 skinning weights per vertex take the MAXW = 8 instantiations of the fused kernels (real SMPL has
+    at most 4); ragged frame counts exercise partial frame tiles and the single-item / multi-item paths."""
+    from smplpp_amd.smpl import SMPL
+    from oracle.cpu import OracleModel
+
+    md = {k: v.copy() for k, v in synth_model.items()}
+    rng = np.random.default_rng(5)
+    w = md["weights"].astype(np.float64)
+    for v in range(w.shape[0]):  # add 1..4 more joints with small weights, renormalise like the generator does
+        extra = rng.choice(np.where(w[v] == 0)[0], size=int(rng.integers(1, 5)), replace=False)
+        w[v, extra] = rng.uniform(0.01, 0.1, len(extra))
+    w /= w.sum(axis=1, keepdims=True)
+    md["weights"] = w.astype(np.float32)
+    monkeypatch.setenv("SMPLPP_SKIN", form)
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(md)
+    assert s.info()["weights_per_vertex"] == 8
+    o = OracleModel(md)
+    from smplpp_amd import model_io
+    for n in (3, 70, 333):
+        beta, theta = model_io.synthetic_inputs(n, seed=n)
+        g = s.launch(beta, theta)
+        r = o.fk(beta, theta)
+        for k in ("verts", "rest", "joints"):
+            assert np.abs(g[k] - r[k]).max() < VERT_TOL, (form, n, k)
+
+
 def test_fk_device_pointers_torch(smpl, oracle_synth):
     import torch
     from smplpp_amd import model_io
