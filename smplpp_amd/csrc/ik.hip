@@ -30,6 +30,7 @@ int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t
 constexpr int TD75 = SMPLPP_THETA_DIM;        // 75
 constexpr int TD44 = SMPLPP_LATENT_POSE_DIM;  // 44
 constexpr int NQ = TD75 + NB;                 // differentiation columns handled per frame: theta(75) | beta(10)
+constexpr int IK_MAXK = 48;                   // tasks per frame supported (the reference uses at most 41: MocapBody markers)
 constexpr int MAXADJ = 12;                    // adjacent faces per vertex supported by the normal Jacobian
 constexpr int MAXRING = 3 * (MAXADJ + 1) + 1; // distinct vertices a task can touch
 constexpr int MAXD = 170;                     // unknowns per frame supported by the in-LDS solver
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
                                                       int phi_live, int min_valid, int32_t * __restrict__ ring_buf,
                                                       uint8_t * __restrict__ map_buf, float * __restrict__ pos804,
                                                       double * __restrict__ e_out, double * __restrict__ J_out,
-                                                      int * __restrict__ skip)
+                                                      int * __restrict__ skip, int dbg_stop)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int * sAnc = reinterpret_cast<int *>(lds + L_END);
@@ -206,58 +207,51 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
   }
   __syncthreads();
 
-  // ---- chain derivatives: thread c = rotation column (joint c/3, component c%3)
-  if(tid < 72)
+  if(dbg_stop == 20) return; // (timing experiments only: SMPLPP_IK_DBG_STOP)
+  // ---- chain derivatives: thread (c, r) = rotation column c (joint c/3, component c%3) x matrix
+  // row r.  Row r of dA_i and dg_i depends only on row r of the parent's: 216 independent 24-step recurrences (one thread
+  // per column walked all three rows through ~40 dependent LDS accesses per joint).
+  if(tid < 216)
   {
-    const int c = tid, jc = c / 3;
+    const int c = tid % 72, r = tid / 72, jc = c / 3;
     for(int i = 0; i < NJ; i++)
     {
-      float dA[9], dg[3] = {0.f, 0.f, 0.f};
+      float dA[3] = {0.f, 0.f, 0.f}, dg = 0.f;
       const int p = mv.parent[i];
       if(!((sAnc[i] >> jc) & 1))
       {
-        for(int q = 0; q < 9; q++) dA[q] = 0.f;
       }
       else if(i == jc)
       {
         const float * dR = lds + L_DR + c * 9;
         if(i == 0)
-          for(int q = 0; q < 9; q++) dA[q] = dR[q];
+          for(int cc = 0; cc < 3; cc++) dA[cc] = dR[r * 3 + cc];
         else
         {
           const float * Ap = lds + L_G + p * 12;
-          for(int r = 0; r < 3; r++)
-            for(int cc = 0; cc < 3; cc++)
-              dA[r * 3 + cc] = Ap[r * 4 + 0] * dR[cc] + Ap[r * 4 + 1] * dR[3 + cc] + Ap[r * 4 + 2] * dR[6 + cc];
+          for(int cc = 0; cc < 3; cc++) dA[cc] = Ap[r * 4 + 0] * dR[cc] + Ap[r * 4 + 1] * dR[3 + cc] + Ap[r * 4 + 2] * dR[6 + cc];
         }
       }
       else
       {
-        // parent's dA and dg (dg_p = db_p + dA_p . j_p)
-        float dAp[9], dgp[3];
-        for(int q = 0; q < 9; q++) dAp[q] = lds[L_DAB + (p * 12 + (q / 3) * 4 + q % 3) * 72 + c];
-        for(int r = 0; r < 3; r++)
-          dgp[r] = lds[L_DAB + (p * 12 + r * 4 + 3) * 72 + c]
-                   + (dAp[r * 3] * lds[L_J + p * 3] + dAp[r * 3 + 1] * lds[L_J + p * 3 + 1] + dAp[r * 3 + 2] * lds[L_J + p * 3 + 2]);
+        // parent's dA row and dg (dg_p = db_p + dA_p . j_p)
+        float dAp[3];
+        for(int q = 0; q < 3; q++) dAp[q] = lds[L_DAB + (p * 12 + r * 4 + q) * 72 + c];
+        const float dgp = lds[L_DAB + (p * 12 + r * 4 + 3) * 72 + c]
+                          + (dAp[0] * lds[L_J + p * 3] + dAp[1] * lds[L_J + p * 3 + 1] + dAp[2] * lds[L_J + p * 3 + 2]);
         const float * Ri = lds + L_R + i * 9;
         const float * ti = lds + L_T + i * 3;
-        for(int r = 0; r < 3; r++)
-        {
-          for(int cc = 0; cc < 3; cc++) dA[r * 3 + cc] = dAp[r * 3] * Ri[cc] + dAp[r * 3 + 1] * Ri[3 + cc] + dAp[r * 3 + 2] * Ri[6 + cc];
-          dg[r] = (dAp[r * 3] * ti[0] + dAp[r * 3 + 1] * ti[1] + dAp[r * 3 + 2] * ti[2]) + dgp[r];
-        }
+        for(int cc = 0; cc < 3; cc++) dA[cc] = dAp[0] * Ri[cc] + dAp[1] * Ri[3 + cc] + dAp[2] * Ri[6 + cc];
+        dg = (dAp[0] * ti[0] + dAp[1] * ti[1] + dAp[2] * ti[2]) + dgp;
       }
-      for(int r = 0; r < 3; r++)
-      {
-        for(int cc = 0; cc < 3; cc++) lds[L_DAB + (i * 12 + r * 4 + cc) * 72 + c] = dA[r * 3 + cc];
-        lds[L_DAB + (i * 12 + r * 4 + 3) * 72 + c] =
-            dg[r] - (dA[r * 3] * lds[L_J + i * 3] + dA[r * 3 + 1] * lds[L_J + i * 3 + 1] + dA[r * 3 + 2] * lds[L_J + i * 3 + 2]);
-      }
+      for(int cc = 0; cc < 3; cc++) lds[L_DAB + (i * 12 + r * 4 + cc) * 72 + c] = dA[cc];
+      lds[L_DAB + (i * 12 + r * 4 + 3) * 72 + c] =
+          dg - (dA[0] * lds[L_J + i * 3] + dA[1] * lds[L_J + i * 3 + 1] + dA[2] * lds[L_J + i * 3 + 2]);
     }
   }
-  else if(tid < 72 + NB && optimize_beta) // beta columns: joints move, rotations do not
+  else if(tid < 216 + NB && optimize_beta) // beta columns: joints move, rotations do not
   {
-    const int k = tid - 72;
+    const int k = tid - 216;
     float dgl[NJ][3];
     for(int i = 0; i < NJ; i++)
     {
@@ -281,6 +275,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
     }
   }
 
+  if(dbg_stop == 21) return;
   // ---- phase A: one thread per task — tangents, weight refresh, residual rows, ring list (node.cpp:803-820)
   if(tid < K)
   {
@@ -314,11 +309,12 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
     for(int i = 0; i < 3; i++) ta.vw[(tb + k) * 3 + i] = w[i];
     float ap[3], an[3] = {0.f, 0.f, 0.f};
     actual_pos_dev(mv, verts, face, w, off, ap);
-    actual_normal_dev(mv, verts, face, w, an);
+    // the interpolated normal walks ~100 dependent gathers (3 vertices x their adjacent faces): only when a term uses it,
+    // as node.cpp:811-819 does; smplpp_ik_get_tasks evaluates it on demand for the others
+    if(wn > 0.0f) actual_normal_dev(mv, verts, face, w, an);
     for(int x = 0; x < 3; x++)
     {
       ta.apos[(tb + k) * 3 + x] = ap[x];
-      ta.anrm[(tb + k) * 3 + x] = an[x];
       e_out[(f * K + k) * 4 + x] = (double)(wp * (ap[x] - ta.tpos[(tb + k) * 3 + x])); // node.cpp:807
     }
     if(wn > 0.0f)
@@ -360,21 +356,43 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
   __syncthreads();
   __threadfence_block();
 
-  // ---- phase B: Jacobian rows, tasks in sequence, columns/vertices across the workgroup (node.cpp:823-873)
-  for(int k = 0; k < K; k++)
+  if(dbg_stop == 22) return;
+  // ---- phase B: Jacobian rows (node.cpp:823-873).  Tasks are taken in GROUPS whose ring vertices fit the LDS buffers
+  // together (a position-only task touches 3 vertices, so a 6-target solve is one group; a task with a normal term
+  // touches up to MAXRING and forms a group of its own): each barrier-separated step then serves the whole group, and the
+  // global-memory latencies of the tasks overlap instead of queueing.
+  __shared__ int s_roff[IK_MAXK + 1]; // ring offset of task k inside its group's buffers
+  __shared__ int s_rtask[MAXRING];      // ring slot -> task
+  __shared__ int s_rvert[MAXRING];      // ring slot -> vertex
+  for(int k_lo = 0; k_lo < K;)
   {
-    const int face = ta.face[tb + k];
-    const float off = ta.noff[tb + k], wp = ta.posw[tb + k], wn = ta.nrmw[tb + k], plim = ta.philim[tb + k];
-    const bool use_normal = (off > 0.0f) || (wn > 0.0f);
-    const int32_t * ring = ring_buf + (f * K + k) * (MAXRING + 1);
-    const uint8_t * map = map_buf + (f * K + k) * (3 * MAXADJ * 3);
-    const int nr = ring[0];
-    const float w0 = ta.vw[(tb + k) * 3], w1 = ta.vw[(tb + k) * 3 + 1], w2 = ta.vw[(tb + k) * 3 + 2];
-    double * Jk = J_out + ((f * K + k) * 4) * (int64_t)D;
-
-    if(tid < nr) // B1: per ring vertex rest position, blended rotation, blended w
+    // group [k_lo, k_hi): greedy by ring size (every thread computes the same bounds)
+    int k_hi = k_lo, total = 0;
+    while(k_hi < K)
     {
-      const int v = ring[1 + tid];
+      const int nrk = ring_buf[(f * K + k_hi) * (MAXRING + 1)];
+      // a task with a normal term (ring > 3) keeps the vertex-normal scratch L_VN to itself: a group of its own
+      if(k_hi > k_lo && (total + nrk > MAXRING || nrk > 3 || total > 3 * (k_hi - k_lo))) break;
+      total += nrk;
+      k_hi++;
+    }
+    if((int)tid >= k_lo && (int)tid < k_hi) // ring tables of the group
+    {
+      int off0 = 0;
+      for(int kk = k_lo; kk < (int)tid; kk++) off0 += ring_buf[(f * K + kk) * (MAXRING + 1)];
+      const int32_t * rg = ring_buf + (f * K + tid) * (MAXRING + 1);
+      s_roff[tid] = off0;
+      for(int i = 0; i < rg[0]; i++)
+      {
+        s_rtask[off0 + i] = tid;
+        s_rvert[off0 + i] = rg[1 + i];
+      }
+    }
+    __syncthreads();
+
+    if(tid < total) // B1: per ring vertex rest position, blended rotation, blended w
+    {
+      const int v = s_rvert[tid];
       float * rv = lds + L_RV + tid * 16;
       rv[0] = rest[v * 3];
       rv[1] = rest[v * 3 + 1];
@@ -391,10 +409,10 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       rv[12] = mv.wSum[v];
     }
     __syncthreads();
-    for(int item = tid; item < nr * nq; item += 256) // B2: dp[rv][:, q]  
+    for(int item = tid; item < total * nq; item += 256) // B2: dp[rv][:, q]  
     {
       const int r_ = item / nq, q = item % nq;
-      const int v = ring[1 + r_];
+      const int v = s_rvert[r_];
       const float * rv = lds + L_RV + r_ * 16;
       float acc[3] = {0.f, 0.f, 0.f};
       if(q < 3)
@@ -442,11 +460,18 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       for(int r = 0; r < 3; r++) lds[L_DP + (r_ * 3 + r) * NQ + q] = acc[r] / rv[12];
     }
     __syncthreads();
-    if(tid < nq) // B3: one thread per differentiation column
+    for(int item = tid; item < (k_hi - k_lo) * nq; item += 256) // B3: one (task, differentiation column) per thread
     {
-      const int q = tid;
+      const int k = k_lo + item / nq, q = item % nq;
+      const int face = ta.face[tb + k];
+      const float off = ta.noff[tb + k], wp = ta.posw[tb + k], wn = ta.nrmw[tb + k];
+      const bool use_normal = (off > 0.0f) || (wn > 0.0f);
+      const uint8_t * map = map_buf + (f * K + k) * (3 * MAXADJ * 3);
+      const float w0 = ta.vw[(tb + k) * 3], w1 = ta.vw[(tb + k) * 3 + 1], w2 = ta.vw[(tb + k) * 3 + 2];
+      double * Jk = J_out + ((f * K + k) * 4) * (int64_t)D;
+      const float * dp = lds + L_DP + (s_roff[k] * 3) * NQ; // this task's ring rows
       float dn[3] = {0.f, 0.f, 0.f};
-      if(use_normal) // d actualNormal / dq  
+      if(use_normal) // d actualNormal / dq  (SURVEY.md §9 item 7); such a task is alone in its group (ring offset 0)
       {
         float msum[3] = {0.f, 0.f, 0.f}, dm[3] = {0.f, 0.f, 0.f};
         const float wv[3] = {w0, w1, w2};
@@ -471,9 +496,9 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
             float cr[3];
             cross3(e1, e2, cr);
             const uint8_t * mp = map + (i * MAXADJ + a) * 3;
-            const float * d0 = lds + L_DP + (mp[0] * 3) * NQ + q;
-            const float * d1 = lds + L_DP + (mp[1] * 3) * NQ + q;
-            const float * d2 = lds + L_DP + (mp[2] * 3) * NQ + q;
+            const float * d0 = dp + (mp[0] * 3) * NQ + q;
+            const float * d1 = dp + (mp[1] * 3) * NQ + q;
+            const float * d2 = dp + (mp[2] * 3) * NQ + q;
             const float de1[3] = {d1[0] - d0[0], d1[NQ] - d0[NQ], d1[2 * NQ] - d0[2 * NQ]};
             const float de2[3] = {d2[0] - d0[0], d2[NQ] - d0[NQ], d2[2 * NQ] - d0[2 * NQ]};
             float t1[3], t2[3], dnf[3];
@@ -507,71 +532,92 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       float nd = 0.f;
       for(int x = 0; x < 3; x++)
       {
-        float dpos = (w0 * lds[L_DP + (0 * 3 + x) * NQ + q] + w1 * lds[L_DP + (1 * 3 + x) * NQ + q]) + w2 * lds[L_DP + (2 * 3 + x) * NQ + q];
+        float dpos = (w0 * dp[(0 * 3 + x) * NQ + q] + w1 * dp[(1 * 3 + x) * NQ + q]) + w2 * dp[(2 * 3 + x) * NQ + q];
         if(off > 0.0f) dpos += off * dn[x];
         Jk[(int64_t)x * D + jcol] = (double)(wp * dpos);
         nd += dn[x] * ta.tnrm[(tb + k) * 3 + x];
       }
       Jk[(int64_t)3 * D + jcol] = (wn > 0.0f) ? (double)(wn * nd) : 0.0;
     }
-    // phi columns of every task are zero except this task's own two (node.cpp:792, :834-839)
-    for(int c = tid; c < 2 * K; c += 256)
+    // phi columns of every task are zero except the task's own two (node.cpp:792, :834-839)
+    for(int item = tid; item < (k_hi - k_lo) * 2 * K; item += 256)
+    {
+      const int k = k_lo + item / (2 * K), c = item % (2 * K);
+      const float plim = ta.philim[tb + k];
+      double * Jk = J_out + ((f * K + k) * 4) * (int64_t)D;
       if(c / 2 != k || !(phi_live && plim > 0.0f))
         for(int r = 0; r < 4; r++) Jk[(int64_t)r * D + TD75 + c] = 0.0;
-    if(!optimize_beta)
-    {
-      // nothing: D has no beta columns
     }
     __syncthreads();
-    if(tid < 2 && phi_live && plim > 0.0f) // B4: d/dphi through calcTriangleVertexWeights (vertices detached)
+    if(tid < 2 * (k_hi - k_lo)) // B4: d/dphi through calcTriangleVertexWeights (vertices detached)
     {
-      const int c = tid;
-      float tri[9];
-      for(int i = 0; i < 3; i++)
-        for(int x = 0; x < 3; x++) tri[i * 3 + x] = verts[3 * mv.faces[face * 3 + i] + x];
-      // the point calcVertexWeights was evaluated at (node.cpp:804): pos + tangents . phi with phi == 0
-      float pos[3] = {pos804[(tb + k) * 3], pos804[(tb + k) * 3 + 1], pos804[(tb + k) * 3 + 2]};
-      float d[3][3], a[3], cr[3][3];
-      for(int i = 0; i < 3; i++)
-        for(int x = 0; x < 3; x++) d[i][x] = tri[i * 3 + x] - pos[x];
-      for(int i = 0; i < 3; i++)
+      const int k = k_lo + tid / 2, c = tid % 2;
+      const float plim = ta.philim[tb + k];
+      if(phi_live && plim > 0.0f)
       {
-        cross3(d[(i + 1) % 3], d[(i + 2) % 3], cr[i]);
-        a[i] = sqrtf(cr[i][0] * cr[i][0] + cr[i][1] * cr[i][1] + cr[i][2] * cr[i][2]);
-      }
-      const float asum = (a[0] + a[1]) + a[2];
-      const float nd[3] = {-ta.tang[(tb + k) * 6 + 0 * 2 + c], -ta.tang[(tb + k) * 6 + 1 * 2 + c], -ta.tang[(tb + k) * 6 + 2 * 2 + c]};
-      float da[3], dasum = 0.f, dw[3];
-      for(int i = 0; i < 3; i++)
-      {
-        float t1[3], t2[3];
-        cross3(nd, d[(i + 2) % 3], t1);
-        cross3(d[(i + 1) % 3], nd, t2);
-        da[i] = (a[i] > 0.f) ? (cr[i][0] * (t1[0] + t2[0]) + cr[i][1] * (t1[1] + t2[1]) + cr[i][2] * (t1[2] + t2[2])) / a[i] : 0.f;
-        dasum += da[i];
-      }
-      for(int i = 0; i < 3; i++) dw[i] = (da[i] - (a[i] / asum) * dasum) / asum;
-      float dpos[3] = {0.f, 0.f, 0.f}, dnn[3] = {0.f, 0.f, 0.f};
-      for(int i = 0; i < 3; i++)
-        for(int x = 0; x < 3; x++) dpos[x] += dw[i] * tri[i * 3 + x];
-      if(use_normal)
-      {
-        float dmm[3] = {0.f, 0.f, 0.f};
+        const int face = ta.face[tb + k];
+        const float off = ta.noff[tb + k], wp = ta.posw[tb + k], wn = ta.nrmw[tb + k];
+        const bool use_normal = (off > 0.0f) || (wn > 0.0f);
+        double * Jk = J_out + ((f * K + k) * 4) * (int64_t)D;
+        float tri[9];
         for(int i = 0; i < 3; i++)
-          for(int x = 0; x < 3; x++) dmm[x] += dw[i] * lds[L_VN + i * 3 + x];
-        dnormalize_dev(lds + L_VN + 9, dmm, dnn);
+          for(int x = 0; x < 3; x++) tri[i * 3 + x] = verts[3 * mv.faces[face * 3 + i] + x];
+        // the point calcVertexWeights was evaluated at (node.cpp:804): pos + tangents . phi with phi == 0
+        float pos[3] = {pos804[(tb + k) * 3], pos804[(tb + k) * 3 + 1], pos804[(tb + k) * 3 + 2]};
+        float d[3][3], a[3], cr[3][3];
+        for(int i = 0; i < 3; i++)
+          for(int x = 0; x < 3; x++) d[i][x] = tri[i * 3 + x] - pos[x];
+        for(int i = 0; i < 3; i++)
+        {
+          cross3(d[(i + 1) % 3], d[(i + 2) % 3], cr[i]);
+          a[i] = sqrtf(cr[i][0] * cr[i][0] + cr[i][1] * cr[i][1] + cr[i][2] * cr[i][2]);
+        }
+        const float asum = (a[0] + a[1]) + a[2];
+        const float nd[3] = {-ta.tang[(tb + k) * 6 + 0 * 2 + c], -ta.tang[(tb + k) * 6 + 1 * 2 + c], -ta.tang[(tb + k) * 6 + 2 * 2 + c]};
+        float da[3], dasum = 0.f, dw[3];
+        for(int i = 0; i < 3; i++)
+        {
+          float t1[3], t2[3];
+          cross3(nd, d[(i + 2) % 3], t1);
+          cross3(d[(i + 1) % 3], nd, t2);
+          da[i] = (a[i] > 0.f) ? (cr[i][0] * (t1[0] + t2[0]) + cr[i][1] * (t1[1] + t2[1]) + cr[i][2] * (t1[2] + t2[2])) / a[i] : 0.f;
+          dasum += da[i];
+        }
+        for(int i = 0; i < 3; i++) dw[i] = (da[i] - (a[i] / asum) * dasum) / asum;
+        float dpos[3] = {0.f, 0.f, 0.f}, dnn[3] = {0.f, 0.f, 0.f};
+        for(int i = 0; i < 3; i++)
+          for(int x = 0; x < 3; x++) dpos[x] += dw[i] * tri[i * 3 + x];
+        if(use_normal)
+        {
+          float dmm[3] = {0.f, 0.f, 0.f};
+          for(int i = 0; i < 3; i++)
+            for(int x = 0; x < 3; x++) dmm[x] += dw[i] * lds[L_VN + i * 3 + x];
+          dnormalize_dev(lds + L_VN + 9, dmm, dnn);
+        }
+        float ndot = 0.f;
+        for(int x = 0; x < 3; x++)
+        {
+          if(off > 0.0f) dpos[x] += off * dnn[x];
+          Jk[(int64_t)x * D + TD75 + 2 * k + c] = (double)(wp * dpos[x]);
+          ndot += dnn[x] * ta.tnrm[(tb + k) * 3 + x];
+        }
+        Jk[(int64_t)3 * D + TD75 + 2 * k + c] = (wn > 0.0f) ? (double)(wn * ndot) : 0.0;
       }
-      float ndot = 0.f;
-      for(int x = 0; x < 3; x++)
-      {
-        if(off > 0.0f) dpos[x] += off * dnn[x];
-        Jk[(int64_t)x * D + TD75 + 2 * k + c] = (double)(wp * dpos[x]);
-        ndot += dnn[x] * ta.tnrm[(tb + k) * 3 + x];
-      }
-      Jk[(int64_t)3 * D + TD75 + 2 * k + c] = (wn > 0.0f) ? (double)(wn * ndot) : 0.0;
     }
     __syncthreads();
+    k_lo = k_hi;
   }
+}
+
+__global__ void ik_actual_normals_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all, int K, int64_t nk)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(t >= nk) return;
+  const float * verts = verts_all + (t / K) * mv.V * 3;
+  const float w[3] = {ta.vw[t * 3], ta.vw[t * 3 + 1], ta.vw[t * 3 + 2]};
+  float an[3];
+  actual_normal_dev(mv, verts, ta.face[t], w, an);
+  for(int x = 0; x < 3; x++) ta.anrm[t * 3 + x] = an[x];
 }
 
 // J over the 44-d latent layout from J over theta75 (node.cpp:761-772): columns 0..5 and 69..74 pass through,
@@ -1180,7 +1226,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
 // face in that band passes the cull, whose slack is larger) and writes the new face id and area-ratio weights.  A list
 // that overflows (a far-off hint, e.g. the very first iteration) falls back to the exhaustive block scan.
 constexpr int PROJ_LIST = 256;
-constexpr int PROJ_MAXK = 48;
+constexpr int PROJ_MAXK = IK_MAXK;
 
 __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all,
                                                          const float * __restrict__ pts, int64_t F, int K, int chunks,
@@ -1568,7 +1614,14 @@ extern "C" int smplpp_ik_get_tasks(smplpp_ik * s, int64_t * face_idx, float * ve
   if(vertex_weights) HIP_TRY(hipMemcpy(vertex_weights, s->ta.vw, sizeof(float) * nk * 3, kind));
   if(tangents) HIP_TRY(hipMemcpy(tangents, s->ta.tang, sizeof(float) * nk * 6, kind));
   if(actual_pos) HIP_TRY(hipMemcpy(actual_pos, s->ta.apos, sizeof(float) * nk * 3, kind));
-  if(actual_normal) HIP_TRY(hipMemcpy(actual_normal, s->ta.anrm, sizeof(float) * nk * 3, kind));
+  if(actual_normal)
+  {
+    // IkTask::calcActualNormal() evaluated on demand at the current task state (face, weights) and the last posed mesh
+    ik_actual_normals_kernel<<<dim3((unsigned)((nk + 63) / 64)), 64>>>(view_of(s->m), s->ta, s->verts, (int)s->K, (int64_t)nk);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(actual_normal, s->ta.anrm, sizeof(float) * nk * 3, kind));
+  }
   return SMPLPP_OK;
 }
 
@@ -1597,7 +1650,8 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   }
   ik_eval_kernel<<<dim3((unsigned)n), dim3(256), shmem, st>>>(view_of(m), s->ta, th25, s->verts, s->rest, m->ws.Gp.as<float>(),
                                                               s->joints, s->poserot, K, optimize_beta, phi_live, (int)min_valid,
-                                                              s->ring, s->map, s->pts, s->e, s->J, s->skip);
+                                                              s->ring, s->map, s->pts, s->e, s->J, s->skip,
+                                                              getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0);
   HIP_TRY(hipGetLastError());
   if(s->vp)
   {
