@@ -1304,33 +1304,44 @@ __global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArra
   const float * verts = verts_all + f * mv.V * 3;
   __shared__ int s_face[PROJ_MAXK];
   __shared__ int s_slow[PROJ_MAXK];
-  if((int)threadIdx.x < K)
+  // list minimum + tie rule: 32 lanes per task, eight tasks per pass (one thread per task walked its list with a dependent
+  // global load per entry)
+  for(int k0 = 0; k0 < K; k0 += 8)
   {
-    const int k = threadIdx.x;
-    const int cnt = list_cnt[tb + k];
-    list_cnt[tb + k] = 0; // ready for the next iteration
-    int face = -1;
-    if(cnt >= 1 && cnt <= PROJ_LIST)
-    {
-      const float * ld = list_d + (tb + k) * PROJ_LIST;
-      const int * lf = list_f + (tb + k) * PROJ_LIST;
-      float mn = INFINITY;
-      for(int q = 0; q < cnt; q++) mn = fminf(mn, ld[q]);
-      const float thr = mn * (1.0f + 1e-6f) + 1e-12f;
-      int best = 0x7fffffff;
-      for(int q = 0; q < cnt; q++)
+    const int k = k0 + (int)threadIdx.x / 32, l = (int)threadIdx.x % 32;
+    const bool live = k < K;
+    const int cnt = live ? list_cnt[tb + k] : 0;
+    const bool usable = cnt >= 1 && cnt <= PROJ_LIST;
+    const float * ld = list_d + (tb + (live ? k : 0)) * PROJ_LIST;
+    const int * lf = list_f + (tb + (live ? k : 0)) * PROJ_LIST;
+    float mn = INFINITY;
+    if(usable)
+      for(int q = l; q < cnt; q += 32) mn = fminf(mn, ld[q]);
+    for(int o = 16; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 32));
+    const float thr = mn * (1.0f + 1e-6f) + 1e-12f;
+    int best = 0x7fffffff;
+    if(usable)
+      for(int q = l; q < cnt; q += 32)
         if(ld[q] <= thr && lf[q] < best) best = lf[q];
-      if(best != 0x7fffffff) face = best;
-    }
-    s_face[k] = face;
-    s_slow[k] = (face < 0) ? 1 : 0;
-    if(dbg)
+    for(int o = 16; o > 0; o >>= 1)
     {
-      atomicAdd(&dbg[0], 1);
-      if(cnt == 0) atomicAdd(&dbg[1], 1);
-      if(cnt > PROJ_LIST) atomicAdd(&dbg[2], 1);
-      if(face < 0 && cnt >= 1 && cnt <= PROJ_LIST) atomicAdd(&dbg[3], 1);
-      atomicMax(&dbg[4], cnt);
+      const int other = __shfl_xor(best, o, 32);
+      best = other < best ? other : best;
+    }
+    if(live && l == 0)
+    {
+      const int face = (usable && best != 0x7fffffff) ? best : -1;
+      list_cnt[tb + k] = 0; // ready for the next iteration
+      s_face[k] = face;
+      s_slow[k] = (face < 0) ? 1 : 0;
+      if(dbg)
+      {
+        atomicAdd(&dbg[0], 1);
+        if(cnt == 0) atomicAdd(&dbg[1], 1);
+        if(cnt > PROJ_LIST) atomicAdd(&dbg[2], 1);
+        if(face < 0 && usable) atomicAdd(&dbg[3], 1);
+        atomicMax(&dbg[4], cnt);
+      }
     }
   }
   __syncthreads();
