@@ -1231,7 +1231,7 @@ constexpr int PROJ_MAXK = IK_MAXK;
 __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all,
                                                          const float * __restrict__ pts, int64_t F, int K, int chunks,
                                                          const int * __restrict__ skip, int * __restrict__ list_cnt,
-                                                         float * __restrict__ list_d, int * __restrict__ list_f)
+                                                         float * __restrict__ list_d, int * __restrict__ list_f, int dbg_stop)
 {
   const int64_t f = blockIdx.x / chunks;
   const int chunk = blockIdx.x % chunks;
@@ -1252,12 +1252,14 @@ __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays
     sreach[k] = (d == d) ? sqrtf(d) : INFINITY;
   }
   __syncthreads();
+  if(dbg_stop == 10) return; // (timing experiments only: SMPLPP_IK_DBG_STOP)
   const int64_t per = (F + chunks - 1) / chunks;
   const int64_t f_lo = chunk * per, f_hi = (f_lo + per < F) ? f_lo + per : F;
   for(int64_t base = f_lo + threadIdx.x; base < f_hi; base += (int64_t)blockDim.x * CP_BATCH)
   {
     TriBatch t;
     load_tri_batch(verts, mv.faces, f_hi, base, blockDim.x, t);
+    if(dbg_stop == 11) { if(t.v[0][0] == 12345.678f) list_cnt[0] = 1; continue; }
 #pragma unroll
     for(int b = 0; b < CP_BATCH; b++)
     {
@@ -1279,8 +1281,9 @@ __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays
         const float d0 = (sp[k][0] - g[0]) * (sp[k][0] - g[0]) + (sp[k][1] - g[1]) * (sp[k][1] - g[1]) + (sp[k][2] - g[2]) * (sp[k][2] - g[2]);
         const float reach = (sreach[k] + r) * 1.00001f + 2e-6f;
         if(d0 > reach * reach) continue;
-        float c[3];
-        const float d = tri_sqdist_dev(verts, mv.faces, face, sp[k], c);
+        if(dbg_stop == 12) continue;
+        // survivor: exact distance from the vertices already in registers (the shared, non-inlined evaluation)
+        const float d = tri_sqdist_vals(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], sp[k][0], sp[k][1], sp[k][2]).x;
         const int slot = atomicAdd(&list_cnt[tb + k], 1);
         if(slot < PROJ_LIST)
         {
@@ -1740,7 +1743,8 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
       int chunks = (int)(1536 / s->n);
       chunks = chunks < 1 ? 1 : (chunks > 32 ? 32 : chunks);
       proj_scan_kernel<<<dim3((unsigned)(s->n * chunks)), dim3(256), 0, st>>>(view_of(m), s->ta, s->verts, s->pts, m->F, K, chunks, s->skip,
-                                                                            s->list_cnt, s->list_d, s->list_f);
+                                                                            s->list_cnt, s->list_d, s->list_f,
+                                                                            getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0);
       HIP_TRY(hipGetLastError());
       static int * dbg_buf = nullptr;
       if(dbg && !dbg_buf) HIP_TRY(hipMalloc((void **)&dbg_buf, sizeof(int) * 8));

@@ -139,12 +139,27 @@ __device__ inline void closest_on_triangle_dev(const float * p, const float * a,
 // Results written by thread 0.
 // noinline: both passes below must round identically (two inlined copies may contract FMAs differently, and for a
 // query ON the surface the squared distance is pure rounding noise).
-__device__ __attribute__((noinline)) inline float tri_sqdist_dev(const float * verts, const int32_t * faces, int64_t f,
-                                                                    const float * p, float * c)
+// The ONE copy of the exact point-triangle distance (values in, values out: callers that already hold the triangle in
+// registers do not gather it again).  .x = squared distance, .yzw = closest point.
+__device__ __attribute__((noinline)) inline float4 tri_sqdist_vals(float a0, float a1, float a2, float b0, float b1, float b2, float c0,
+                                                                      float c1, float c2, float p0, float p1, float p2)
 {
-  closest_on_triangle_dev(p, verts + 3 * faces[f * 3], verts + 3 * faces[f * 3 + 1], verts + 3 * faces[f * 3 + 2], c);
+  const float a[3] = {a0, a1, a2}, b[3] = {b0, b1, b2}, cc[3] = {c0, c1, c2}, p[3] = {p0, p1, p2};
+  float c[3];
+  closest_on_triangle_dev(p, a, b, cc, c);
   const float dx = c[0] - p[0], dy = c[1] - p[1], dz = c[2] - p[2];
-  return dx * dx + dy * dy + dz * dz;
+  return make_float4(dx * dx + dy * dy + dz * dz, c[0], c[1], c[2]);
+}
+__device__ inline float tri_sqdist_dev(const float * verts, const int32_t * faces, int64_t f, const float * p, float * c)
+{
+  const float * a = verts + 3 * faces[f * 3];
+  const float * b = verts + 3 * faces[f * 3 + 1];
+  const float * cc = verts + 3 * faces[f * 3 + 2];
+  const float4 r = tri_sqdist_vals(a[0], a[1], a[2], b[0], b[1], b[2], cc[0], cc[1], cc[2], p[0], p[1], p[2]);
+  c[0] = r.y;
+  c[1] = r.z;
+  c[2] = r.w;
+  return r.x;
 }
 
 // Conservative cull: every point of a triangle is at least |p - v0| - max(|v1 - v0|, |v2 - v0|) from p, so the face
