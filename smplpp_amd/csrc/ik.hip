@@ -1275,13 +1275,19 @@ __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays
         const float dx = a[c * 3] - g[0], dy = a[c * 3 + 1] - g[1], dz = a[c * 3 + 2] - g[2];
         r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
       }
-      const float r = sqrtf(r2);
+      const float r = __builtin_amdgcn_sqrtf(r2) * 1.000001f; // hardware sqrt (1 ulp) with its error folded into the slack
+      // branch-free cull over the queries (one divergent branch per face, not per (face, query)), survivors afterwards
+      uint64_t hit = 0;
       for(int k = 0; k < K; k++)
       {
         const float d0 = (sp[k][0] - g[0]) * (sp[k][0] - g[0]) + (sp[k][1] - g[1]) * (sp[k][1] - g[1]) + (sp[k][2] - g[2]) * (sp[k][2] - g[2]);
         const float reach = (sreach[k] + r) * 1.00001f + 2e-6f;
-        if(d0 > reach * reach) continue;
-        if(dbg_stop == 12) continue;
+        hit |= (d0 <= reach * reach) ? (1ull << k) : 0ull;
+      }
+      while(hit)
+      {
+        const int k = __builtin_ctzll(hit);
+        hit &= hit - 1;
         // survivor: exact distance from the vertices already in registers (the shared, non-inlined evaluation)
         const float d = tri_sqdist_vals(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], sp[k][0], sp[k][1], sp[k][2]).x;
         const int slot = atomicAdd(&list_cnt[tb + k], 1);
