@@ -862,6 +862,36 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
     }
   if(dbg_stop == 4) return;
   // factorisation
+  // The holders of a column publish its raw entries (and 1/sqrt of the pivot) to LDS; one barrier later everybody applies
+  // the rank-1 update.  LOOK-AHEAD: right after the barrier of column j the holders of column j + 1 update just that
+  // column and publish it (into the other buffer) BEFORE the rest of their update, so the pivot's extraction, rsqrt and
+  // LDS write leave the critical path: a column costs barrier + LDS read + the widest thread's update.
+  auto publish = [&](const int BJ, int jj_, int j_) { // called by the threads with tx == jj_ ; j_ = 16 * BJ + jj_ (BJ: constant after unrolling)
+    double * lrp = lraw + (j_ & 1) * (16 * NT);
+#pragma unroll
+    for(int a = BJ; a < NT; a++)
+    {
+      const int i = ty + 16 * a;
+      if(i >= j_ && i <= nf)
+      {
+        lrp[i] = acc[a][BJ];
+        if(i == j_)
+        {
+          double d = acc[a][BJ];
+          if(!(d > 0.0))
+          {
+            *bad = 1;
+            d = 1.0;
+          }
+          const double y = fast_rsqrt(d);
+          ldiag[(j_ & 1) * 2] = y;         // 1 / piv
+          ldiag[(j_ & 1) * 2 + 1] = d * y; // piv
+          dinv[j_] = y;
+        }
+      }
+    }
+  };
+  if(tx == 0 && nf > 0) publish(0, 0, 0);
 #pragma unroll
   for(int bj = 0; bj < NT; bj++)
   {
@@ -869,45 +899,10 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
     {
       const int j = 16 * bj + jj;
       if(j >= nf) break; // uniform
-      double * lr = lraw + (j & 1) * (16 * NT);
-      if(tx == jj) // this thread holds column j for rows ty + 16a
-      {
-#pragma unroll
-        for(int a = bj; a < NT; a++)
-        {
-          const int i = ty + 16 * a;
-          if(i >= j && i <= nf)
-          {
-            lr[i] = acc[a][bj];
-            if(i == j) // the pivot's owner also publishes 1/sqrt(d) (computed before the barrier, off everyone else's path)
-            {
-              double d = acc[a][bj];
-              if(!(d > 0.0))
-              {
-                *bad = 1;
-                d = 1.0;
-              }
-              const double y = fast_rsqrt(d);
-              ldiag[(j & 1) * 2] = y;         // 1 / piv
-              ldiag[(j & 1) * 2 + 1] = d * y; // piv
-              dinv[j] = y;
-            }
-          }
-        }
-      }
+      const double * lr = lraw + (j & 1) * (16 * NT);
       __syncthreads();
       const double inv_piv = ldiag[(j & 1) * 2];
       const double inv_d = inv_piv * inv_piv;
-      if(tx == jj)
-      {
-        const double piv = ldiag[(j & 1) * 2 + 1];
-#pragma unroll
-        for(int a = bj; a < NT; a++)
-        {
-          const int i = ty + 16 * a;
-          if(i >= j && i <= nf) M[tri_idx(i, j)] = (i == j) ? piv : acc[a][bj] * inv_piv;
-        }
-      }
       double li[NT], lk[NT];
 #pragma unroll
       for(int a = bj; a < NT; a++)
@@ -917,12 +912,48 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
         li[a] = (i > j && i <= nf) ? ri : 0.0;
         lk[a] = (k > j && k < nf) ? rk * inv_d : 0.0;
       }
+      // look-ahead: column j + 1 first, by its holders, then published
+      if(j + 1 < nf)
+      {
+        if(jj < 15)
+        {
+          if(tx == jj + 1)
+          {
+#pragma unroll
+            for(int a = bj; a < NT; a++) acc[a][bj] -= li[a] * lk[bj];
+            lk[bj] = 0.0; // done for this thread
+            publish(bj, jj + 1, j + 1);
+          }
+        }
+        else if(bj + 1 < NT)
+        {
+          if(tx == 0)
+          {
+            const int bn = bj + 1 < NT ? bj + 1 : NT - 1; // (the clamp only keeps the unrolled index in range)
+#pragma unroll
+            for(int a = bn; a < NT; a++) acc[a][bn] -= li[a] * lk[bn];
+            lk[bn] = 0.0;
+            publish(bn, 0, j + 1);
+          }
+        }
+      }
 #pragma unroll
       for(int a = bj; a < NT; a++)
 #pragma unroll
         for(int b = bj; b <= a; b++) acc[a][b] -= li[a] * lk[b];
     }
   }
+  __syncthreads();
+  // the scaled factor for the back substitution, once: a column's raw entries are final as soon as it has been published
+  // (later updates only touch columns to its right), and L_ik = raw_ik / piv_k, piv_k = d_k / sqrt(d_k) = raw_kk * dinv_k
+#pragma unroll
+  for(int a = 0; a < NT; a++)
+#pragma unroll
+    for(int b = 0; b <= a; b++)
+    {
+      const int i = ty + 16 * a, k = tx + 16 * b;
+      if(k < nf && i >= k && i <= nf) M[tri_idx(i, k)] = acc[a][b] * dinv[k];
+    }
   __syncthreads();
 }
 
