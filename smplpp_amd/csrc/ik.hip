@@ -891,6 +891,11 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
       }
     }
   };
+  bool kcol[NT]; // tx + 16 a is a column of the system (not the rhs row, not padding)
+#pragma unroll
+  for(int a = 0; a < NT; a++) kcol[a] = tx + 16 * a < nf;
+  for(int q = tid; q < 2 * 16 * NT; q += 256) lraw[q] = 0.0;
+  __syncthreads();
   if(tx == 0 && nf > 0) publish(0, 0, 0);
 #pragma unroll
   for(int bj = 0; bj < NT; bj++)
@@ -903,14 +908,16 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
       __syncthreads();
       const double inv_piv = ldiag[(j & 1) * 2];
       const double inv_d = inv_piv * inv_piv;
+      // lraw was zeroed and rows beyond nf are never published, so only the diagonal block (a == bj) needs the "below the
+      // pivot" test; the rhs row (k == nf) is masked by a per-thread constant
       double li[NT], lk[NT];
 #pragma unroll
       for(int a = bj; a < NT; a++)
       {
-        const int i = ty + 16 * a, k = tx + 16 * a; // < 16 NT: inside lraw, loads are unconditional (stale entries are masked)
-        const double ri = lr[i], rk = lr[k];
-        li[a] = (i > j && i <= nf) ? ri : 0.0;
-        lk[a] = (k > j && k < nf) ? rk * inv_d : 0.0;
+        const int i = ty + 16 * a, k = tx + 16 * a;
+        const double ri = lr[i], rk = lr[k] * inv_d;
+        li[a] = (a > bj || i > j) ? ri : 0.0;
+        lk[a] = (kcol[a] && (a > bj || k > j)) ? rk : 0.0;
       }
       // look-ahead: column j + 1 first, by its holders, then published
       if(j + 1 < nf)
