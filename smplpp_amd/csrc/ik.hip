@@ -811,7 +811,9 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
                                             int chunk_rows, double * lraw /*[2][16*NT]*/, double * ldiag /*[4]*/, double * dinv /*[nf]*/, int * bad,
                                             int dbg_stop = 0)
 {
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  // thread (ty, tx): tx in the HIGH bits, so the 16 holders of a column (one tx, all ty) sit in one wavefront and the other
+  // three skip the publish path (extraction, rsqrt, LDS writes) instead of executing it for four lanes each
+  const int tid = threadIdx.x, tx = tid >> 4, ty = tid & 15;
   double acc[NT][NT];
   int colI[NT], colK[NT];
 #pragma unroll
