@@ -424,11 +424,11 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
   // SMPLPP_SKIN = b | p | q | v1 selects the form of the fused kernel for A/B runs.  Default b (skin_b.hip): bf16x3
   // operand pieces on the bf16 matrix pipe, fp32-exact; p (skin_p.hip): fp32 MFMA, one wavefront per SIMD, persistent,
   // skinning rows issued in MFMA shadows; q (skin_q.hip, staggered work queue) and v1 (skin_kernel above) are kept for
-  // comparison.  Forms with 32-bit output offsets fall back to v1 for outputs of 2 GiB and more.
+  // comparison.  p (32-bit output offsets) falls back to v1 for outputs of 2 GiB and more; b splits such batches itself.
   const char * form_env = getenv("SMPLPP_SKIN"); // read per call: the parity tests switch forms inside one process
   char form = form_env ? form_env[0] : 'b';
   if(m->maxw > 8) form = 'v';
-  if((form == 'b' || form == 'p') && n * m->V * 12 >= 0x7fffff00LL) form = 'v';
+  if(form == 'p' && n * m->V * 12 >= 0x7fffff00LL) form = 'v'; // (b splits such batches into launches of <= 2 GiB itself)
   const int64_t n64 = ((n + 63) / 64) * 64;
   HIP_TRY(ws.Gp.reserve(sizeof(float) * (size_t)n64 * NJ * 12)); // b / p stage whole frame tiles of G' (padding never stored)
   if(form == 'b')

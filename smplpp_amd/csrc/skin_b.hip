@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
 }
 
 template<int MAXW, bool WANT_REST>
-static hipError_t launch_b(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st)
+static hipError_t launch_b(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st, int64_t f_off)
 {
   const int nftp = (int)((n + 63) / 64);
   const int nvgp = (int)m->VGPn;
@@ -559,16 +559,32 @@ static hipError_t launch_b(const smplpp_model * m, int64_t n, const float * thet
     if(e != hipSuccess) return e;
     attr_set = true;
   }
-  skin_kernel_b<MAXW, WANT_REST><<<dim3(blocks), dim3(256), B_LDS_TOTAL, st>>>(m->ws.A3.as<uint8_t>(), m->B3, m->ws.Gp.as<float>(), theta, m->wIdx,
-                                                                             m->wVal, m->wSum, verts, rest, n, m->V, nvgp, nftp, ipb);
+  // f_off (a multiple of 64): first frame of this launch inside the workspace / caller arrays of a longer batch
+  skin_kernel_b<MAXW, WANT_REST><<<dim3(blocks), dim3(256), B_LDS_TOTAL, st>>>(
+      m->ws.A3.as<uint8_t>() + (f_off / 64) * (int64_t)(BB_KS * BB_A_BYTES), m->B3, m->ws.Gp.as<float>() + f_off * (NJ * 12),
+      theta + f_off * ((NJ + 1) * 3), m->wIdx, m->wVal, m->wSum, verts ? verts + f_off * m->V * 3 : nullptr,
+      rest ? rest + f_off * m->V * 3 : nullptr, n, m->V, nvgp, nftp, ipb);
   return hipGetLastError();
 }
 
 // Gp must hold whole 64-frame tiles (padding content is irrelevant: the rows it feeds are never stored)
 hipError_t launch_skin_bf16x3(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st)
 {
-  if(m->maxw == 4) return rest ? launch_b<4, true>(m, n, theta, verts, rest, st) : launch_b<4, false>(m, n, theta, verts, rest, st);
-  if(m->maxw == 8) return rest ? launch_b<8, true>(m, n, theta, verts, rest, st) : launch_b<8, false>(m, n, theta, verts, rest, st);
-  return hipErrorInvalidValue; // dense weights keep the first form
+  // the kernel addresses its outputs with 32-bit buffer offsets: longer batches go in launches of <= 2 GiB of vertices
+  int64_t per = (0x7fffff00LL / (m->V * 12)) & ~63LL;
+  if(per < 64) return hipErrorInvalidValue;
+  for(int64_t off = 0; off < n; off += per)
+  {
+    const int64_t nn = (n - off < per) ? n - off : per;
+    hipError_t e;
+    if(m->maxw == 4)
+      e = rest ? launch_b<4, true>(m, nn, theta, verts, rest, st, off) : launch_b<4, false>(m, nn, theta, verts, rest, st, off);
+    else if(m->maxw == 8)
+      e = rest ? launch_b<8, true>(m, nn, theta, verts, rest, st, off) : launch_b<8, false>(m, nn, theta, verts, rest, st, off);
+    else
+      return hipErrorInvalidValue; // dense weights keep the first form
+    if(e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 } // namespace smplpp_hip

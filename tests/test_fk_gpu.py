@@ -137,6 +137,27 @@ def test_fk_eight_weights_per_vertex(synth_model, form, monkeypatch):
             assert np.abs(g[k] - r[k]).max() < VERT_TOL, (form, n, k)
 
 
+def test_fk_outputs_beyond_2gib(smpl, oracle_synth):
+    """The default fused kernels address their outputs with 32-bit buffer offsets; a batch whose vertex array reaches
+    2 GiB (26 100 frames) is split into launches of at most 2 GiB (fp32-MFMA form: falls back to 64-bit addressing) and must still be right (device buffers: no 2 GiB host copy)."""
+    import torch
+    from smplpp_amd import model_io
+
+    n = 26100
+    beta, theta = model_io.synthetic_inputs(512, seed=9)
+    reps = (n + 511) // 512
+    bt = torch.from_numpy(np.tile(beta, (reps, 1))[:n].copy()).cuda()
+    tt = torch.from_numpy(np.tile(theta, (reps, 1, 1))[:n].copy()).cuda()
+    o = smpl.launch(bt, tt, want=("verts",))["verts"]
+    torch.cuda.synchronize()
+    assert o.shape == (n, 6890, 3) and o.numel() * 4 >= 2**31
+    sel = np.array([0, 511, 12345, 25599, n - 1])
+    r = oracle_synth.fk(beta[sel % 512], theta[sel % 512], want=("verts",))["verts"]
+    assert np.abs(o[torch.from_numpy(sel).cuda()].cpu().numpy() - r).max() < VERT_TOL
+    del o, bt, tt
+    torch.cuda.empty_cache()
+
+
 def test_fk_device_pointers_torch(smpl, oracle_synth):
     import torch
     from smplpp_amd import model_io
