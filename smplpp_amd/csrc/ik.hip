@@ -815,43 +815,87 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
   // three skip the publish path (extraction, rsqrt, LDS writes) instead of executing it for four lanes each
   const int tid = threadIdx.x, tx = tid >> 4, ty = tid & 15;
   double acc[NT][NT];
-  int colI[NT], colK[NT];
-#pragma unroll
-  for(int a = 0; a < NT; a++)
+  // A_FF = J_F^T J_F and the rhs row J_F^T rowv (the Gram of the augmented operand [J_F | rowv]) on the fp64 matrix pipe:
+  // v_mfma_f64_16x16x4_f64, one 16 x 16 tile of the lower triangle per accumulator, the wavefronts take tiles round-robin,
+  // the rows of J (staged in LDS in chunks) are the k dimension, four per MFMA.  Lane l feeds A[i = l % 16][k = l / 16] and
+  // B[k = l / 16][j = l % 16] and receives D[4 r + l / 16][l % 16] in register r (probed: tools/micro/mfma_f64_layout.hip).
+  // The tiles go through the packed LDS matrix M into the register layout of the factorisation below.
   {
-    const int i = ty + 16 * a, k = tx + 16 * a;
-    colI[a] = (i < nf) ? idx[i] : (i == nf ? -1 : -2); // -1: the rhs row, -2: outside
-    colK[a] = (k < nf) ? idx[k] : -2;
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    constexpr int NTILE = NT * (NT + 1) / 2, TPW = (NTILE + 3) / 4;
+    const int wave = tid >> 6, l = tid & 63, l16 = l & 15, lq = l >> 4;
+    d4 tacc[TPW];
+    int colA[TPW], colB[TPW]; // column of J (>= 0), -1 the rhs entry, -2 nothing, of this lane's A / B operand element
+    bool live[TPW];
 #pragma unroll
-    for(int b = 0; b < NT; b++) acc[a][b] = 0.0;
-  }
-  // A_FF = J_F^T J_F and the rhs row J_F^T rowv, accumulated over row chunks of J staged in LDS
-  for(int c0 = 0; c0 < rows; c0 += chunk_rows)
-  {
-    const int cr = (rows - c0 < chunk_rows) ? rows - c0 : chunk_rows;
-    __syncthreads();
-    stage_rows(Jc, J + (int64_t)c0 * D, cr * D);
-    __syncthreads();
-    // branch-free: every lane loads (a clamped column, the rhs entry) unconditionally and selects afterwards, so the twelve
-    // LDS reads of a row issue back to back and the rows pipeline (conditional loads cost a branch + a full LDS round trip each)
-#pragma unroll 4
-    for(int r = 0; r < cr; r++)
+    for(int u = 0; u < TPW; u++)
     {
-      double vi[NT], vk[NT];
-      const double rv = rowv[c0 + r];
-#pragma unroll
-      for(int a = 0; a < NT; a++)
+      const int t = wave + 4 * u;
+      int ta = 0, tb = t; // tile t of the row-major lower triangle: (ta, tb), tb <= ta
+      while(tb > ta)
       {
-        const double ji = Jc[r * D + (colI[a] >= 0 ? colI[a] : 0)];
-        const double jk = Jc[r * D + (colK[a] >= 0 ? colK[a] : 0)];
-        vi[a] = (colI[a] >= 0) ? ji : (colI[a] == -1 ? rv : 0.0);
-        vk[a] = (colK[a] >= 0) ? jk : 0.0;
+        tb -= ta + 1;
+        ta++;
       }
-#pragma unroll
-      for(int a = 0; a < NT; a++)
-#pragma unroll
-        for(int b = 0; b <= a; b++) acc[a][b] += vi[a] * vk[b];
+      live[u] = t < NTILE && 16 * ta <= nf && 16 * tb < nf; // (wave-uniform)
+      const int mi = 16 * ta + l16, mk = 16 * tb + l16;
+      colA[u] = (mi < nf) ? idx[mi] : (mi == nf ? -1 : -2);
+      colB[u] = (mk < nf) ? idx[mk] : -2;
+      tacc[u] = d4{0.0, 0.0, 0.0, 0.0};
     }
+    for(int c0 = 0; c0 < rows; c0 += chunk_rows)
+    {
+      const int cr = (rows - c0 < chunk_rows) ? rows - c0 : chunk_rows;
+      __syncthreads();
+      stage_rows(Jc, J + (int64_t)c0 * D, cr * D);
+      __syncthreads();
+      for(int r0 = 0; r0 < cr; r0 += 4)
+      {
+        const int r = r0 + lq;
+        const bool rin = r < cr;
+        const double rv = rowv[c0 + (rin ? r : 0)];
+        const double * Jr = Jc + (rin ? r : 0) * D;
+#pragma unroll
+        for(int u = 0; u < TPW; u++)
+        {
+          if(!live[u]) continue;
+          const double ja = Jr[colA[u] >= 0 ? colA[u] : 0], jb = Jr[colB[u] >= 0 ? colB[u] : 0];
+          const double va = !rin ? 0.0 : (colA[u] >= 0 ? ja : (colA[u] == -1 ? rv : 0.0));
+          const double vb = (rin && colB[u] >= 0) ? jb : 0.0;
+          tacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, tacc[u], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for(int u = 0; u < TPW; u++)
+    {
+      if(!live[u]) continue;
+      const int t = wave + 4 * u;
+      int ta = 0, q = t;
+      while(q > ta)
+      {
+        q -= ta + 1;
+        ta++;
+      }
+      const int tb = q;
+#pragma unroll
+      for(int rr = 0; rr < 4; rr++)
+      {
+        const int i = 16 * ta + 4 * rr + lq, k = 16 * tb + l16;
+        if(i >= k && i <= nf && k < nf) M[tri_idx(i, k)] = tacc[u][rr];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for(int a2 = 0; a2 < NT; a2++)
+#pragma unroll
+      for(int b2 = 0; b2 <= a2; b2++)
+      {
+        const int i = ty + 16 * a2, k = tx + 16 * b2;
+        acc[a2][b2] = (i >= k && i <= nf && k < nf) ? M[tri_idx(i, k)] : 0.0;
+      }
+    __syncthreads(); // M is rewritten by the factorisation
   }
 #pragma unroll
   for(int a = 0; a < NT; a++)
