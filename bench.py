@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--ik-iters", type=int, default=50)
     ap.add_argument("--no-ik", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[3] (mocap excerpt) and configs[4] (VPoser-latent IK) legs")
+    ap.add_argument("--mocap-restarts", type=int, default=8, help="restarts per GPU of the capture excerpt (BASELINE: 64 over 8 GPUs)")
+    ap.add_argument("--vposer-frames", type=int, default=128, help="frames per GPU of the VPoser-latent IK leg (BASELINE: 512 over 4 GPUs)")
     ap.add_argument("--gather", action="store_true", help="also time one final RCCL gather of all vertices to rank 0")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
@@ -203,6 +206,71 @@ def main():
             "final_max_e_sqnorm": float(np.max(e2)), "workload": "configs[2]: 6-target IK, 50 iterations, direct theta (D = 87)",
         }
 
+    # ---- configs[3]: the capture excerpt (tests/golden/sample_walk_excerpt.npz: 32 frames x 41 Baseline markers of
+    # data/sample_walk.c3d), R warm-started chains per GPU, marker-thickness normal offsets, QP on, 31 warm-up iterations
+    # on frame 0 then one iteration per frame (node.cpp:1369-1407); configs[4]: VPoser-latent IK (44-d layout, synthetic
+    # decoder: the real weights cannot travel), 6 targets, 50 iterations
+    mocap_leg = vposer_leg = None
+    if not args.no_ik and not args.no_extra:
+        from smplpp_amd import mocap
+        from smplpp_amd.ik import VPoserDecoder
+
+        g = np.load(os.path.join(ROOT, "tests", "golden", "sample_walk_excerpt.npz"))
+        names = list(g["task_names"])
+        mfaces = np.array([mocap.BASELINE41[nm] for nm in names], np.int64)
+        Km = len(names)
+        pts = g["points"] - g["points"][0][g["valid"][0]].mean(axis=0) + np.array([0, -0.3, 0], np.float32)
+        R = args.mocap_restarts
+        rng = np.random.default_rng(200 + rank)
+        th0 = np.zeros((R, 25, 3), np.float32)
+        th0[:, 1:] = rng.normal(0, 0.03, (R, 24, 3))  # the restarts differ in their initial pose
+        ms = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R)
+        ms.solve(pts, g["valid"], np.zeros(10, np.float32), th0, max_frames=2)  # warm-up of the code path
+        torch.cuda.synchronize()
+        D.barrier()
+        t1 = time.perf_counter()
+        thm, fr = ms.solve(pts, g["valid"], np.zeros(10, np.float32), th0)
+        torch.cuda.synchronize()
+        D.barrier()
+        mt = D.max_over_ranks(time.perf_counter() - t1)
+        iters = mocap.MocapMotionSolver.WARMUP_ITERS + len(fr) - 1
+        mocap_leg = {
+            "value": world * R * len(fr) / mt, "unit": "solved capture frames/s", "ik_iterations_per_s": world * R * iters / mt,
+            "restarts_per_gpu": R, "frames": len(fr), "markers": Km, "finite": bool(np.isfinite(thm).all()),
+            "workload": "configs[3]: sample_walk.c3d excerpt (32 frames x 41 markers), warm-started chains, box QP, direct theta (D = 157); "
+                        "host-driven per-frame loop (targets set from the host each frame)",
+        }
+
+        Kv = 6
+        nv = args.vposer_frames
+        vp = VPoserDecoder(VPoserDecoder.synthetic_params(seed=3), device=local)
+        _, vfaces = reference_task_faces(Kv)
+        hidv = np.zeros((nv, 25, 3), np.float32)
+        hidv[:, 1:22] = rng.normal(0, 0.15, (nv, 21, 3))
+        hvv = smpl.launch(np.zeros((nv, 10), np.float32), hidv, want=("verts",))["verts"]
+        tpv = hvv[:, model["face_indices"][vfaces] - 1].mean(axis=2)
+        vs = IkSolver(smpl, nv, Kv, vposer=vp)
+        vs.setTasks(face_idx=vfaces, target_pos=tpv, phi_limit=np.zeros(Kv), normal_task_weight=np.zeros(Kv))
+        g0 = np.zeros((nv, vs.theta_dim), np.float32)
+        vt = 0.0
+        for rep in range(3):
+            vs.setTasks(face_idx=vfaces, vertex_weights=np.full((Kv, 3), 1 / 3, np.float32))
+            vs.setConfig(np.zeros((nv, 10), np.float32), g0)
+            torch.cuda.synchronize()
+            D.barrier()
+            t1 = time.perf_counter()
+            ev = vs.iterate(args.ik_iters)
+            torch.cuda.synchronize()
+            D.barrier()
+            if rep > 0:
+                vt += time.perf_counter() - t1
+        vt = D.max_over_ranks(vt / 2)
+        vposer_leg = {
+            "value": world * nv * args.ik_iters / vt, "unit": "IK iterations/s", "frames_per_gpu": nv, "iters": args.ik_iters, "tasks": Kv,
+            "ms_per_iter_batch": vt / args.ik_iters * 1e3, "final_max_e_sqnorm": float(np.max(ev)),
+            "workload": "configs[4]: VPoser-latent IK (32-d latent + decoder in the loop, 44-d layout, D = 56), synthetic decoder weights",
+        }
+
     gather_ms = None
     if args.gather and world > 1:
         torch.cuda.synchronize()
@@ -282,6 +350,10 @@ def main():
     }
     if ik is not None:
         line["ik"] = ik
+    if mocap_leg is not None:
+        line["mocap"] = mocap_leg
+    if vposer_leg is not None:
+        line["vposer_ik"] = vposer_leg
     if gather_ms is not None:
         line["final_gather_ms"] = gather_ms
     if world == 1 and not args.no_cpu_baseline:

@@ -163,17 +163,23 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
                                                       int phi_live, int min_valid, int32_t * __restrict__ ring_buf,
                                                       uint8_t * __restrict__ map_buf, float * __restrict__ pos804,
                                                       double * __restrict__ e_out, double * __restrict__ J_out,
-                                                      int * __restrict__ skip, int dbg_stop)
+                                                      int * __restrict__ skip, int dbg_stop, int tsplit)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int * sAnc = reinterpret_cast<int *>(lds + L_END);
-  const int64_t f = blockIdx.x;
+  // grid = n * tsplit: when frames are fewer than CUs (mocap chains: 8 per GPU x 41 markers) a frame's tasks are split over
+  // tsplit workgroups, each rebuilding the frame's derivative tables (4 us) for its contiguous share of the tasks
+  const int64_t f = blockIdx.x / tsplit;
+  const int part = (int)(blockIdx.x % tsplit);
+
   const int tid = threadIdx.x;
   const int nq = TD75 + (optimize_beta ? NB : 0);
   const int D = TD75 + 2 * K + (optimize_beta ? NB : 0);
   const float * verts = verts_all + f * mv.V * 3;
   const float * rest = rest_all + f * mv.V * 3;
   const int64_t tb = f * K; // task base
+  const int per_part = (K + tsplit - 1) / tsplit;
+  const int k_begin = part * per_part, k_end = (k_begin + per_part < K) ? k_begin + per_part : K;
 
   // node.cpp:785 — a frame with too few valid markers skips the whole solve block (no task refresh either)
   {
@@ -277,9 +283,9 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
 
   if(dbg_stop == 21) return;
   // ---- phase A: one thread per task — tangents, weight refresh, residual rows, ring list (node.cpp:803-820)
-  if(tid < K)
+  if(k_begin + tid < k_end)
   {
-    const int k = tid;
+    const int k = k_begin + tid;
     const int face = ta.face[tb + k];
     float tri[9];
     for(int i = 0; i < 3; i++)
@@ -364,11 +370,11 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
   __shared__ int s_roff[IK_MAXK + 1]; // ring offset of task k inside its group's buffers
   __shared__ int s_rtask[MAXRING];      // ring slot -> task
   __shared__ int s_rvert[MAXRING];      // ring slot -> vertex
-  for(int k_lo = 0; k_lo < K;)
+  for(int k_lo = k_begin; k_lo < k_end;)
   {
     // group [k_lo, k_hi): greedy by ring size (every thread computes the same bounds)
     int k_hi = k_lo, total = 0;
-    while(k_hi < K)
+    while(k_hi < k_end)
     {
       const int nrk = ring_buf[(f * K + k_hi) * (MAXRING + 1)];
       // a task with a normal term (ring > 3) keeps the vertex-normal scratch L_VN to itself: a group of its own
@@ -1389,9 +1395,13 @@ __global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArra
                                                            const float * __restrict__ pts, int64_t F, int K,
                                                            const int * __restrict__ skip, int * __restrict__ list_cnt,
                                                            const float * __restrict__ list_d, const int * __restrict__ list_f,
-                                                           int * __restrict__ dbg)
+                                                           int * __restrict__ dbg, int tsplit)
 {
-  const int64_t f = blockIdx.x;
+  // grid = n * tsplit: with few frames per GPU a frame's tasks are shared out (see ik_eval_kernel); the exhaustive fallback
+  // below is sequential over a workgroup's tasks
+  const int64_t f = blockIdx.x / tsplit;
+  const int part = (int)(blockIdx.x % tsplit), per_part = (K + tsplit - 1) / tsplit;
+  const int k_begin = part * per_part, k_end = (k_begin + per_part < K) ? k_begin + per_part : K;
   const int64_t tb = f * K;
   if(skip[f]) return;
   const float * verts = verts_all + f * mv.V * 3;
@@ -1399,10 +1409,10 @@ __global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArra
   __shared__ int s_slow[PROJ_MAXK];
   // list minimum + tie rule: 32 lanes per task, eight tasks per pass (one thread per task walked its list with a dependent
   // global load per entry)
-  for(int k0 = 0; k0 < K; k0 += 8)
+  for(int k0 = k_begin; k0 < k_end; k0 += 8)
   {
     const int k = k0 + (int)threadIdx.x / 32, l = (int)threadIdx.x % 32;
-    const bool live = k < K;
+    const bool live = k < k_end;
     const int cnt = live ? list_cnt[tb + k] : 0;
     const bool usable = cnt >= 1 && cnt <= PROJ_LIST;
     const float * ld = list_d + (tb + (live ? k : 0)) * PROJ_LIST;
@@ -1438,7 +1448,7 @@ __global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArra
     }
   }
   __syncthreads();
-  for(int k = 0; k < K; k++) // rare: exhaustive scan for the tasks whose list overflowed (or was empty / NaN)
+  for(int k = k_begin; k < k_end; k++) // rare: exhaustive scan for the tasks whose list overflowed (or was empty / NaN)
   {
     if(!s_slow[k]) continue; // uniform across the workgroup
     __shared__ int64_t s_f64;
@@ -1446,9 +1456,9 @@ __global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArra
     if(threadIdx.x == 0) s_face[k] = (int)s_f64;
     __syncthreads();
   }
-  if((int)threadIdx.x < K)
+  if(k_begin + (int)threadIdx.x < k_end)
   {
-    const int k = threadIdx.x;
+    const int k = k_begin + threadIdx.x;
     const int face = s_face[k];
     float tri[9], w[3], c[3];
     for(int i = 0; i < 3; i++)
@@ -1752,10 +1762,13 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ik_eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     attr = true;
   }
-  ik_eval_kernel<<<dim3((unsigned)n), dim3(256), shmem, st>>>(view_of(m), s->ta, th25, s->verts, s->rest, m->ws.Gp.as<float>(),
-                                                              s->joints, s->poserot, K, optimize_beta, phi_live, (int)min_valid,
-                                                              s->ring, s->map, s->pts, s->e, s->J, s->skip,
-                                                              getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0);
+  int tsplit = (n < 256) ? (int)(256 / n) : 1; // one round of workgroups (one per CU: 83 KB of LDS each)
+  if(tsplit > K) tsplit = K;
+  if(tsplit < 1) tsplit = 1;
+  ik_eval_kernel<<<dim3((unsigned)(n * tsplit)), dim3(256), shmem, st>>>(view_of(m), s->ta, th25, s->verts, s->rest, m->ws.Gp.as<float>(),
+                                                                       s->joints, s->poserot, K, optimize_beta, phi_live, (int)min_valid,
+                                                                       s->ring, s->map, s->pts, s->e, s->J, s->skip,
+                                                                       getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0, tsplit);
   HIP_TRY(hipGetLastError());
   if(s->vp)
   {
@@ -1839,8 +1852,11 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
       static int * dbg_buf = nullptr;
       if(dbg && !dbg_buf) HIP_TRY(hipMalloc((void **)&dbg_buf, sizeof(int) * 8));
       if(dbg) HIP_TRY(hipMemsetAsync(dbg_buf, 0, sizeof(int) * 8, st));
-      proj_finish_kernel<<<dim3((unsigned)s->n), dim3(256), 0, st>>>(view_of(m), s->ta, s->verts, s->pts, m->F, K, s->skip, s->list_cnt,
-                                                                   s->list_d, s->list_f, dbg ? dbg_buf : nullptr);
+      int fsplit = (s->n < 256) ? (int)(256 / s->n) : 1;
+      if(fsplit > K) fsplit = K;
+      if(fsplit < 1) fsplit = 1;
+      proj_finish_kernel<<<dim3((unsigned)(s->n * fsplit)), dim3(256), 0, st>>>(view_of(m), s->ta, s->verts, s->pts, m->F, K, s->skip, s->list_cnt,
+                                                                              s->list_d, s->list_f, dbg ? dbg_buf : nullptr, fsplit);
       HIP_TRY(hipGetLastError());
       if(dbg)
       {
