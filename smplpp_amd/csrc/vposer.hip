@@ -197,7 +197,11 @@ __device__ inline void sixd_to_aa(const float * o6, float * aa_out, float * jac3
   }
 }
 
-// grid = n frames, block = 256.  LDS: a1/D1 then a2/D2 ([512][33] floats each, column 32 = activation).
+// grid = n frames, block = 256.  LDS: a1/D1 then a2/D2, [512][VS] floats each (33 used: 32 tangent columns + the
+// activation in column 32; the stride VS = 36 keeps every row 16-byte aligned so a row is read with nine ds_read_b128 —
+// every lane reads the same row (broadcast), and 33 scalar LDS reads per k made the LDS issue slots the bottleneck);
+// the layer-2 output [126][33] reuses the a1/D1 region.
+constexpr int VS = 36;
 __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ z, int64_t z_stride, const float * __restrict__ w0t,
                                                      const float * __restrict__ b0, const float * __restrict__ w1t,
                                                      const float * __restrict__ b1, const float * __restrict__ w2t,
@@ -205,10 +209,10 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
                                                      float * __restrict__ jac, int want_jac)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float * L1 = lds;                  // [512][33]
-  float * L2 = lds + HID * 33;       // [512][33]
-  float * sz = L2 + HID * 33;        // [32]
-  float * so = sz + LAT;             // [126][33]
+  float * L1 = lds;                  // [512][VS]
+  float * L2 = lds + HID * VS;       // [512][VS]
+  float * sz = L2 + HID * VS;        // [32]
+  float * so = L1;                   // [126][33]  (a1/D1 is dead once layer 1 is done)
   const int64_t f = blockIdx.x;
   const int tid = threadIdx.x;
   if(tid < LAT) sz[tid] = z[f * z_stride + tid];
@@ -219,8 +223,8 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
     float h = b0[row];
     for(int c = 0; c < LAT; c++) h += w0t[c * HID + row] * sz[c];
     const float slope = (h > 0.0f) ? 1.0f : 0.01f;
-    L1[row * 33 + 32] = h * slope;
-    for(int c = 0; c < LAT; c++) L1[row * 33 + c] = slope * w0t[c * HID + row];
+    L1[row * VS + 32] = h * slope;
+    for(int c = 0; c < LAT; c++) L1[row * VS + c] = slope * w0t[c * HID + row];
   }
   __syncthreads();
   // layer 1 (+ LeakyReLU): value and 32 tangents per row
@@ -228,33 +232,64 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
     float acc0[33], acc1[33];
     for(int c = 0; c < 33; c++) acc0[c] = acc1[c] = 0.f;
     const int r0 = tid, r1 = tid + 256;
-    for(int k = 0; k < HID; k++)
-    {
-      const float wa = w1t[k * HID + r0], wb = w1t[k * HID + r1];
-      const float * d = L1 + k * 33;
-      if(want_jac)
-      {
+    // weights stream from L2 eight k ahead (a load per k in the loop body pays the L2 latency 512 times)
+    constexpr int KU = 8;
+    float wa[KU], wb[KU], wan[KU], wbn[KU];
 #pragma unroll
-        for(int c = 0; c < 33; c++)
-        {
-          acc0[c] += wa * d[c];
-          acc1[c] += wb * d[c];
-        }
-      }
-      else
+    for(int u = 0; u < KU; u++)
+    {
+      wa[u] = w1t[u * HID + r0];
+      wb[u] = w1t[u * HID + r1];
+    }
+    for(int k0 = 0; k0 < HID; k0 += KU)
+    {
+      const int kn = (k0 + KU < HID) ? k0 + KU : k0; // (the last block re-reads itself: harmless)
+#pragma unroll
+      for(int u = 0; u < KU; u++)
       {
-        acc0[32] += wa * d[32];
-        acc1[32] += wb * d[32];
+        wan[u] = w1t[(kn + u) * HID + r0];
+        wbn[u] = w1t[(kn + u) * HID + r1];
+      }
+#pragma unroll
+      for(int u = 0; u < KU; u++)
+      {
+        const int k = k0 + u;
+        const float4 * d4 = reinterpret_cast<const float4 *>(L1 + k * VS);
+        if(want_jac)
+        {
+#pragma unroll
+          for(int c4 = 0; c4 < 8; c4++)
+          {
+            const float4 d = d4[c4];
+            acc0[4 * c4 + 0] += wa[u] * d.x;
+            acc0[4 * c4 + 1] += wa[u] * d.y;
+            acc0[4 * c4 + 2] += wa[u] * d.z;
+            acc0[4 * c4 + 3] += wa[u] * d.w;
+            acc1[4 * c4 + 0] += wb[u] * d.x;
+            acc1[4 * c4 + 1] += wb[u] * d.y;
+            acc1[4 * c4 + 2] += wb[u] * d.z;
+            acc1[4 * c4 + 3] += wb[u] * d.w;
+          }
+        }
+        const float dv = L1[k * VS + 32];
+        acc0[32] += wa[u] * dv;
+        acc1[32] += wb[u] * dv;
+      }
+#pragma unroll
+      for(int u = 0; u < KU; u++)
+      {
+        wa[u] = wan[u];
+        wb[u] = wbn[u];
       }
     }
     const float h0 = acc0[32] + b1[r0], h1 = acc1[32] + b1[r1];
     const float s0 = (h0 > 0.0f) ? 1.0f : 0.01f, s1 = (h1 > 0.0f) ? 1.0f : 0.01f;
-    L2[r0 * 33 + 32] = h0 * s0;
-    L2[r1 * 33 + 32] = h1 * s1;
+    L2[r0 * VS + 32] = h0 * s0;
+    L2[r1 * VS + 32] = h1 * s1;
     for(int c = 0; c < LAT; c++)
     {
-      L2[r0 * 33 + c] = s0 * acc0[c];
-      L2[r1 * 33 + c] = s1 * acc1[c];
+      L2[r0 * VS + c] = s0 * acc0[c];
+      L2[r1 * VS + c] = s1 * acc1[c];
     }
   }
   __syncthreads();
@@ -263,17 +298,36 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
   {
     float acc[33];
     for(int c = 0; c < 33; c++) acc[c] = 0.f;
-    for(int k = 0; k < HID; k++)
-    {
-      const float wv = w2t[k * OUT6 + tid];
-      const float * d = L2 + k * 33;
-      if(want_jac)
-      {
+    constexpr int KU = 8;
+    float wv[KU], wn[KU];
 #pragma unroll
-        for(int c = 0; c < 33; c++) acc[c] += wv * d[c];
+    for(int u = 0; u < KU; u++) wv[u] = w2t[u * OUT6 + tid];
+    for(int k0 = 0; k0 < HID; k0 += KU)
+    {
+      const int kn = (k0 + KU < HID) ? k0 + KU : k0;
+#pragma unroll
+      for(int u = 0; u < KU; u++) wn[u] = w2t[(kn + u) * OUT6 + tid];
+#pragma unroll
+      for(int u = 0; u < KU; u++)
+      {
+        const int k = k0 + u;
+        const float4 * d4 = reinterpret_cast<const float4 *>(L2 + k * VS);
+        if(want_jac)
+        {
+#pragma unroll
+          for(int c4 = 0; c4 < 8; c4++)
+          {
+            const float4 d = d4[c4];
+            acc[4 * c4 + 0] += wv[u] * d.x;
+            acc[4 * c4 + 1] += wv[u] * d.y;
+            acc[4 * c4 + 2] += wv[u] * d.z;
+            acc[4 * c4 + 3] += wv[u] * d.w;
+          }
+        }
+        acc[32] += wv[u] * L2[k * VS + 32];
       }
-      else
-        acc[32] += wv * d[32];
+#pragma unroll
+      for(int u = 0; u < KU; u++) wv[u] = wn[u];
     }
     acc[32] += b2[tid];
     for(int c = 0; c < 33; c++) so[tid * 33 + c] = acc[c];
@@ -311,7 +365,7 @@ __global__ void rotmat_to_aa_kernel(const float * __restrict__ rot, float * __re
 int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
                           float * jac, hipStream_t st)
 {
-  const size_t shmem = sizeof(float) * (size_t)(2 * HID * 33 + LAT + OUT6 * 33);
+  const size_t shmem = sizeof(float) * (size_t)(2 * HID * VS + LAT);
   static bool attr = false;
   if(!attr)
   {
