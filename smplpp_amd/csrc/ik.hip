@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   if(tid == 0)
   {
     double s = 0.0;
-    for(int r = 0; r < rows; r++) s += e[r] * e[r]; // ascending order, as the oracle sums it
+    for(int r = 0; r < rows; r++) s += e[r] * e[r]; // ascending order (the CPU checker sums the same way)
     s_e2 = s;
     s_bad = 0;
     s_done = 0;
