@@ -124,6 +124,41 @@ __device__ inline void actual_normal_dev(const ModelView & mv, const float * ver
   nn[2] = acc[2];
 }
 
+// the same two evaluations from vertex normals computed once (the three normals do not depend on the weights; each costs
+// ~30 dependent gathers)
+__device__ inline void actual_normal_vn(const float * vn /*[3][3]*/, const float * w, float * nn)
+{
+  float acc[3] = {0.f, 0.f, 0.f};
+  for(int i = 0; i < 3; i++)
+  {
+    acc[0] += w[i] * vn[i * 3];
+    acc[1] += w[i] * vn[i * 3 + 1];
+    acc[2] += w[i] * vn[i * 3 + 2];
+  }
+  normalize3(acc);
+  nn[0] = acc[0];
+  nn[1] = acc[1];
+  nn[2] = acc[2];
+}
+__device__ inline void actual_pos_vn(const ModelView & mv, const float * verts, int face, const float * w, float off, const float * vn,
+                                     float * p)
+{
+  for(int x = 0; x < 3; x++) // src/IkTask.cpp:64
+  {
+    float s = 0.f;
+    for(int i = 0; i < 3; i++) s += verts[3 * mv.faces[face * 3 + i] + x] * w[i];
+    p[x] = s;
+  }
+  if(off > 0.0f) // :66-69
+  {
+    float nn[3];
+    actual_normal_vn(vn, w, nn);
+    p[0] += off * nn[0];
+    p[1] += off * nn[1];
+    p[2] += off * nn[2];
+  }
+}
+
 __device__ inline void actual_pos_dev(const ModelView & mv, const float * verts, int face, const float * w, float off, float * p)
 {
   for(int x = 0; x < 3; x++) // src/IkTask.cpp:64
@@ -282,11 +317,25 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
   }
 
   if(dbg_stop == 21) return;
+  // ---- vertex normals of the tasks that use one (normal offset or normal term): one thread per (task, triangle vertex)
+  __shared__ float s_vn[IK_MAXK][9];
+  if(tid < 3 * (k_end - k_begin))
+  {
+    const int k = k_begin + tid / 3, i = tid % 3;
+    if(ta.noff[tb + k] > 0.0f || ta.nrmw[tb + k] > 0.0f)
+    {
+      float vn[3];
+      vertex_normal_dev(verts, mv.faces, mv.adjOff, mv.adjFace, mv.faces[ta.face[tb + k] * 3 + i], vn);
+      for(int x = 0; x < 3; x++) s_vn[k - k_begin][i * 3 + x] = vn[x];
+    }
+  }
+  __syncthreads();
   // ---- phase A: one thread per task — tangents, weight refresh, residual rows, ring list (node.cpp:803-820)
   if(k_begin + tid < k_end)
   {
     const int k = k_begin + tid;
     const int face = ta.face[tb + k];
+    const float * vnk = s_vn[k - k_begin];
     float tri[9];
     for(int i = 0; i < 3; i++)
       for(int x = 0; x < 3; x++) tri[i * 3 + x] = verts[3 * mv.faces[face * 3 + i] + x];
@@ -309,15 +358,15 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
     }
     float w[3] = {ta.vw[(tb + k) * 3], ta.vw[(tb + k) * 3 + 1], ta.vw[(tb + k) * 3 + 2]};
     float pos[3];
-    actual_pos_dev(mv, verts, face, w, off, pos);
+    actual_pos_vn(mv, verts, face, w, off, vnk, pos);
     for(int x = 0; x < 3; x++) pos804[(tb + k) * 3 + x] = pos[x]; // the point calcVertexWeights is differentiated at
     triangle_weights_dev(pos, tri, w); // calcVertexWeights with phi_ == 0 (src/IkTask.cpp:49-57, node.cpp:804)
     for(int i = 0; i < 3; i++) ta.vw[(tb + k) * 3 + i] = w[i];
     float ap[3], an[3] = {0.f, 0.f, 0.f};
-    actual_pos_dev(mv, verts, face, w, off, ap);
-    // the interpolated normal walks ~100 dependent gathers (3 vertices x their adjacent faces): only when a term uses it,
-    // as node.cpp:811-819 does; smplpp_ik_get_tasks evaluates it on demand for the others
-    if(wn > 0.0f) actual_normal_dev(mv, verts, face, w, an);
+    actual_pos_vn(mv, verts, face, w, off, vnk, ap);
+    // the interpolated normal only when a term uses it, as node.cpp:811-819 does; smplpp_ik_get_tasks evaluates it on
+    // demand for the others
+    if(wn > 0.0f) actual_normal_vn(vnk, w, an);
     for(int x = 0; x < 3; x++)
     {
       ta.apos[(tb + k) * 3 + x] = ap[x];
