@@ -154,6 +154,11 @@ __device__ __forceinline__ void full_barrier()
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#if SKINB_ABL & 256
+// slot timestamps (development only): wavefront 0 of workgroup 0 stamps s_memtime at every slot of its first 8 items
+__device__ unsigned long long g_slot_times[8 * 256];
+#endif
+
 template<int MAXW, bool WANT_REST>
 __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restrict__ A3, const uint8_t * __restrict__ B3,
                                                         const float * __restrict__ Gp, const float * __restrict__ theta,
@@ -249,6 +254,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
   };
 
   int f0_prev = 0;
+#if SKINB_ABL & 256
+  int dbg_item = 0;
+#endif
   // ---- prologue: k-steps 0, 1, 2 of the first item into images 0, 1, 2
   {
     int Abase, Bbase, Gbase;
@@ -398,6 +406,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
       constexpr int KS = S / B_SLOTS, M = S % B_SLOTS;
       constexpr int X = M / 6, Q = M % 6;
       constexpr int AP = KS & 1, IMG = KS % B_NIMG, IMGN = (KS + 1) % B_NIMG;
+#if SKINB_ABL & 256
+      if(blockIdx.x == 0 && tid == 0 && dbg_item < 8) g_slot_times[dbg_item * 256 + S] = __builtin_readcyclecounter();
+#endif
       if constexpr(!(SKINB_ABL & 4))
         acc[X] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[AP][B_PA[Q]]),
                                                          __builtin_bit_cast(bf16x8, bfr[AP][X][B_PB[Q]]), acc[X], 0, 0, 0);
@@ -486,7 +497,13 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_b(const uint8_t * __restri
   };
 
   do_item(jb, std::false_type{});
-  for(int t = jb + nbx; t < cnt; t += nbx) do_item(t, std::true_type{});
+  for(int t = jb + nbx; t < cnt; t += nbx)
+  {
+#if SKINB_ABL & 256
+    dbg_item++;
+#endif
+    do_item(t, std::true_type{});
+  }
 
   // ---- drain: the epilogue of the last item with nothing to hide behind (its G' tile was DMA'd in its own slots 223..240)
   *rootWr = rstage;
@@ -567,6 +584,12 @@ static hipError_t launch_b(const smplpp_model * m, int64_t n, const float * thet
   return hipGetLastError();
 }
 
+#if SKINB_ABL & 256
+extern "C" int smplpp_debug_slot_times(unsigned long long * out)
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(smplpp_hip::g_slot_times), sizeof(unsigned long long) * 8 * 256);
+}
+#endif
 // Gp must hold whole 64-frame tiles (padding content is irrelevant: the rows it feeds are never stored)
 hipError_t launch_skin_bf16x3(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st)
 {
