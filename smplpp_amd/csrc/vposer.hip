@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
   float * L2 = lds + HID * VS;       // [512][VS]
   float * sz = L2 + HID * VS;        // [32]
   float * so = L1;                   // [126][33]  (a1/D1 is dead once layer 1 is done)
+  float * sSlope = sz + LAT;         // [512] LeakyReLU slopes of layer 1
   const int64_t f = blockIdx.x;
   const int tid = threadIdx.x;
   if(tid < LAT) sz[tid] = z[f * z_stride + tid];
@@ -227,13 +228,14 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
     for(int c = 0; c < LAT; c++) L1[row * VS + c] = slope * w0t[c * HID + row];
   }
   __syncthreads();
-  // layer 1 (+ LeakyReLU): value and 32 tangents per row
+  // layer 1 (+ LeakyReLU).  The activation column is a matrix-vector product on the VALU (two rows per thread); the 32
+  // tangent columns are a [512 x 512] . [512 x 32] GEMM on v_mfma_f32_32x32x2_f32 (exact fp32): wavefront w owns the four
+  // 32-row tiles 4w..4w+3, lane l feeds A[row = l % 32][k = l / 32] = W1[row][k] (K-major weights: coalesced) and
+  // B[k = l / 32][col = l % 32] = D1[k][col] from LDS, weights prefetched eight k ahead.
   {
-    float acc0[33], acc1[33];
-    for(int c = 0; c < 33; c++) acc0[c] = acc1[c] = 0.f;
     const int r0 = tid, r1 = tid + 256;
-    // weights stream from L2 eight k ahead (a load per k in the loop body pays the L2 latency 512 times)
-    constexpr int KU = 8;
+    float h0 = 0.f, h1 = 0.f;
+    constexpr int KU = 16;
     float wa[KU], wb[KU], wan[KU], wbn[KU];
 #pragma unroll
     for(int u = 0; u < KU; u++)
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
     }
     for(int k0 = 0; k0 < HID; k0 += KU)
     {
-      const int kn = (k0 + KU < HID) ? k0 + KU : k0; // (the last block re-reads itself: harmless)
+      const int kn = (k0 + KU < HID) ? k0 + KU : k0;
 #pragma unroll
       for(int u = 0; u < KU; u++)
       {
@@ -253,27 +255,9 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
 #pragma unroll
       for(int u = 0; u < KU; u++)
       {
-        const int k = k0 + u;
-        const float4 * d4 = reinterpret_cast<const float4 *>(L1 + k * VS);
-        if(want_jac)
-        {
-#pragma unroll
-          for(int c4 = 0; c4 < 8; c4++)
-          {
-            const float4 d = d4[c4];
-            acc0[4 * c4 + 0] += wa[u] * d.x;
-            acc0[4 * c4 + 1] += wa[u] * d.y;
-            acc0[4 * c4 + 2] += wa[u] * d.z;
-            acc0[4 * c4 + 3] += wa[u] * d.w;
-            acc1[4 * c4 + 0] += wb[u] * d.x;
-            acc1[4 * c4 + 1] += wb[u] * d.y;
-            acc1[4 * c4 + 2] += wb[u] * d.z;
-            acc1[4 * c4 + 3] += wb[u] * d.w;
-          }
-        }
-        const float dv = L1[k * VS + 32];
-        acc0[32] += wa[u] * dv;
-        acc1[32] += wb[u] * dv;
+        const float dv = L1[(k0 + u) * VS + 32];
+        h0 += wa[u] * dv;
+        h1 += wb[u] * dv;
       }
 #pragma unroll
       for(int u = 0; u < KU; u++)
@@ -282,55 +266,113 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
         wb[u] = wbn[u];
       }
     }
-    const float h0 = acc0[32] + b1[r0], h1 = acc1[32] + b1[r1];
+    h0 += b1[r0];
+    h1 += b1[r1];
     const float s0 = (h0 > 0.0f) ? 1.0f : 0.01f, s1 = (h1 > 0.0f) ? 1.0f : 0.01f;
     L2[r0 * VS + 32] = h0 * s0;
     L2[r1 * VS + 32] = h1 * s1;
-    for(int c = 0; c < LAT; c++)
+    sSlope[r0] = s0;
+    sSlope[r1] = s1;
+  }
+  if(want_jac)
+  {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int wave = tid >> 6, l = tid & 63, l31 = l & 31, lh = l >> 5;
+    f32x16 acc[4];
+#pragma unroll
+    for(int t = 0; t < 4; t++)
+#pragma unroll
+      for(int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+    constexpr int KU = 4; // k-steps of 2 per batch
+    float wq[KU][4], wn[KU][4];
+#pragma unroll
+    for(int u = 0; u < KU; u++)
+#pragma unroll
+      for(int t = 0; t < 4; t++) wq[u][t] = w1t[(2 * u + lh) * HID + 32 * (4 * wave + t) + l31];
+    for(int k2 = 0; k2 < HID / 2; k2 += KU)
     {
-      L2[r0 * VS + c] = s0 * acc0[c];
-      L2[r1 * VS + c] = s1 * acc1[c];
+      const int kn = (k2 + KU < HID / 2) ? k2 + KU : k2;
+#pragma unroll
+      for(int u = 0; u < KU; u++)
+#pragma unroll
+        for(int t = 0; t < 4; t++) wn[u][t] = w1t[(2 * (kn + u) + lh) * HID + 32 * (4 * wave + t) + l31];
+#pragma unroll
+      for(int u = 0; u < KU; u++)
+      {
+        const float bv = L1[(2 * (k2 + u) + lh) * VS + l31];
+#pragma unroll
+        for(int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[u][t], bv, acc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for(int u = 0; u < KU; u++)
+#pragma unroll
+        for(int t = 0; t < 4; t++) wq[u][t] = wn[u][t];
     }
+    __syncthreads(); // slopes are in LDS
+#pragma unroll
+    for(int t = 0; t < 4; t++)
+#pragma unroll
+      for(int r = 0; r < 16; r++)
+      {
+        const int row = 32 * (4 * wave + t) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        L2[row * VS + l31] = sSlope[row] * acc[t][r];
+      }
   }
   __syncthreads();
-  // layer 2: 126 rows
+  // layer 2: 126 rows (activation column on the VALU, tangents on the matrix pipe: wavefront w owns rows 32w..32w+31)
   if(tid < OUT6)
   {
-    float acc[33];
-    for(int c = 0; c < 33; c++) acc[c] = 0.f;
-    constexpr int KU = 8;
-    float wv[KU], wn[KU];
+    float h = 0.f;
+    constexpr int KU = 16;
+    float wv[KU], wvn[KU];
 #pragma unroll
     for(int u = 0; u < KU; u++) wv[u] = w2t[u * OUT6 + tid];
     for(int k0 = 0; k0 < HID; k0 += KU)
     {
       const int kn = (k0 + KU < HID) ? k0 + KU : k0;
 #pragma unroll
-      for(int u = 0; u < KU; u++) wn[u] = w2t[(kn + u) * OUT6 + tid];
+      for(int u = 0; u < KU; u++) wvn[u] = w2t[(kn + u) * OUT6 + tid];
+#pragma unroll
+      for(int u = 0; u < KU; u++) h += wv[u] * L2[(k0 + u) * VS + 32];
+#pragma unroll
+      for(int u = 0; u < KU; u++) wv[u] = wvn[u];
+    }
+    so[tid * 33 + 32] = h + b2[tid];
+  }
+  if(want_jac)
+  {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int wave = tid >> 6, l = tid & 63, l31 = l & 31, lh = l >> 5;
+    const int arow = 32 * wave + l31;
+    const bool alive = arow < OUT6;
+    const int acol = alive ? arow : 0;
+    f32x16 acc;
+#pragma unroll
+    for(int r = 0; r < 16; r++) acc[r] = 0.0f;
+    constexpr int KU = 8;
+    float wq[KU], wn[KU];
+#pragma unroll
+    for(int u = 0; u < KU; u++) wq[u] = alive ? w2t[(2 * u + lh) * OUT6 + acol] : 0.0f;
+    for(int k2 = 0; k2 < HID / 2; k2 += KU)
+    {
+      const int kn = (k2 + KU < HID / 2) ? k2 + KU : k2;
 #pragma unroll
       for(int u = 0; u < KU; u++)
       {
-        const int k = k0 + u;
-        const float4 * d4 = reinterpret_cast<const float4 *>(L2 + k * VS);
-        if(want_jac)
-        {
-#pragma unroll
-          for(int c4 = 0; c4 < 8; c4++)
-          {
-            const float4 d = d4[c4];
-            acc[4 * c4 + 0] += wv[u] * d.x;
-            acc[4 * c4 + 1] += wv[u] * d.y;
-            acc[4 * c4 + 2] += wv[u] * d.z;
-            acc[4 * c4 + 3] += wv[u] * d.w;
-          }
-        }
-        acc[32] += wv[u] * L2[k * VS + 32];
+        const float wv = w2t[(2 * (kn + u) + lh) * OUT6 + acol];
+        wn[u] = alive ? wv : 0.0f;
       }
 #pragma unroll
-      for(int u = 0; u < KU; u++) wv[u] = wn[u];
+      for(int u = 0; u < KU; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[u], L2[(2 * (k2 + u) + lh) * VS + l31], acc, 0, 0, 0);
+#pragma unroll
+      for(int u = 0; u < KU; u++) wq[u] = wn[u];
     }
-    acc[32] += b2[tid];
-    for(int c = 0; c < 33; c++) so[tid * 33 + c] = acc[c];
+#pragma unroll
+    for(int r = 0; r < 16; r++)
+    {
+      const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if(row < OUT6) so[row * 33 + l31] = acc[r];
+    }
   }
   __syncthreads();
   // rotation tail: one thread per joint
@@ -365,7 +407,7 @@ __global__ void rotmat_to_aa_kernel(const float * __restrict__ rot, float * __re
 int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
                           float * jac, hipStream_t st)
 {
-  const size_t shmem = sizeof(float) * (size_t)(2 * HID * VS + LAT);
+  const size_t shmem = sizeof(float) * (size_t)(2 * HID * VS + LAT + HID);
   static bool attr = false;
   if(!attr)
   {
