@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
     for(int t = 0; t < 4; t++)
 #pragma unroll
       for(int r = 0; r < 16; r++) acc[t][r] = 0.0f;
-    constexpr int KU = 4; // k-steps of 2 per batch
+    constexpr int KU = 8; // k-steps of 2 per batch
     float wq[KU][4], wn[KU][4];
 #pragma unroll
     for(int u = 0; u < KU; u++)
