@@ -2,7 +2,7 @@
 # Per-kernel average durations of the IK loop of bench.py (rocprofv3 --kernel-trace --stats). usage (GPU box, repo root): bash tools/ik_kernel_times.sh
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/iktrace; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench.json 2> $OUT/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $OUT/bench.json 2> $OUT/err.txt
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/*/*kernel_stats.csv")[0]
