@@ -962,97 +962,102 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
       if(i == nf && k < nf) acc[a][b] += bpri[idx[k]];
     }
   if(dbg_stop == 4) return;
-  // factorisation
-  // The holders of a column publish its raw entries (and 1/sqrt of the pivot) to LDS; one barrier later everybody applies
-  // the rank-1 update.  LOOK-AHEAD: right after the barrier of column j the holders of column j + 1 update just that
-  // column and publish it (into the other buffer) BEFORE the rest of their update, so the pivot's extraction, rsqrt and
-  // LDS write leave the critical path: a column costs barrier + LDS read + the widest thread's update.
-  auto publish = [&](const int BJ, int jj_, int j_) { // called by the threads with tx == jj_ ; j_ = 16 * BJ + jj_ (BJ: constant after unrolling)
-    double * lrp = lraw + (j_ & 1) * (16 * NT);
-#pragma unroll
-    for(int a = BJ; a < NT; a++)
-    {
-      const int i = ty + 16 * a;
-      if(i >= j_ && i <= nf)
-      {
-        lrp[i] = acc[a][BJ];
-        if(i == j_)
-        {
-          double d = acc[a][BJ];
-          if(!(d > 0.0))
-          {
-            *bad = 1;
-            d = 1.0;
-          }
-          const double y = fast_rsqrt(d);
-          ldiag[(j_ & 1) * 2] = y;         // 1 / piv
-          ldiag[(j_ & 1) * 2 + 1] = d * y; // piv
-          dinv[j_] = y;
-        }
-      }
-    }
-  };
+  // factorisation, TWO columns per barrier.  The holders of columns j0 and j1 = j0 + 1 publish their raw entries; one
+  // barrier later every thread forms, from those two published columns alone, the corrected column j1
+  //   c_i = a_{i,j1} - a_{i,j0} a_{j1,j0} / d0      (d0 = a_{j0,j0}),   d1 = c_{j1}
+  // for the rows and columns it owns and applies the rank-2 update  a_ik -= a_{i,j0} a_{k,j0} / d0 + c_i c_k / d1
+  // to its registers (the elements of column j1 itself take only the first term and become c).  Nothing but two
+  // reciprocals sits between the barrier and the update; square roots are taken once, after the loop.
+  // lraw: [2 (pair parity)][2 (column of the pair)][16 NT], zeroed: rows beyond nf are never published.
+  constexpr int LS = 16 * NT;
   bool kcol[NT]; // tx + 16 a is a column of the system (not the rhs row, not padding)
 #pragma unroll
   for(int a = 0; a < NT; a++) kcol[a] = tx + 16 * a < nf;
-  for(int q = tid; q < 2 * 16 * NT; q += 256) lraw[q] = 0.0;
+  for(int q = tid; q < 4 * LS; q += 256) lraw[q] = 0.0;
   __syncthreads();
-  if(tx == 0 && nf > 0) publish(0, 0, 0);
+  int pair = 0;
 #pragma unroll
   for(int bj = 0; bj < NT; bj++)
   {
-    for(int jj = 0; jj < 16; jj++)
+    for(int jj = 0; jj < 16; jj += 2)
     {
-      const int j = 16 * bj + jj;
-      if(j >= nf) break; // uniform
-      const double * lr = lraw + (j & 1) * (16 * NT);
+      const int j0 = 16 * bj + jj, j1 = j0 + 1;
+      if(j0 >= nf) break; // uniform
+      const bool two = j1 < nf; // uniform
+      double * l0 = lraw + (pair & 1) * 2 * LS;
+      double * l1 = l0 + LS;
+      pair++;
+      if(tx == jj || (two && tx == jj + 1)) // the holders publish (both columns live in tile column bj)
+      {
+        double * lp = (tx == jj) ? l0 : l1;
+        const int jc = (tx == jj) ? j0 : j1;
+#pragma unroll
+        for(int a = bj; a < NT; a++)
+        {
+          const int i = ty + 16 * a;
+          if(i >= jc && i <= nf) lp[i] = acc[a][bj];
+        }
+      }
       __syncthreads();
-      const double inv_piv = ldiag[(j & 1) * 2];
-      const double inv_d = inv_piv * inv_piv;
-      // lraw was zeroed and rows beyond nf are never published, so only the diagonal block (a == bj) needs the "below the
-      // pivot" test; the rhs row (k == nf) is masked by a per-thread constant
-      double li[NT], lk[NT];
+      double d0 = l0[j0];
+      if(!(d0 > 0.0))
+      {
+        *bad = 1;
+        d0 = 1.0;
+      }
+      double inv0 = __builtin_amdgcn_rcp(d0);
+      inv0 = inv0 * (2.0 - d0 * inv0);
+      inv0 = inv0 * (2.0 - d0 * inv0);
+      const double m = two ? l0[j1] * inv0 : 0.0;
+      double d1 = two ? l1[j1] - l0[j1] * m : 1.0;
+      if(!(d1 > 0.0))
+      {
+        *bad = 1;
+        d1 = 1.0;
+      }
+      double inv1 = __builtin_amdgcn_rcp(d1);
+      inv1 = inv1 * (2.0 - d1 * inv1);
+      inv1 = inv1 * (2.0 - d1 * inv1);
+      if(!two) inv1 = 0.0;
+      double ri0[NT], ci[NT], sk0[NT], sk1[NT]; // rows: raw column j0, corrected column j1; columns: the same, scaled
 #pragma unroll
       for(int a = bj; a < NT; a++)
       {
         const int i = ty + 16 * a, k = tx + 16 * a;
-        const double ri = lr[i], rk = lr[k] * inv_d;
-        li[a] = (a > bj || i > j) ? ri : 0.0;
-        lk[a] = (kcol[a] && (a > bj || k > j)) ? rk : 0.0;
+        const double r0i = l0[i], r1i = l1[i], r0k = l0[k], r1k = l1[k];
+        const bool irow = (a > bj || i > j0); // strictly below the first pivot
+        ri0[a] = irow ? r0i : 0.0;
+        ci[a] = (a > bj || i > j1) ? r1i - r0i * m : 0.0; // strictly below the second pivot
+        const bool kc = kcol[a] && (a > bj || k > j0);
+        sk0[a] = kc ? r0k * inv0 : 0.0;
+        sk1[a] = (kcol[a] && (a > bj || k > j1)) ? (r1k - r0k * m) * inv1 : 0.0;
       }
-      // look-ahead: column j + 1 first, by its holders, then published
-      if(j + 1 < nf)
-      {
-        if(jj < 15)
-        {
-          if(tx == jj + 1)
-          {
-#pragma unroll
-            for(int a = bj; a < NT; a++) acc[a][bj] -= li[a] * lk[bj];
-            lk[bj] = 0.0; // done for this thread
-            publish(bj, jj + 1, j + 1);
-          }
-        }
-        else if(bj + 1 < NT)
-        {
-          if(tx == 0)
-          {
-            const int bn = bj + 1 < NT ? bj + 1 : NT - 1; // (the clamp only keeps the unrolled index in range)
-#pragma unroll
-            for(int a = bn; a < NT; a++) acc[a][bn] -= li[a] * lk[bn];
-            lk[bn] = 0.0;
-            publish(bn, 0, j + 1);
-          }
-        }
-      }
+      // (the elements of column j1 itself get only the j0 term — their sk1 is zero — and so become the corrected column)
 #pragma unroll
       for(int a = bj; a < NT; a++)
 #pragma unroll
-        for(int b = bj; b <= a; b++) acc[a][b] -= li[a] * lk[b];
+        for(int b = bj; b <= a; b++) acc[a][b] -= ri0[a] * sk0[b] + ci[a] * sk1[b];
     }
   }
   __syncthreads();
-  // the scaled factor for the back substitution, once: a column's raw entries are final as soon as it has been published
+  // reciprocal pivots 1/sqrt(d_k) from the final diagonal entries, once
+#pragma unroll
+  for(int a = 0; a < NT; a++)
+  {
+    const int i = ty + 16 * a;
+    if(ty == tx && i < nf)
+    {
+      double d = acc[a][a];
+      if(!(d > 0.0))
+      {
+        *bad = 1;
+        d = 1.0;
+      }
+      dinv[i] = fast_rsqrt(d);
+    }
+  }
+  __syncthreads();
+  // the scaled factor for the back substitution, once: a column's raw entries are final once its pair has been processed
   // (later updates only touch columns to its right), and L_ik = raw_ik / piv_k, piv_k = d_k / sqrt(d_k) = raw_kk * dinv_k
 #pragma unroll
   for(int a = 0; a < NT; a++)
@@ -1088,8 +1093,8 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   double * lo = bpri + D;
   double * hi = lo + D;
   double * rowv = hi + D;
-  double * lraw = rowv + rows; // [2][96] published column of the register-tiled factorisation
-  double * ldiag = lraw + 192; // [2][2]  1/pivot, pivot
+  double * lraw = rowv + rows; // [2][2][96] published column pairs of the register-tiled factorisation
+  double * ldiag = lraw + 384; // [4] (spare)
   double * dinv = ldiag + 4;   // [D] reciprocal pivots for the back substitution
   int * idx = reinterpret_cast<int *>(dinv + D);
   int * state = idx + D; // 0 free, -1 at lo, +1 at hi, 2 pinned (empty box)
@@ -1879,7 +1884,7 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
     const int beta_dim = opt_beta ? NB : 0;
     // LDS plan: packed system + vectors, the rest (up to a 150 KB total) for the J row chunk
     const int D = s->theta_dim + 2 * K + beta_dim, rows = 4 * K;
-    const size_t fixed = sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 7 * (size_t)D + 2 * (size_t)rows + 196) + sizeof(int) * 2 * (size_t)D;
+    const size_t fixed = sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 7 * (size_t)D + 2 * (size_t)rows + 388) + sizeof(int) * 2 * (size_t)D;
     const size_t budget = 150 * 1024;
     int chunk_rows = (int)((budget - fixed) / (sizeof(double) * (size_t)D));
     if(chunk_rows > rows) chunk_rows = rows;
