@@ -137,6 +137,34 @@ def test_fk_eight_weights_per_vertex(synth_model, form, monkeypatch):
             assert np.abs(g[k] - r[k]).max() < VERT_TOL, (form, n, k)
 
 
+@pytest.mark.parametrize("V", [61, 200, 1000])
+def test_fk_small_sparse_models(V):
+    """Vertex counts that are not multiples of 64 (partial vertex-group pairs, fewer pairs than XCDs) with <= 4 weights per
+    vertex: the default fused kernel on small meshes, ragged frame counts."""
+    from smplpp_amd import model_io
+    from smplpp_amd.smpl import SMPL
+    from oracle.cpu import OracleModel
+
+    md = model_io.tiny_model(V, seed=11)
+    w = md["weights"].astype(np.float64)
+    keep = np.argsort(-w, axis=1)[:, :4]
+    sp = np.zeros_like(w)
+    np.put_along_axis(sp, keep, np.take_along_axis(w, keep, axis=1), axis=1)
+    sp /= sp.sum(axis=1, keepdims=True)
+    md["weights"] = sp.astype(np.float32)
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(md)
+    assert s.info()["weights_per_vertex"] == 4
+    o = OracleModel(md)
+    for n in (1, 65, 130):
+        beta, theta = model_io.synthetic_inputs(n, seed=V + n)
+        g = s.launch(beta, theta)
+        r = o.fk(beta, theta)
+        for k in ("verts", "rest", "joints"):
+            assert np.abs(g[k] - r[k]).max() < VERT_TOL, (V, n, k)
+
+
 def test_fk_outputs_beyond_2gib(smpl, oracle_synth):
     """The default fused kernels address their outputs with 32-bit buffer offsets; a batch whose vertex array reaches
     2 GiB (26 100 frames) is split into launches of at most 2 GiB (fp32-MFMA form: falls back to 64-bit addressing) and must still be right (device buffers: no 2 GiB host copy)."""
