@@ -82,7 +82,16 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
   __shared__ int sPar[NJ];
   __shared__ int sLvl[NJ + 1 + NJ];
   if(f >= n) return;
-  // ---- phase 0
+  // ---- phase 0 (the folded-regressor rows are fetched now, so their latency overlaps Rodrigues and the first barrier)
+  float j0v = 0.0f, jsv[NB];
+#pragma unroll
+  for(int k = 0; k < NB; k++) jsv[k] = 0.0f;
+  if(tid < NJ * 3)
+  {
+    j0v = J0[tid];
+#pragma unroll
+    for(int k = 0; k < NB; k++) jsv[k] = JS[tid * NB + k];
+  }
   if(tid >= 64 && tid < 64 + NB) sBeta[tid - 64] = beta ? beta[f * NB + (tid - 64)] : 0.0f;
   if(tid >= 128 && tid < 128 + NJ) sPar[tid - 128] = parent[tid - 128];
   if(tid >= 192 && tid < 192 + nlev + 1) sLvl[tid - 192] = lvl_off[tid - 192];
@@ -118,9 +127,9 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
   }
   if(tid < NJ * 3) // joints (src/JointRegression.cpp:588-590 through the folded regressor)
   {
-    float s = J0[tid];
+    float s = j0v;
 #pragma unroll
-    for(int k = 0; k < NB; k++) s += JS[tid * NB + k] * sBeta[k];
+    for(int k = 0; k < NB; k++) s += jsv[k] * sBeta[k];
     sJ[tid / 3][tid % 3] = s;
     if(joints_out) joints_out[f * NJ * 3 + tid] = s;
   }
