@@ -141,6 +141,27 @@ constexpr int barrier_vmcnt(int ks, bool hp, bool rest)
   return c;
 }
 
+// the tables above must describe exactly what the slot stream issues per item
+constexpr int sum_vmem_ops(bool hp, bool rest)
+{
+  int c = 0;
+  for(int S = 0; S < B_NSLOT; S++) c += vmem_ops(S, hp, rest);
+  return c;
+}
+constexpr int sum_epilogue_lds_ops(int maxw)
+{
+  int c = 0;
+  for(int S = 0; S < B_NSLOT; S++) c += epilogue_lds_ops(S, maxw);
+  return c;
+}
+static_assert(sum_vmem_ops(false, false) == BB_KS * 6 + B_GCHUNKS + 1, "operand DMAs + G' DMAs + root load");
+static_assert(sum_vmem_ops(true, false) == BB_KS * 6 + B_GCHUNKS + 1 + 16, "+ one vertex store per row");
+static_assert(sum_vmem_ops(true, true) == BB_KS * 6 + B_GCHUNKS + 1 + 32, "+ one rest store per row");
+static_assert(sum_epilogue_lds_ops(4) == 16 * (4 * 3 + 1) && sum_epilogue_lds_ops(8) == 16 * (8 * 3 + 1), "joint matrices + root per row");
+static_assert(B_ROW_END < 12 * B_SLOTS + B_BAR, "the rows must end before the barrier after which the G' image is overwritten");
+static_assert(B_ROW0 - B_RD_AHEAD > B_BAR, "the first G' read of an item must follow the barrier that publishes the tile");
+static_assert(B_GDMA0 + B_GCHUNKS <= B_NSLOT, "the G' DMAs must fit the item");
+
 // Barrier of a k-step: LGKM = LDS instructions of this wavefront that may stay in flight (epilogue reads issued behind
 // slot 5's sched_barrier line), VM = vector-memory instructions that may stay in flight (see barrier_vmcnt).
 template<int LGKM, int VM>
