@@ -309,7 +309,7 @@ def main():
             "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
                     "algorithmic_bytes_per_launch": ALG_BYTES_CONST + ALG_BYTES_PER_FRAME * n},
             "note": "achieved = ALGORITHMIC fp32 FLOPs of the blend-shape contraction (2*20670*217 per frame) / kernel time, "
-                    "priced against the fp32 matrix peak (the arithmetic type of the path: results are fp32-exact, max error vs "
+                    "priced against the fp32 matrix peak (the arithmetic type of the path: results carry fp32 accuracy — max error vs "
                     "the fp64 oracle 7e-7 m, same as the fp32-MFMA form); 'issued' prices the bf16 instructions actually "
                     "executed against the dense bf16 peak. Dense bf16 MFMA holds ~1.6 GHz on this chip (tools/micro/mfma_lds.hip), "
                     "so the issued-rate ceiling is ~2/3 of the datasheet figure. Batch 1024 has 152 FLOP/B: the matrix pipe, "
