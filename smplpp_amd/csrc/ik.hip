@@ -159,6 +159,25 @@ __device__ inline void actual_pos_vn(const ModelView & mv, const float * verts, 
   }
 }
 
+// ... and with the triangle's vertices already at hand (src/IkTask.cpp:64-69)
+__device__ inline void actual_pos_tri(const float * tri /*[3][3]*/, const float * w, float off, const float * vn, float * p)
+{
+  for(int x = 0; x < 3; x++)
+  {
+    float s = 0.f;
+    for(int i = 0; i < 3; i++) s += tri[i * 3 + x] * w[i];
+    p[x] = s;
+  }
+  if(off > 0.0f)
+  {
+    float nn[3];
+    actual_normal_vn(vn, w, nn);
+    p[0] += off * nn[0];
+    p[1] += off * nn[1];
+    p[2] += off * nn[2];
+  }
+}
+
 __device__ inline void actual_pos_dev(const ModelView & mv, const float * verts, int face, const float * w, float off, float * p)
 {
   for(int x = 0; x < 3; x++) // src/IkTask.cpp:64
@@ -186,16 +205,23 @@ constexpr int L_DR = L_T + NJ * 3;             // [72][9]
 constexpr int L_DAB = L_DR + 72 * 9;           // [24*12][72]  (joint, entry) major, column fastest
 constexpr int L_DBB = L_DAB + NJ * 12 * 72;    // [24*3][10]
 constexpr int L_RV = L_DBB + NJ * 3 * NB;      // [MAXRING][16]  rest(3) Ablend(9) wsum(1)
-constexpr int L_DP = L_RV + MAXRING * 16;      // [MAXRING][3][NQ]
+constexpr int RVS = 24;                         // floats per ring vertex: rest 3 | Ablend 9 | wsum 1 | posed 3 | weights 4 | joints 4
+constexpr int L_DP = L_RV + MAXRING * RVS;     // [MAXRING][3][NQ]
 constexpr int L_VN = L_DP + MAXRING * 3 * NQ;  // [3][3] vertex normals + [3] their weighted sum
 constexpr int L_END = L_VN + 12;
 constexpr int L_ANC_BYTES = NJ * 4;            // int anc[24] after the float region
 
+#ifdef SMPLPP_EVAL_STAMPS
+__device__ unsigned long long g_eval_stamps[64 * 16];
+#define EVAL_STAMP(i) do { if(tid == 0 && blockIdx.x < 64) g_eval_stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while(0)
+#else
+#define EVAL_STAMP(i) do {} while(0)
+#endif
 __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ theta25,
                                                       const float * __restrict__ verts_all, const float * __restrict__ rest_all,
                                                       const float * __restrict__ Gp, const float * __restrict__ joints,
                                                       const float * __restrict__ poserot, int K, int optimize_beta,
-                                                      int phi_live, int min_valid, int32_t * __restrict__ ring_buf,
+                                                      int phi_live, int min_valid, int32_t * __restrict__ ring_buf, int32_t * __restrict__ ring_key,
                                                       uint8_t * __restrict__ map_buf, float * __restrict__ pos804,
                                                       double * __restrict__ e_out, double * __restrict__ J_out,
                                                       int * __restrict__ skip, int dbg_stop, int tsplit)
@@ -208,6 +234,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
   const int part = (int)(blockIdx.x % tsplit);
 
   const int tid = threadIdx.x;
+  EVAL_STAMP(0);
   const int nq = TD75 + (optimize_beta ? NB : 0);
   const int D = TD75 + 2 * K + (optimize_beta ? NB : 0);
   const float * verts = verts_all + f * mv.V * 3;
@@ -248,6 +275,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
   }
   __syncthreads();
 
+  EVAL_STAMP(1);
   if(dbg_stop == 20) return; // (timing experiments only: SMPLPP_IK_DBG_STOP)
   // ---- chain derivatives: thread (c, r) = rotation column c (joint c/3, component c%3) x matrix
   // row r.  Row r of dA_i and dg_i depends only on row r of the parent's: 216 independent 24-step recurrences (one thread
@@ -316,100 +344,194 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
     }
   }
 
+  EVAL_STAMP(2);
   if(dbg_stop == 21) return;
-  // ---- vertex normals of the tasks that use one (normal offset or normal term): one thread per (task, triangle vertex)
+  // ---- phase A, in four steps so that nothing walks dependent HBM gathers serially:
+  //   A0  one thread per task: the ring list (topology only: cached per (face, uses-normal), rebuilt when the face changes)
+  //   A1  all threads: posed positions of the ring vertices -> LDS
+  //   A2  one thread per (task, triangle vertex): vertex normal from those positions (tasks with a normal offset / term)
+  //   A3  one thread per task: tangents, weight refresh, residual rows (node.cpp:803-820)
   __shared__ float s_vn[IK_MAXK][9];
-  if(tid < 3 * (k_end - k_begin))
-  {
-    const int k = k_begin + tid / 3, i = tid % 3;
-    if(ta.noff[tb + k] > 0.0f || ta.nrmw[tb + k] > 0.0f)
-    {
-      float vn[3];
-      vertex_normal_dev(verts, mv.faces, mv.adjOff, mv.adjFace, mv.faces[ta.face[tb + k] * 3 + i], vn);
-      for(int x = 0; x < 3; x++) s_vn[k - k_begin][i * 3 + x] = vn[x];
-    }
-  }
-  __syncthreads();
-  // ---- phase A: one thread per task — tangents, weight refresh, residual rows, ring list (node.cpp:803-820)
-  if(k_begin + tid < k_end)
+  __shared__ int32_t s_ringb[IK_MAXK][MAXRING + 1];
+  // posed positions of the ring vertices of every task of this workgroup: [task][MAXRING][3], in the dp buffer of phase B
+  // (free until then)
+  static_assert(IK_MAXK * MAXRING * 3 <= MAXRING * 3 * NQ, "s_rpos must fit the L_DP region");
+  float(*s_rpos)[MAXRING][3] = reinterpret_cast<float(*)[MAXRING][3]>(lds + L_DP);
+  const int ntask = k_end - k_begin;
+  if(tid < ntask) // A0
   {
     const int k = k_begin + tid;
     const int face = ta.face[tb + k];
-    const float * vnk = s_vn[k - k_begin];
-    float tri[9];
-    for(int i = 0; i < 3; i++)
-      for(int x = 0; x < 3; x++) tri[i * 3 + x] = verts[3 * mv.faces[face * 3 + i] + x];
-    const float off = ta.noff[tb + k], wp = ta.posw[tb + k], wn = ta.nrmw[tb + k];
-    const bool use_normal = (off > 0.0f) || (wn > 0.0f);
-    // calcTangents (src/IkTask.cpp:33-47)
+    const bool use_normal = (ta.noff[tb + k] > 0.0f) || (ta.nrmw[tb + k] > 0.0f);
+    int32_t * ring = s_ringb[tid];
+    uint8_t * map = map_buf + (f * K + k) * (3 * MAXADJ * 3);
+    int32_t * ring_out = ring_buf + (f * K + k) * (MAXRING + 1);
+    const int key = face * 2 + (use_normal ? 1 : 0);
+    const bool cached = ring_key[tb + k] == key;
+    int nr = 0;
+    if(cached)
     {
-      float t1[3] = {tri[3] - tri[0], tri[4] - tri[1], tri[5] - tri[2]};
+      nr = ring_out[0];
+      for(int q = 1; q <= nr; q++) ring[q] = ring_out[q];
+    }
+    else
+    {
+      int fv[3];
+      for(int i = 0; i < 3; i++) fv[i] = mv.faces[face * 3 + i];
+      for(int i = 0; i < 3; i++) ring[1 + nr++] = fv[i]; // slots 0..2 = the face's own vertices
+      if(use_normal) // + the distinct vertices of the faces around them
+      {
+        // all candidate vertices first (two rounds of independent loads: adjacent faces, then their corners; the duplicate
+        // search below then runs on LDS only), into this task's slice of the position buffer used as integer scratch
+        int * cand = reinterpret_cast<int *>(&s_rpos[tid][0][0]); // [3][MAXADJ][3] = 108 <= 120
+        int b0[3], cnt[3];
+        for(int i = 0; i < 3; i++)
+        {
+          b0[i] = mv.adjOff[fv[i]];
+          cnt[i] = mv.adjOff[fv[i] + 1] - b0[i];
+          if(cnt[i] > MAXADJ) cnt[i] = MAXADJ;
+        }
+        int fa[3][MAXADJ];
+#pragma unroll
+        for(int i = 0; i < 3; i++)
+#pragma unroll
+          for(int a2 = 0; a2 < MAXADJ; a2++) fa[i][a2] = mv.adjFace[b0[i] + (a2 < cnt[i] ? a2 : 0)];
+#pragma unroll
+        for(int i = 0; i < 3; i++)
+#pragma unroll
+          for(int a2 = 0; a2 < MAXADJ; a2++)
+#pragma unroll
+            for(int cc = 0; cc < 3; cc++) cand[(i * MAXADJ + a2) * 3 + cc] = mv.faces[fa[i][a2] * 3 + cc];
+        for(int i = 0; i < 3; i++)
+          for(int a2 = 0; a2 < cnt[i]; a2++)
+            for(int cc = 0; cc < 3; cc++)
+            {
+              const int v = cand[(i * MAXADJ + a2) * 3 + cc];
+              int slot = -1;
+              for(int q = 0; q < nr; q++)
+                if(ring[1 + q] == v) slot = q;
+              if(slot < 0 && nr < MAXRING)
+              {
+                slot = nr;
+                ring[1 + nr++] = v;
+              }
+              map[(i * MAXADJ + a2) * 3 + cc] = (uint8_t)(slot < 0 ? 0 : slot);
+            }
+      }
+      for(int q = 1; q <= nr; q++) ring_out[q] = ring[q];
+      ring_out[0] = nr;
+      ring_key[tb + k] = key;
+    }
+    ring[0] = nr;
+  }
+  __syncthreads();
+  __threadfence_block(); // a rebuilt map is read by other threads below
+  EVAL_STAMP(3);
+  if(dbg_stop == 23) return;
+  for(int item = tid; item < ntask * MAXRING; item += 256) // A1
+  {
+    const int t = item / MAXRING, q = item % MAXRING;
+    if(q < s_ringb[t][0])
+    {
+      const int v = s_ringb[t][1 + q];
+      s_rpos[t][q][0] = verts[v * 3];
+      s_rpos[t][q][1] = verts[v * 3 + 1];
+      s_rpos[t][q][2] = verts[v * 3 + 2];
+    }
+  }
+  __syncthreads();
+  EVAL_STAMP(4);
+  if(dbg_stop == 24) return;
+  if(tid < 3 * ntask) // A2: SMPL::calcVertexNormal (src/SMPL.cpp:527-535) with the adjacent faces' corners taken by ring slot
+  {
+    const int t = tid / 3, i = tid % 3, k = k_begin + t;
+    if(ta.noff[tb + k] > 0.0f || ta.nrmw[tb + k] > 0.0f)
+    {
+      const int u = s_ringb[t][1 + i];
+      const int b0 = mv.adjOff[u], cnt = mv.adjOff[u + 1] - b0;
+      float vn[3];
+      if(cnt > MAXADJ) // more faces than the ring map covers: the general routine
+        vertex_normal_dev(verts, mv.faces, mv.adjOff, mv.adjFace, u, vn);
+      else
+      {
+        const uint8_t * map = map_buf + (f * K + k) * (3 * MAXADJ * 3);
+        float sum = 0.0f;
+        for(int q = 0; q < cnt; q++) sum += 1.0f;
+        const float w = 1.0f / sum;
+        float acc[3] = {0.f, 0.f, 0.f};
+        for(int a2 = 0; a2 < cnt; a2++)
+        {
+          const uint8_t * mp = map + (i * MAXADJ + a2) * 3;
+          float fn[3];
+          face_normal_pts(s_rpos[t][mp[0]], s_rpos[t][mp[1]], s_rpos[t][mp[2]], fn);
+          acc[0] += w * fn[0];
+          acc[1] += w * fn[1];
+          acc[2] += w * fn[2];
+        }
+        normalize3(acc);
+        vn[0] = acc[0];
+        vn[1] = acc[1];
+        vn[2] = acc[2];
+      }
+      for(int x = 0; x < 3; x++) s_vn[t][i * 3 + x] = vn[x];
+    }
+  }
+  __syncthreads();
+  EVAL_STAMP(5);
+  if(dbg_stop == 25) return;
+  if(tid < ntask) // A3: every load first, every store last (a load behind a store waits for the store's round trip too)
+  {
+    const int k = k_begin + tid;
+    const float * vnk = s_vn[tid];
+    float tri[9];
+#pragma unroll
+    for(int i = 0; i < 3; i++)
+#pragma unroll
+      for(int x = 0; x < 3; x++) tri[i * 3 + x] = s_rpos[tid][i][x]; // ring slots 0..2 are the face's own vertices
+    const float off = ta.noff[tb + k], wp = ta.posw[tb + k], wn = ta.nrmw[tb + k];
+    float w[3] = {ta.vw[(tb + k) * 3], ta.vw[(tb + k) * 3 + 1], ta.vw[(tb + k) * 3 + 2]};
+    const float tp[3] = {ta.tpos[(tb + k) * 3], ta.tpos[(tb + k) * 3 + 1], ta.tpos[(tb + k) * 3 + 2]};
+    const float tn[3] = {ta.tnrm[(tb + k) * 3], ta.tnrm[(tb + k) * 3 + 1], ta.tnrm[(tb + k) * 3 + 2]};
+    // calcTangents (src/IkTask.cpp:33-47)
+    float t1[3] = {tri[3] - tri[0], tri[4] - tri[1], tri[5] - tri[2]};
+    float t2[3];
+    {
       float e2[3] = {tri[6] - tri[0], tri[7] - tri[1], tri[8] - tri[2]};
-      float nn[3], t2[3];
+      float nn[3];
       cross3(t1, e2, nn);
       cross3(nn, t1, t2);
       normalize3(t1);
       normalize3(t2);
-      for(int x = 0; x < 3; x++)
-      {
-        ta.tang[(tb + k) * 6 + x * 2 + 0] = t1[x];
-        ta.tang[(tb + k) * 6 + x * 2 + 1] = t2[x];
-      }
     }
-    float w[3] = {ta.vw[(tb + k) * 3], ta.vw[(tb + k) * 3 + 1], ta.vw[(tb + k) * 3 + 2]};
     float pos[3];
-    actual_pos_vn(mv, verts, face, w, off, vnk, pos);
-    for(int x = 0; x < 3; x++) pos804[(tb + k) * 3 + x] = pos[x]; // the point calcVertexWeights is differentiated at
-    triangle_weights_dev(pos, tri, w); // calcVertexWeights with phi_ == 0 (src/IkTask.cpp:49-57, node.cpp:804)
-    for(int i = 0; i < 3; i++) ta.vw[(tb + k) * 3 + i] = w[i];
+    actual_pos_tri(tri, w, off, vnk, pos); // the point calcVertexWeights is differentiated at
+    triangle_weights_dev(pos, tri, w);     // calcVertexWeights with phi_ == 0 (src/IkTask.cpp:49-57, node.cpp:804)
     float ap[3], an[3] = {0.f, 0.f, 0.f};
-    actual_pos_vn(mv, verts, face, w, off, vnk, ap);
+    actual_pos_tri(tri, w, off, vnk, ap);
     // the interpolated normal only when a term uses it, as node.cpp:811-819 does; smplpp_ik_get_tasks evaluates it on
     // demand for the others
     if(wn > 0.0f) actual_normal_vn(vnk, w, an);
-    for(int x = 0; x < 3; x++)
-    {
-      ta.apos[(tb + k) * 3 + x] = ap[x];
-      e_out[(f * K + k) * 4 + x] = (double)(wp * (ap[x] - ta.tpos[(tb + k) * 3 + x])); // node.cpp:807
-    }
+    double e3 = 0.0; // :819
     if(wn > 0.0f)
     {
-      const float dt = (an[0] * ta.tnrm[(tb + k) * 3] + an[1] * ta.tnrm[(tb + k) * 3 + 1]) + an[2] * ta.tnrm[(tb + k) * 3 + 2];
-      e_out[(f * K + k) * 4 + 3] = (double)(wn * (dt + 1.0f)); // :813-814
+      const float dt = (an[0] * tn[0] + an[1] * tn[1]) + an[2] * tn[2];
+      e3 = (double)(wn * (dt + 1.0f)); // :813-814
     }
-    else
-      e_out[(f * K + k) * 4 + 3] = 0.0; // :819
-    // ring: distinct vertices of the face and (when a normal is differentiated) of the faces around its vertices
-    int32_t * ring = ring_buf + (f * K + k) * (MAXRING + 1);
-    uint8_t * map = map_buf + (f * K + k) * (3 * MAXADJ * 3);
-    int nr = 0;
-    for(int i = 0; i < 3; i++) ring[1 + nr++] = mv.faces[face * 3 + i]; // slots 0..2 = the face's own vertices
-    if(use_normal)
-      for(int i = 0; i < 3; i++)
-      {
-        const int u = mv.faces[face * 3 + i];
-        const int b = mv.adjOff[u];
-        int cnt = mv.adjOff[u + 1] - b;
-        if(cnt > MAXADJ) cnt = MAXADJ;
-        for(int a = 0; a < cnt; a++)
-          for(int cc = 0; cc < 3; cc++)
-          {
-            const int v = mv.faces[mv.adjFace[b + a] * 3 + cc];
-            int slot = -1;
-            for(int q = 0; q < nr; q++)
-              if(ring[1 + q] == v) slot = q;
-            if(slot < 0 && nr < MAXRING)
-            {
-              slot = nr;
-              ring[1 + nr++] = v;
-            }
-            map[(i * MAXADJ + a) * 3 + cc] = (uint8_t)(slot < 0 ? 0 : slot);
-          }
-      }
-    ring[0] = nr;
+#pragma unroll
+    for(int x = 0; x < 3; x++)
+    {
+      ta.tang[(tb + k) * 6 + x * 2 + 0] = t1[x];
+      ta.tang[(tb + k) * 6 + x * 2 + 1] = t2[x];
+      pos804[(tb + k) * 3 + x] = pos[x];
+      ta.vw[(tb + k) * 3 + x] = w[x];
+      ta.apos[(tb + k) * 3 + x] = ap[x];
+      e_out[(f * K + k) * 4 + x] = (double)(wp * (ap[x] - tp[x])); // node.cpp:807
+    }
+    e_out[(f * K + k) * 4 + 3] = e3;
   }
+  EVAL_STAMP(6);
+  if(dbg_stop == 28) return;
   __syncthreads();
-  __threadfence_block();
 
   if(dbg_stop == 22) return;
   // ---- phase B: Jacobian rows (node.cpp:823-873).  Tasks are taken in GROUPS whose ring vertices fit the LDS buffers
@@ -419,13 +541,16 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
   __shared__ int s_roff[IK_MAXK + 1]; // ring offset of task k inside its group's buffers
   __shared__ int s_rtask[MAXRING];      // ring slot -> task
   __shared__ int s_rvert[MAXRING];      // ring slot -> vertex
+  __shared__ uint8_t s_map[3 * MAXADJ * 3]; // (vertex of the face, adjacent face, corner) -> ring slot, of a normal task
+  __shared__ int s_cnt[3];              // adjacent-face count of the face's three vertices
+  __shared__ float s_nrm[NQ * 3 * 6];   // per (column, triangle vertex): vertex normal (3) and its derivative (3)
   for(int k_lo = k_begin; k_lo < k_end;)
   {
     // group [k_lo, k_hi): greedy by ring size (every thread computes the same bounds)
     int k_hi = k_lo, total = 0;
     while(k_hi < k_end)
     {
-      const int nrk = ring_buf[(f * K + k_hi) * (MAXRING + 1)];
+      const int nrk = s_ringb[k_hi - k_begin][0];
       // a task with a normal term (ring > 3) keeps the vertex-normal scratch L_VN to itself: a group of its own
       if(k_hi > k_lo && (total + nrk > MAXRING || nrk > 3 || total > 3 * (k_hi - k_lo))) break;
       total += nrk;
@@ -434,8 +559,8 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
     if((int)tid >= k_lo && (int)tid < k_hi) // ring tables of the group
     {
       int off0 = 0;
-      for(int kk = k_lo; kk < (int)tid; kk++) off0 += ring_buf[(f * K + kk) * (MAXRING + 1)];
-      const int32_t * rg = ring_buf + (f * K + tid) * (MAXRING + 1);
+      for(int kk = k_lo; kk < (int)tid; kk++) off0 += s_ringb[kk - k_begin][0];
+      const int32_t * rg = s_ringb[tid - k_begin];
       s_roff[tid] = off0;
       for(int i = 0; i < rg[0]; i++)
       {
@@ -448,7 +573,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
     if(tid < total) // B1: per ring vertex rest position, blended rotation, blended w
     {
       const int v = s_rvert[tid];
-      float * rv = lds + L_RV + tid * 16;
+      float * rv = lds + L_RV + tid * RVS;
       rv[0] = rest[v * 3];
       rv[1] = rest[v * 3 + 1];
       rv[2] = rest[v * 3 + 2];
@@ -462,24 +587,40 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       }
       for(int q = 0; q < 9; q++) rv[3 + q] = Ab[q];
       rv[12] = mv.wSum[v];
+      for(int m = 0; m < 4; m++) // the (first four) skinning weights and joints, so that B2 does not re-read them per column
+      {
+        rv[16 + m] = (m < mv.maxw) ? mv.wVal[(int64_t)v * mv.maxw + m] : 0.0f;
+        rv[20 + m] = __int_as_float((m < mv.maxw) ? (int)mv.wIdx[(int64_t)v * mv.maxw + m] : 0);
+      }
+      rv[13] = verts[v * 3]; // posed position: the normal chain of B3 reads its triangles from here, not from HBM
+      rv[14] = verts[v * 3 + 1];
+      rv[15] = verts[v * 3 + 2];
+    }
+    else if(tid >= 64 && tid < 64 + 3 * MAXADJ * 3) // ring-slot map of the group's (single) normal task
+      s_map[tid - 64] = map_buf[(f * K + k_lo) * (3 * MAXADJ * 3) + (tid - 64)];
+    else if(tid >= 192 && tid < 195)
+    {
+      const int u = mv.faces[ta.face[tb + k_lo] * 3 + (tid - 192)];
+      s_cnt[tid - 192] = mv.adjOff[u + 1] - mv.adjOff[u];
     }
     __syncthreads();
     for(int item = tid; item < total * nq; item += 256) // B2: dp[rv][:, q]  
     {
       const int r_ = item / nq, q = item % nq;
       const int v = s_rvert[r_];
-      const float * rv = lds + L_RV + r_ * 16;
+      const float * rv = lds + L_RV + r_ * RVS;
       float acc[3] = {0.f, 0.f, 0.f};
       if(q < 3)
         acc[q] = rv[12]; // root translation: identity (divided by wsum below)
       else if(q < TD75)
       {
         const int c = q - 3, jc = c / 3;
+        const bool wlds = mv.maxw <= 4;
         for(int m = 0; m < mv.maxw; m++)
         {
-          const float wm = mv.wVal[(int64_t)v * mv.maxw + m];
+          const float wm = wlds ? rv[16 + m] : mv.wVal[(int64_t)v * mv.maxw + m];
           if(wm == 0.0f) continue;
-          const int i = mv.wIdx[(int64_t)v * mv.maxw + m];
+          const int i = wlds ? __float_as_int(rv[20 + m]) : (int)mv.wIdx[(int64_t)v * mv.maxw + m];
           const float * d = lds + L_DAB + (i * 12) * 72 + c;
           for(int r = 0; r < 3; r++)
             acc[r] += wm * (((d[(r * 4) * 72] * rv[0] + d[(r * 4 + 1) * 72] * rv[1]) + d[(r * 4 + 2) * 72] * rv[2]) + d[(r * 4 + 3) * 72]);
@@ -515,70 +656,82 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       for(int r = 0; r < 3; r++) lds[L_DP + (r_ * 3 + r) * NQ + q] = acc[r] / rv[12];
     }
     __syncthreads();
+    // B3n (a task with a normal term / offset is alone in its group): the derivative of each of the three vertex normals,
+    // one thread per (column, triangle vertex) — the chain n_f -> vn over ~6 adjacent faces is the long part of the
+    // kernel for such tasks, and only nq of the 256 threads worked when a column's thread walked all three vertices
+    const bool group_normal = (ta.noff[tb + k_lo] > 0.0f) || (ta.nrmw[tb + k_lo] > 0.0f); // uniform
+    if(group_normal) // d vertexNormal_i / dq  
+    {
+      const float * dp = lds + L_DP; // ring offset 0
+      for(int item = tid; item < nq * 3; item += 256)
+      {
+        const int q = item / 3, i = item % 3;
+        int cnt = s_cnt[i];
+        float sum = 0.f;
+        for(int a = 0; a < cnt; a++) sum += 1.0f;
+        const float aw = 1.0f / sum;
+        if(cnt > MAXADJ) cnt = MAXADJ;
+        float mu[3] = {0.f, 0.f, 0.f}, dmu[3] = {0.f, 0.f, 0.f};
+        for(int a = 0; a < cnt; a++)
+        {
+          // the adjacent face's corners by ring slot: positions staged in LDS by B1
+          const uint8_t * mp = s_map + (i * MAXADJ + a) * 3;
+          const float * p0 = lds + L_RV + mp[0] * RVS + 13;
+          const float * p1 = lds + L_RV + mp[1] * RVS + 13;
+          const float * p2 = lds + L_RV + mp[2] * RVS + 13;
+          const float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+          const float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+          float cr[3];
+          cross3(e1, e2, cr);
+          const float * d0 = dp + (mp[0] * 3) * NQ + q;
+          const float * d1 = dp + (mp[1] * 3) * NQ + q;
+          const float * d2 = dp + (mp[2] * 3) * NQ + q;
+          const float de1[3] = {d1[0] - d0[0], d1[NQ] - d0[NQ], d1[2 * NQ] - d0[2 * NQ]};
+          const float de2[3] = {d2[0] - d0[0], d2[NQ] - d0[NQ], d2[2 * NQ] - d0[2 * NQ]};
+          float t1[3], t2[3], dnf[3];
+          cross3(de1, e2, t1);
+          cross3(e1, de2, t2);
+          const float dc[3] = {t1[0] + t2[0], t1[1] + t2[1], t1[2] + t2[2]};
+          dnormalize_dev(cr, dc, dnf);
+          float cn = fmaxf(sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]), 1e-12f);
+          for(int x = 0; x < 3; x++)
+          {
+            mu[x] += aw * (cr[x] / cn);
+            dmu[x] += aw * dnf[x];
+          }
+        }
+        float dvn[3];
+        dnormalize_dev(mu, dmu, dvn);
+        const float mn = fmaxf(sqrtf(mu[0] * mu[0] + mu[1] * mu[1] + mu[2] * mu[2]), 1e-12f);
+        for(int x = 0; x < 3; x++)
+        {
+          const float vnx = mu[x] / mn;
+          s_nrm[(q * 3 + i) * 6 + x] = vnx;
+          s_nrm[(q * 3 + i) * 6 + 3 + x] = dvn[x];
+          if(q == 0) lds[L_VN + i * 3 + x] = vnx;
+        }
+      }
+      __syncthreads();
+    }
     for(int item = tid; item < (k_hi - k_lo) * nq; item += 256) // B3: one (task, differentiation column) per thread
     {
       const int k = k_lo + item / nq, q = item % nq;
-      const int face = ta.face[tb + k];
       const float off = ta.noff[tb + k], wp = ta.posw[tb + k], wn = ta.nrmw[tb + k];
       const bool use_normal = (off > 0.0f) || (wn > 0.0f);
-      const uint8_t * map = map_buf + (f * K + k) * (3 * MAXADJ * 3);
       const float w0 = ta.vw[(tb + k) * 3], w1 = ta.vw[(tb + k) * 3 + 1], w2 = ta.vw[(tb + k) * 3 + 2];
       double * Jk = J_out + ((f * K + k) * 4) * (int64_t)D;
       const float * dp = lds + L_DP + (s_roff[k] * 3) * NQ; // this task's ring rows
       float dn[3] = {0.f, 0.f, 0.f};
-      if(use_normal) // d actualNormal / dq  (SURVEY.md §9 item 7); such a task is alone in its group (ring offset 0)
+      if(use_normal) // d actualNormal / dq: the three vertex terms in order, as a single thread summed them
       {
         float msum[3] = {0.f, 0.f, 0.f}, dm[3] = {0.f, 0.f, 0.f};
         const float wv[3] = {w0, w1, w2};
         for(int i = 0; i < 3; i++)
-        {
-          const int u = mv.faces[face * 3 + i];
-          const int b = mv.adjOff[u];
-          int cnt = mv.adjOff[u + 1] - b;
-          float sum = 0.f;
-          for(int a = 0; a < cnt; a++) sum += 1.0f;
-          const float aw = 1.0f / sum;
-          if(cnt > MAXADJ) cnt = MAXADJ;
-          float mu[3] = {0.f, 0.f, 0.f}, dmu[3] = {0.f, 0.f, 0.f};
-          for(int a = 0; a < cnt; a++)
-          {
-            const int fa = mv.adjFace[b + a];
-            const float * p0 = verts + 3 * mv.faces[fa * 3];
-            const float * p1 = verts + 3 * mv.faces[fa * 3 + 1];
-            const float * p2 = verts + 3 * mv.faces[fa * 3 + 2];
-            const float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
-            const float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
-            float cr[3];
-            cross3(e1, e2, cr);
-            const uint8_t * mp = map + (i * MAXADJ + a) * 3;
-            const float * d0 = dp + (mp[0] * 3) * NQ + q;
-            const float * d1 = dp + (mp[1] * 3) * NQ + q;
-            const float * d2 = dp + (mp[2] * 3) * NQ + q;
-            const float de1[3] = {d1[0] - d0[0], d1[NQ] - d0[NQ], d1[2 * NQ] - d0[2 * NQ]};
-            const float de2[3] = {d2[0] - d0[0], d2[NQ] - d0[NQ], d2[2 * NQ] - d0[2 * NQ]};
-            float t1[3], t2[3], dnf[3];
-            cross3(de1, e2, t1);
-            cross3(e1, de2, t2);
-            const float dc[3] = {t1[0] + t2[0], t1[1] + t2[1], t1[2] + t2[2]};
-            dnormalize_dev(cr, dc, dnf);
-            float cn = fmaxf(sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]), 1e-12f);
-            for(int x = 0; x < 3; x++)
-            {
-              mu[x] += aw * (cr[x] / cn);
-              dmu[x] += aw * dnf[x];
-            }
-          }
-          float dvn[3];
-          dnormalize_dev(mu, dmu, dvn);
-          const float mn = fmaxf(sqrtf(mu[0] * mu[0] + mu[1] * mu[1] + mu[2] * mu[2]), 1e-12f);
           for(int x = 0; x < 3; x++)
           {
-            const float vnx = mu[x] / mn;
-            msum[x] += wv[i] * vnx;
-            dm[x] += wv[i] * dvn[x];
-            if(q == 0) lds[L_VN + i * 3 + x] = vnx;
+            msum[x] += wv[i] * s_nrm[(q * 3 + i) * 6 + x];
+            dm[x] += wv[i] * s_nrm[(q * 3 + i) * 6 + 3 + x];
           }
-        }
         dnormalize_dev(msum, dm, dn);
         if(q == 0)
           for(int x = 0; x < 3; x++) lds[L_VN + 9 + x] = msum[x];
@@ -662,6 +815,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
     __syncthreads();
     k_lo = k_hi;
   }
+  EVAL_STAMP(7);
 }
 
 __global__ void ik_actual_normals_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all, int K, int64_t nk)
@@ -674,6 +828,13 @@ __global__ void ik_actual_normals_kernel(ModelView mv, TaskArrays ta, const floa
   actual_normal_dev(mv, verts, ta.face[t], w, an);
   for(int x = 0; x < 3; x++) ta.anrm[t * 3 + x] = an[x];
 }
+
+#ifdef SMPLPP_EVAL_STAMPS
+extern "C" int smplpp_debug_eval_stamps(unsigned long long * out)
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(smplpp_hip::g_eval_stamps), sizeof(unsigned long long) * 64 * 16);
+}
+#endif
 
 // J over the 44-d latent layout from J over theta75 (node.cpp:761-772): columns 0..5 and 69..74 pass through,
 // columns 6..68 (joints 1..21) are pulled back through d(vposer out)/dz [63,32].
@@ -1564,6 +1725,7 @@ struct smplpp_ik
   float *verts = nullptr, *rest = nullptr, *joints = nullptr, *poserot = nullptr, *pts = nullptr;
   double *e = nullptr, *J = nullptr, *Jl = nullptr, *e2 = nullptr, *xout = nullptr;
   int32_t * ring = nullptr;
+  int32_t * ringkey = nullptr; // [n,K] 2 * face + uses-normal the cached ring / map of a task was built for (-1: none)
   uint8_t * map = nullptr;
   int *skip = nullptr, *status = nullptr, *list_cnt = nullptr, *list_f = nullptr;
   float * list_d = nullptr;
@@ -1661,6 +1823,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   A_(e2, (size_t)n);
   A_(xout, (size_t)n * Dmax);
   A_(ring, nk * (MAXRING + 1));
+  A_(ringkey, nk);
   A_(map, nk * 3 * MAXADJ * 3);
   A_(list_cnt, nk);
   A_(list_d, nk * PROJ_LIST);
@@ -1677,6 +1840,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   // IkTask defaults (include/smplpp/IkTask.h:54-84)
   auto grid = [](size_t c) { return dim3((unsigned)((c + 255) / 256)); };
   HIP_TRY(hipMemset(s->ta.face, 0, sizeof(int32_t) * nk));
+  HIP_TRY(hipMemset(s->ringkey, 0xFF, sizeof(int32_t) * nk));
   fill_f32_kernel<<<grid(nk * 3), 256>>>(s->ta.vw, 1.0f / 3.0f, nk * 3);
   fill_f32_kernel<<<grid(nk * 6), 256>>>(s->ta.tang, 0.0f, nk * 6);
   fill_f32_kernel<<<grid(nk * 3), 256>>>(s->ta.tpos, 0.0f, nk * 3);
@@ -1821,7 +1985,7 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   if(tsplit < 1) tsplit = 1;
   ik_eval_kernel<<<dim3((unsigned)(n * tsplit)), dim3(256), shmem, st>>>(view_of(m), s->ta, th25, s->verts, s->rest, m->ws.Gp.as<float>(),
                                                                        s->joints, s->poserot, K, optimize_beta, phi_live, (int)min_valid,
-                                                                       s->ring, s->map, s->pts, s->e, s->J, s->skip,
+                                                                       s->ring, s->ringkey, s->map, s->pts, s->e, s->J, s->skip,
                                                                        getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0, tsplit);
   HIP_TRY(hipGetLastError());
   if(s->vp)

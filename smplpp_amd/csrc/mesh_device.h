@@ -22,15 +22,16 @@ __device__ inline void normalize3(float * x)
 }
 
 // SMPL::calcNormal (src/SMPL.cpp:518-525)
-__device__ inline void face_normal_dev(const float * verts, const int32_t * faces, int face, float * nn)
+__device__ inline void face_normal_pts(const float * v0, const float * v1, const float * v2, float * nn)
 {
-  const float * v0 = verts + 3 * faces[face * 3 + 0];
-  const float * v1 = verts + 3 * faces[face * 3 + 1];
-  const float * v2 = verts + 3 * faces[face * 3 + 2];
   float a[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
   float b[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
   cross3(a, b, nn);
   normalize3(nn);
+}
+__device__ inline void face_normal_dev(const float * verts, const int32_t * faces, int face, float * nn)
+{
+  face_normal_pts(verts + 3 * faces[face * 3 + 0], verts + 3 * faces[face * 3 + 1], verts + 3 * faces[face * 3 + 2], nn);
 }
 
 // SMPL::calcVertexNormal (src/SMPL.cpp:527-535), uniform weights 1/deg (:630-639), ascending face id

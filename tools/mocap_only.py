@@ -18,3 +18,13 @@ torch.cuda.synchronize(); t = time.perf_counter()
 th, fr = ms.solve(pts, g["valid"], np.zeros(10, np.float32), th0)
 torch.cuda.synchronize(); dt = time.perf_counter() - t
 print("R=%d: %d frames in %.2f ms -> %.0f solved frames/s" % (R, len(fr), dt * 1e3, R * len(fr) / dt))
+if os.environ.get("SMPLPP_HIP_LIB", "").endswith("stamps.so"):
+    import ctypes
+    from smplpp_amd import _lib
+    L = _lib.load(); buf = (ctypes.c_ulonglong * (64 * 16))()
+    L.smplpp_debug_eval_stamps.restype = ctypes.c_int
+    assert L.smplpp_debug_eval_stamps(buf) == 0
+    T = np.array(buf, dtype=np.uint64).reshape(64, 16)[:, :8].astype(np.int64)
+    d = np.diff(T, axis=1)
+    print("eval phases (ticks, median over 64 workgroups of the LAST launch): const %d chain %d A0 %d A1 %d A2 %d A3 %d B %d ; total %d" % tuple(list(np.median(d, axis=0)) + [np.median(T[:, 7] - T[:, 0])]))
+    print("max over workgroups:", d.max(axis=0), (T[:, 7] - T[:, 0]).max())
