@@ -15,6 +15,8 @@
 #include "mesh_device.h"
 #include "staging.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -1265,9 +1267,11 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   if(skip[f])
   {
     if(tid == 0 && e2_out) e2_out[f] = 0.0;
-    for(int k = tid; k < K * 3; k += 256) pts[tb * 3 + k] = ta.apos[tb * 3 + k];
+    if(pts)
+      for(int k = tid; k < K * 3; k += 256) pts[tb * 3 + k] = ta.apos[tb * 3 + k];
     return;
   }
+  __builtin_amdgcn_s_setprio(3); // a latency chain: its few wavefronts issue ahead of the face scan that shares the CU
   const double * J = J_all + f * rows * (int64_t)D;
   for(int r = tid; r < rows; r += 256) ebuf[r] = e_all[f * rows + r];
   __syncthreads();
@@ -1511,7 +1515,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     if(ok) theta[f * theta_dim + i] += (float)xfull[i];
   for(int i = tid; i < beta_dim; i += 256)
     if(ok) beta[f * NB + i] += (float)xfull[theta_dim + 2 * K + i];
-  for(int i = tid; i < K * 3; i += 256) // p_k = actualPos_k + tangents_k . x_phi_k (:956-959)
+  for(int i = tid; pts && i < K * 3; i += 256) // p_k = actualPos_k + tangents_k . x_phi_k (:956-959); null: x_phi = 0 for all
   {
     const int k = i / 3, x = i % 3;
     const float p0 = ok ? (float)xfull[theta_dim + 2 * k] : 0.0f, p1 = ok ? (float)xfull[theta_dim + 2 * k + 1] : 0.0f;
@@ -1731,6 +1735,19 @@ struct smplpp_ik
   float * list_d = nullptr;
   std::vector<void *> owned;
   bool have_eval = false;
+  // re-projection beside the solve: when no task's surface coordinates can move (phiLimit_ <= 0 everywhere, or the
+  // motion stage's forced zero, node.cpp:699) the query points are the actual positions the evaluation already wrote,
+  // so the face scan does not depend on the solve and runs on a second stream while the solve is in flight
+  // The posed mesh is double-buffered so that the side stream can still read iteration i's mesh (scan + finish) while the
+  // main stream already writes iteration i+1's; the join sits in front of iteration i+1's evaluation, the first kernel that
+  // reads what the finish kernel wrote (face, weights). Both events ride on a kernel's own completion signal
+  // (hipExtLaunchKernelGGL): a separate hipEventRecord costs the recording stream ~7 us per iteration.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool phi_locked = false;
+  bool side_pending = false; // a finish kernel is in flight on the side stream; ev_join marks its end
+  float * vbuf[2] = {nullptr, nullptr};
+  int vcur = 0;
 };
 
 template<class T>
@@ -1763,6 +1780,10 @@ extern "C" int smplpp_ik_destroy(smplpp_ik * s)
 {
   if(!s) return SMPLPP_OK;
   (void)hipSetDevice(s->m->device);
+  if(s->side) (void)hipStreamSynchronize(s->side);
+  if(s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  if(s->ev_join) (void)hipEventDestroy(s->ev_join);
+  if(s->side) (void)hipStreamDestroy(s->side);
   for(void * p : s->owned) (void)hipFree(p);
   delete s;
   return SMPLPP_OK;
@@ -1813,7 +1834,8 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   A_(theta, (size_t)n * s->theta_dim);
   A_(beta, (size_t)n * NB);
   A_(theta25, (size_t)n * 75);
-  A_(verts, (size_t)n * m->V * 3);
+  A_(vbuf[0], (size_t)n * m->V * 3);
+  A_(vbuf[1], (size_t)n * m->V * 3);
   A_(rest, (size_t)n * m->V * 3);
   A_(joints, (size_t)n * NJ * 3);
   A_(poserot, (size_t)n * NJ * 9);
@@ -1854,6 +1876,10 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   HIP_TRY(hipMemset(s->skip, 0, sizeof(int) * n));
   HIP_TRY(hipMemset(s->list_cnt, 0, sizeof(int) * nk));
   HIP_TRY(hipMemset(s->status, 0, sizeof(int) * n));
+  s->verts = s->vbuf[0];
+  HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   HIP_TRY(hipDeviceSynchronize());
   *out = s;
   return SMPLPP_OK;
@@ -1896,6 +1922,14 @@ extern "C" int smplpp_ik_set_tasks(smplpp_ik * s, const int64_t * face_idx, cons
   if((rc = set_array(normal_task_weight, s->ta.nrmw, nk, space, cvd))) return rc;
   if((rc = set_array(phi_limit, s->ta.philim, nk, space, cvd))) return rc;
   if((rc = set_array(normal_offset, s->ta.noff, nk, space, cvd))) return rc;
+  if(phi_limit)
+  {
+    std::vector<float> h(nk);
+    HIP_TRY(hipMemcpy(h.data(), s->ta.philim, sizeof(float) * nk, hipMemcpyDeviceToHost));
+    bool locked = true;
+    for(size_t i = 0; i < nk && locked; i++) locked = !(h[i] > 0.0f);
+    s->phi_locked = locked;
+  }
   return SMPLPP_OK;
 }
 
@@ -1958,7 +1992,7 @@ extern "C" int smplpp_ik_get_tasks(smplpp_ik * s, int64_t * face_idx, float * ve
 }
 
 // forward + eval for all frames (enqueue only)
-static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64_t min_valid, hipStream_t st)
+static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64_t min_valid, hipStream_t st, hipEvent_t eval_done = nullptr)
 {
   smplpp_model * m = s->m;
   const int64_t n = s->n;
@@ -1971,8 +2005,15 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
     ik_splice_kernel<<<dim3((unsigned)((n * 75 + 255) / 256)), 256, 0, st>>>(s->theta, s->vout, s->theta25, n);
     th25 = s->theta25;
   }
+  s->vcur ^= 1;
+  s->verts = s->vbuf[s->vcur];
   int rc = fk_device(m, n, s->beta, th25, s->verts, s->joints, nullptr, s->rest, s->poserot, st); // node.cpp:777
   if(rc) return rc;
+  if(s->side_pending) // the previous iteration's re-projection (side stream) wrote the faces / weights read from here on
+  {
+    HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
+    s->side_pending = false;
+  }
   const size_t shmem = sizeof(float) * L_END + L_ANC_BYTES;
   static bool attr = false;
   if(!attr)
@@ -1983,10 +2024,10 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   int tsplit = (n < 256) ? (int)(256 / n) : 1; // one round of workgroups (one per CU: 83 KB of LDS each)
   if(tsplit > K) tsplit = K;
   if(tsplit < 1) tsplit = 1;
-  ik_eval_kernel<<<dim3((unsigned)(n * tsplit)), dim3(256), shmem, st>>>(view_of(m), s->ta, th25, s->verts, s->rest, m->ws.Gp.as<float>(),
-                                                                       s->joints, s->poserot, K, optimize_beta, phi_live, (int)min_valid,
-                                                                       s->ring, s->ringkey, s->map, s->pts, s->e, s->J, s->skip,
-                                                                       getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0, tsplit);
+  hipExtLaunchKernelGGL(ik_eval_kernel, dim3((unsigned)(n * tsplit)), dim3(256), shmem, st, nullptr, eval_done, 0, view_of(m), s->ta, th25,
+                        (const float *)s->verts, (const float *)s->rest, (const float *)m->ws.Gp.as<float>(), (const float *)s->joints,
+                        (const float *)s->poserot, K, optimize_beta, phi_live, (int)min_valid, s->ring, s->ringkey, s->map, s->pts, s->e,
+                        s->J, s->skip, getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0, tsplit);
   HIP_TRY(hipGetLastError());
   if(s->vp)
   {
@@ -2031,6 +2072,9 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
     attr = true;
   }
   const bool dbg = getenv("SMPLPP_DEBUG_SYNC") != nullptr;
+  const int dbg_stop = getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0;
+  const char * ov = getenv("SMPLPP_IK_OVERLAP"); // dev switch: 0 keeps the scan behind the solve
+  const bool overlap_ok = !(ov && ov[0] == '0') && !dbg;
 #define DBG_SYNC(tag)                                                            \
   if(dbg)                                                                        \
   {                                                                              \
@@ -2042,7 +2086,10 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
   {
     const int opt_beta = (optimize_beta_from >= 0 && it >= optimize_beta_from) ? 1 : 0; // node.cpp:655
     const int phi_live = (optimize_beta_from >= 0) ? (it >= optimize_beta_from ? 1 : 0) : 1; // :693-700
-    rc = ik_forward_eval(s, opt_beta, phi_live, min_valid, st);
+    // x_phi = 0 for every task (no task's surface coordinates can move): the query points are the actual positions the
+    // evaluation wrote, so scan + finish run on the side stream beside the solve and the next iteration's pose / FK
+    const bool beside = overlap_ok && (!phi_live || s->phi_locked);
+    rc = ik_forward_eval(s, opt_beta, phi_live, min_valid, st, beside ? s->ev_fork : nullptr);
     if(rc) return rc;
     DBG_SYNC("forward+eval");
     const int beta_dim = opt_beta ? NB : 0;
@@ -2054,18 +2101,24 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
     if(chunk_rows > rows) chunk_rows = rows;
     if(chunk_rows < 4) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_iterate: system too large for the in-LDS solver");
     const size_t solve_shmem = fixed + sizeof(double) * (size_t)chunk_rows * D;
-    ik_solve_kernel<<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, s->pts, K,
-                                                                        s->theta_dim, beta_dim, phi_live, enable_qp, s->vp ? 1 : 0,
-                                                                        chunk_rows, s->skip, s->e2, s->status, s->xout,
-                                                                        getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0);
+    ik_solve_kernel<<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta,
+                                                                        beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live,
+                                                                        enable_qp, s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status,
+                                                                        s->xout, dbg_stop);
     HIP_TRY(hipGetLastError());
     DBG_SYNC("solve");
     {
+      const float * qpts = beside ? s->ta.apos : s->pts;
+      hipStream_t pst = st;
+      if(beside)
+      {
+        HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+        pst = s->side;
+      }
       int chunks = (int)(1536 / s->n);
       chunks = chunks < 1 ? 1 : (chunks > 32 ? 32 : chunks);
-      proj_scan_kernel<<<dim3((unsigned)(s->n * chunks)), dim3(256), 0, st>>>(view_of(m), s->ta, s->verts, s->pts, m->F, K, chunks, s->skip,
-                                                                            s->list_cnt, s->list_d, s->list_f,
-                                                                            getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0);
+      proj_scan_kernel<<<dim3((unsigned)(s->n * chunks)), dim3(256), 0, pst>>>(view_of(m), s->ta, s->verts, qpts, m->F, K, chunks, s->skip,
+                                                                             s->list_cnt, s->list_d, s->list_f, dbg_stop);
       HIP_TRY(hipGetLastError());
       static int * dbg_buf = nullptr;
       if(dbg && !dbg_buf) HIP_TRY(hipMalloc((void **)&dbg_buf, sizeof(int) * 8));
@@ -2073,9 +2126,11 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
       int fsplit = (s->n < 256) ? (int)(256 / s->n) : 1;
       if(fsplit > K) fsplit = K;
       if(fsplit < 1) fsplit = 1;
-      proj_finish_kernel<<<dim3((unsigned)(s->n * fsplit)), dim3(256), 0, st>>>(view_of(m), s->ta, s->verts, s->pts, m->F, K, s->skip, s->list_cnt,
-                                                                              s->list_d, s->list_f, dbg ? dbg_buf : nullptr, fsplit);
+      hipExtLaunchKernelGGL(proj_finish_kernel, dim3((unsigned)(s->n * fsplit)), dim3(256), 0, pst, nullptr, beside ? s->ev_join : nullptr, 0,
+                            view_of(m), s->ta, (const float *)s->verts, qpts, m->F, K, (const int *)s->skip, s->list_cnt, s->list_d,
+                            s->list_f, dbg ? dbg_buf : (int *)nullptr, fsplit);
       HIP_TRY(hipGetLastError());
+      if(beside) s->side_pending = true;
       if(dbg)
       {
         int h[8];
@@ -2086,6 +2141,11 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
     DBG_SYNC("project");
   }
 #undef DBG_SYNC
+  if(s->side_pending) // everything the caller does next on its stream is ordered behind the last re-projection
+  {
+    HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
+    s->side_pending = false;
+  }
   if(e_sqnorm)
   {
     hipMemcpyKind kind = space == SMPLPP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
