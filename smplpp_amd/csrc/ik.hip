@@ -1019,6 +1019,132 @@ __device__ inline void stage_rows(double * dst, const double * __restrict__ src,
   }
 }
 
+// Dual form of the damped free-set system for FEWER RESIDUAL ROWS THAN FREE UNKNOWNS (r = 4K < nf; the 6-target solve has
+// r = 24 against 75): with G = the diagonal damping (> 0, node.cpp:887-904) and J_F the free columns,
+//   (G + J_F' J_F)^-1 c = G^-1 c - G^-1 J_F' (I + J_F G^-1 J_F')^-1 J_F G^-1 c
+// so the Cholesky factorisation is r x r instead of nf x nf — the same x = -LLT(A)^-1 b of node.cpp:933-938 to fp64
+// round-off (S = I + Jf Jf' with Jf = J_F G^-1/2 is at least as well conditioned as A). Steps: gather the free columns
+// into LDS (eight loads in flight), c / u = G^-1 c and the column scaling (one thread per column), S and v = J u (one
+// element per thread), factorisation + both substitutions inside ONE wavefront (left-looking on the packed LDS matrix with
+// v as the augmented last row; pivots travel by v_readlane, no workgroup barrier per column), x = u - G^-1/2 Jf' w.
+// Returns A^-1 c in xs[0..nf) like back_subst(). Needs r <= 63, r * nf doubles in Jf, nf in us/ginv, r in w.
+__device__ inline void solve_dual(double * M, const double * __restrict__ J, const double * rowv, double * Jf, const double * diag,
+                                  const double * bpri, const int * idx, int nf, int D, int r, double * ginv, double * us, double * w,
+                                  double * xs, int * bad)
+{
+  const int tid = threadIdx.x;
+  const int cnt = r * nf;
+  for(int q0 = 0; q0 < cnt; q0 += 256 * 8)
+  {
+    double t[8];
+#pragma unroll
+    for(int u = 0; u < 8; u++)
+    {
+      int q = q0 + u * 256 + tid;
+      q = q < cnt ? q : cnt - 1;
+      const int i = q / nf, a = q - i * nf;
+      t[u] = J[(int64_t)i * D + idx[a]];
+    }
+#pragma unroll
+    for(int u = 0; u < 8; u++)
+    {
+      const int q = q0 + u * 256 + tid;
+      if(q < cnt) Jf[q] = t[u];
+    }
+  }
+  __syncthreads();
+  if(tid < nf)
+  {
+    const int a = tid, q = idx[a];
+    double c = bpri[q];
+    for(int i = 0; i < r; i++) c += Jf[i * nf + a] * rowv[i];
+    const double gi = 1.0 / diag[q];
+    const double sg = sqrt(gi);
+    ginv[a] = gi;
+    xs[a] = c * gi;  // u
+    us[a] = c * sg;  // u / sg: v = J u = Jf (u / sg)
+    for(int i = 0; i < r; i++) Jf[i * nf + a] *= sg;
+  }
+  __syncthreads();
+  {
+    const int nitem = (r + 1) * (r + 2) / 2 - 1; // rows 0..r of the packed lower triangle; the (r, r) corner is never used
+    for(int item = tid; item < nitem; item += 256)
+    {
+      int i, j;
+      tri_unpack(item, i, j);
+      const double * a = (i < r) ? Jf + i * nf : us;
+      const double * b = Jf + j * nf;
+      double s0 = (i == j) ? 1.0 : 0.0, s1 = 0.0;
+      int q = 0;
+      for(; q + 1 < nf; q += 2)
+      {
+        s0 += a[q] * b[q];
+        s1 += a[q + 1] * b[q + 1];
+      }
+      if(q < nf) s0 += a[q] * b[q];
+      M[item] = s0 + s1;
+    }
+  }
+  __syncthreads();
+  if(tid < 64)
+  {
+    const int i = tid;
+    const bool act = i <= r;
+    const double * Li = M + tri_idx(act ? i : 0, 0);
+    double myrinv = 0.0;
+    bool badl = false;
+    for(int k0 = 0; k0 < r; k0++)
+    {
+      const int k = __builtin_amdgcn_readfirstlane(k0);
+      const double * Lk = M + tri_idx(k, 0);
+      double s = 0.0;
+      if(act && i >= k)
+      {
+        double s1 = 0.0;
+        s = Li[k];
+        int m = 0;
+        for(; m + 1 < k; m += 2)
+        {
+          s -= Li[m] * Lk[m];
+          s1 -= Li[m + 1] * Lk[m + 1];
+        }
+        if(m < k) s -= Li[m] * Lk[m];
+        s += s1;
+      }
+      double piv = readlane_f64(s, k);
+      if(!(piv > 0.0))
+      {
+        badl = true;
+        piv = 1.0;
+      }
+      const double ri = fast_rsqrt(piv);
+      if(act && i >= k) M[tri_idx(i, k)] = (i == k) ? piv * ri : s * ri;
+      if(i == k) myrinv = ri;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+    }
+    double yv = (i < r) ? M[tri_idx(r, i)] : 0.0; // y = L^-1 v (the augmented row)
+    for(int k0 = r - 1; k0 >= 0; k0--)
+    {
+      const int k = __builtin_amdgcn_readfirstlane(k0);
+      const double lk = (i < k) ? M[tri_idx(k, 0) + i] : 0.0;
+      const double wk = readlane_f64(yv, k) * readlane_f64(myrinv, k);
+      yv = (i == k) ? wk : yv - lk * wk;
+    }
+    if(i < r) w[i] = yv;
+    if(badl && tid == 0) *bad = 1;
+  }
+  __syncthreads();
+  if(tid < nf)
+  {
+    const int a = tid;
+    double t = 0.0;
+    for(int i = 0; i < r; i++) t += Jf[i * nf + a] * w[i];
+    xs[a] = xs[a] - sqrt(ginv[a]) * t;
+  }
+  __syncthreads();
+}
+
 // Register-tiled build + factorisation of the augmented free-set system for nf + 1 <= 16 * NT: thread (ty, tx) of the
 // 16 x 16 workgroup owns the elements (ty + 16a, tx + 16b), b <= a, in registers.  Per column ONE barrier: the column's
 // holders publish its raw entries (and the pivot entry) to LDS, every thread then applies the rank-1 update to its own
@@ -1382,7 +1508,13 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
           if(state[q] == -1 || state[q] == 1) s += J[(int64_t)r * D + q] * xfull[q];
       rowv[r] = s;
     }
-    if(nf + 1 <= 96)
+    const bool dual = rows < nf && rows <= 63 && chunk_rows >= rows && nf <= 192 && dbg_stop != 9;
+    if(dual)
+    {
+      __syncthreads();
+      solve_dual(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, dinv, lraw, lraw + 192, xs, &s_bad);
+    }
+    else if(nf + 1 <= 96)
     {
       // small systems (every mode except the 41-marker body solve): registers, one barrier per column
       __syncthreads();
@@ -1427,7 +1559,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       chol_aug(M, nf, &s_bad, dinv);
     }
     if(dbg_stop == 2) return;
-    back_subst(M, nf, xs, dinv);
+    if(!dual) back_subst(M, nf, xs, dinv);
     if(dbg_stop == 3) return;
     if(!enable_qp)
     {
@@ -2075,6 +2207,7 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
   const int dbg_stop = getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0;
   const char * ov = getenv("SMPLPP_IK_OVERLAP"); // dev switch: 0 keeps the scan behind the solve
   const bool overlap_ok = !(ov && ov[0] == '0') && !dbg;
+  const int64_t scan_blocks = getenv("SMPLPP_SCAN_BLOCKS") ? atoll(getenv("SMPLPP_SCAN_BLOCKS")) : 1536; // dev switch
 #define DBG_SYNC(tag)                                                            \
   if(dbg)                                                                        \
   {                                                                              \
@@ -2115,7 +2248,7 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
         HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
         pst = s->side;
       }
-      int chunks = (int)(1536 / s->n);
+      int chunks = (int)(scan_blocks / s->n);
       chunks = chunks < 1 ? 1 : (chunks > 32 ? 32 : chunks);
       proj_scan_kernel<<<dim3((unsigned)(s->n * chunks)), dim3(256), 0, pst>>>(view_of(m), s->ta, s->verts, qpts, m->F, K, chunks, s->skip,
                                                                              s->list_cnt, s->list_d, s->list_f, dbg_stop);

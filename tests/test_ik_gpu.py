@@ -251,3 +251,67 @@ def test_ik_many_frames_surface_queries(smpl, oracle_synth, synth_model):
     _, theta = s.getConfig()
     assert np.isfinite(theta).all() and np.isfinite(e2b).all()
     assert np.median(e2b) < 0.05 * np.median(e2)
+
+
+def _run_ik(smpl, g, n, iters, env, monkeypatch, **kw):
+    """theta / beta / faces after `iters` iterations from seeded perturbed starts under the given environment switches."""
+    from smplpp_amd.ik import IkSolver
+
+    for k in ("SMPLPP_IK_DBG_STOP", "SMPLPP_IK_OVERLAP"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    K = len(g["face_idx"])
+    rng = np.random.default_rng(11)
+    theta0 = np.tile(g["traj_theta"][0], (n, 1, 1)) + rng.normal(0, 0.05, (n, 25, 3)).astype(np.float32)
+    s = IkSolver(smpl, n, K)
+    s.setTasks(face_idx=g["face_idx"], target_pos=g["target_pos"], target_normal=g["target_normal"], **kw.get("tasks", {}))
+    s.setConfig(np.zeros((n, 10), np.float32), theta0)
+    e2 = s.iterate(iters, **kw.get("iterate", {}))
+    beta, theta = s.getConfig()
+    t = s.getTasks()
+    return theta, beta, t["face_idx"], t["vertex_weights"], e2
+
+
+def test_ik_reprojection_beside_the_solve_is_bit_identical(smpl, golden_ik_synth, monkeypatch):
+    """With every phiLimit_ <= 0 the face scan + finish run on a second stream beside the solve and the next pose / FK
+    (double-buffered mesh). Same kernels, different schedule: results must match the single-stream order bit for bit."""
+    K = len(golden_ik_synth["face_idx"])
+    kw = {"tasks": {"phi_limit": np.zeros(K)}}
+    a = _run_ik(smpl, golden_ik_synth, 96, 12, {"SMPLPP_IK_OVERLAP": "0"}, monkeypatch, **kw)
+    b = _run_ik(smpl, golden_ik_synth, 96, 12, {}, monkeypatch, **kw)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    # one iteration per call (the capture-fitting driver's pattern): the join at the end of every call
+    for k in ("SMPLPP_IK_DBG_STOP", "SMPLPP_IK_OVERLAP"):
+        monkeypatch.delenv(k, raising=False)
+    from smplpp_amd.ik import IkSolver
+
+    rng = np.random.default_rng(11)
+    theta0 = np.tile(golden_ik_synth["traj_theta"][0], (96, 1, 1)) + rng.normal(0, 0.05, (96, 25, 3)).astype(np.float32)
+    s = IkSolver(smpl, 96, K)
+    s.setTasks(face_idx=golden_ik_synth["face_idx"], target_pos=golden_ik_synth["target_pos"],
+               target_normal=golden_ik_synth["target_normal"], phi_limit=np.zeros(K))
+    s.setConfig(np.zeros((96, 10), np.float32), theta0)
+    for _ in range(12):
+        s.iterate(1)
+    assert np.array_equal(s.getConfig()[1], a[0])
+    assert np.array_equal(s.getTasks()["face_idx"], a[2])
+
+
+@pytest.mark.parametrize("mode", ["llt", "box_qp"])
+def test_ik_dual_form_solve_matches_the_primal_factorisation(smpl, golden_ik_synth, monkeypatch, mode):
+    """With fewer residual rows than free unknowns (4K = 24 < 75) the solve factorises I + J G^-1 J' (24 x 24) instead of
+    G + J'J; SMPLPP_IK_DBG_STOP=9 forces the primal form. Same step to fp64 round-off: fp32 angles within a few ulp."""
+    K = len(golden_ik_synth["face_idx"])
+    if mode == "llt":
+        kw = {"tasks": {"phi_limit": np.zeros(K)}}
+    else:  # phi live and bounded, beta bounded: the dual form inside every active-set pass
+        kw = {"tasks": {"phi_limit": np.full(K, 0.04), "normal_offset": np.full(K, 0.015), "normal_task_weight": np.zeros(K)},
+              "iterate": {"enable_qp": True, "optimize_beta_from": 0}}
+    a = _run_ik(smpl, golden_ik_synth, 8, 1, {"SMPLPP_IK_DBG_STOP": "9"}, monkeypatch, **kw)
+    b = _run_ik(smpl, golden_ik_synth, 8, 1, {}, monkeypatch, **kw)
+    assert np.abs(a[0] - b[0]).max() < 2e-6
+    assert np.abs(a[1] - b[1]).max() < 2e-6
+    assert np.array_equal(a[2], b[2])
+    assert np.abs(a[4] - b[4]).max() == 0
