@@ -50,6 +50,7 @@ struct TaskArrays
   float * noff;    // [n,K]
   float * apos;    // [n,K,3]
   float * anrm;    // [n,K,3]
+  float * hint;    // [n,K] squared distance of the actual position to the task's own face (cull radius of the re-projection)
 };
 
 struct ModelView
@@ -530,6 +531,9 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       e_out[(f * K + k) * 4 + x] = (double)(wp * (ap[x] - tp[x])); // node.cpp:807
     }
     e_out[(f * K + k) * 4 + 3] = e3;
+    // the re-projection's cull radius when the query point is the actual position (no surface coordinate can move): the
+    // exact distance to the task's own face, from the vertices already in registers (same evaluation as the scan's)
+    ta.hint[tb + k] = tri_sqdist_vals(tri[0], tri[1], tri[2], tri[3], tri[4], tri[5], tri[6], tri[7], tri[8], ap[0], ap[1], ap[2]).x;
   }
   EVAL_STAMP(6);
   if(dbg_stop == 28) return;
@@ -1019,6 +1023,117 @@ __device__ inline void stage_rows(double * dst, const double * __restrict__ src,
   }
 }
 
+// Factorisation + both substitutions of the packed (r + 1) x (r + 1) augmented matrix [S v; v' *] by ONE wavefront, lane i
+// owning row i. Register form (r <= RMAX <= 32): the row lives in registers, a column's entries reach the other lanes by
+// v_readlane (an SGPR operand of the FMA), so a column costs its pivot's rsqrt plus (r - k) FMAs and no LDS round trip;
+// the factor is written back packed and re-read by columns (independent loads, hoisted) for the back substitution, whose
+// chain is then readlane + FMA only. w[0..r) = S^-1 v.
+template<int RMAX>
+__device__ inline void chol_wave_reg(double * M, int r, double * w, int * bad)
+{
+  const int i = threadIdx.x; // < 64
+  const bool act = i <= r;
+  double row[RMAX];
+#pragma unroll
+  for(int j = 0; j < RMAX; j++) row[j] = (act && j <= i && j < r) ? M[tri_idx(i, j)] : 0.0;
+  double myrinv = 0.0;
+  bool badl = false;
+#pragma unroll
+  for(int k = 0; k < RMAX; k++)
+  {
+    if(k < r) // uniform
+    {
+      double piv = readlane_f64(row[k], k);
+      if(!(piv > 0.0))
+      {
+        badl = true;
+        piv = 1.0;
+      }
+      const double ri = fast_rsqrt(piv);
+      const double l = row[k] * ri; // lane k: sqrt(piv); lanes below the diagonal: L[i][k]; the rhs lane r: y[k]
+      row[k] = l;
+      if(i == k) myrinv = ri;
+#pragma unroll
+      for(int j = k + 1; j < RMAX; j++) row[j] = fma(-l, readlane_f64(l, j), row[j]);
+    }
+  }
+#pragma unroll
+  for(int j = 0; j < RMAX; j++)
+    if(act && j <= i && j < r) M[tri_idx(i, j)] = row[j];
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  double col[RMAX + 1]; // col[k] = L[k][i] for k > i (k == r: y[i])
+  col[0] = 0.0;
+#pragma unroll
+  for(int k = 1; k <= RMAX; k++) col[k] = (i < k && k <= r && i < r) ? M[tri_idx(k, i)] : 0.0;
+  double acc = 0.0;
+#pragma unroll
+  for(int k = RMAX; k >= 1; k--)
+    if(k == r) acc = col[k];
+#pragma unroll
+  for(int k = RMAX - 1; k >= 0; k--)
+  {
+    if(k < r) // uniform
+    {
+      const double wk = readlane_f64(acc, k) * readlane_f64(myrinv, k);
+      acc = (i == k) ? wk : fma(-col[k], wk, acc); // col[k] is 0 for lanes i >= k
+    }
+  }
+  if(i < r) w[i] = acc;
+  if(badl && i == 0) *bad = 1;
+}
+
+// LDS form for 32 < r <= 63 (left-looking on the packed matrix)
+__device__ inline void chol_wave_lds(double * M, int r, double * w, int * bad)
+{
+  const int tid = threadIdx.x;
+  const int i = tid;
+  const bool act = i <= r;
+  const double * Li = M + tri_idx(act ? i : 0, 0);
+  double myrinv = 0.0;
+  bool badl = false;
+  for(int k0 = 0; k0 < r; k0++)
+  {
+    const int k = __builtin_amdgcn_readfirstlane(k0);
+    const double * Lk = M + tri_idx(k, 0);
+    double s = 0.0;
+    if(act && i >= k)
+    {
+      double s1 = 0.0;
+      s = Li[k];
+      int m = 0;
+      for(; m + 1 < k; m += 2)
+      {
+        s -= Li[m] * Lk[m];
+        s1 -= Li[m + 1] * Lk[m + 1];
+      }
+      if(m < k) s -= Li[m] * Lk[m];
+      s += s1;
+    }
+    double piv = readlane_f64(s, k);
+    if(!(piv > 0.0))
+    {
+      badl = true;
+      piv = 1.0;
+    }
+    const double ri = fast_rsqrt(piv);
+    if(act && i >= k) M[tri_idx(i, k)] = (i == k) ? piv * ri : s * ri;
+    if(i == k) myrinv = ri;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+  double yv = (i < r) ? M[tri_idx(r, i)] : 0.0; // y = L^-1 v (the augmented row)
+  for(int k0 = r - 1; k0 >= 0; k0--)
+  {
+    const int k = __builtin_amdgcn_readfirstlane(k0);
+    const double lk = (i < k) ? M[tri_idx(k, 0) + i] : 0.0;
+    const double wk = readlane_f64(yv, k) * readlane_f64(myrinv, k);
+    yv = (i == k) ? wk : yv - lk * wk;
+  }
+  if(i < r) w[i] = yv;
+  if(badl && tid == 0) *bad = 1;
+}
+
 // Dual form of the damped free-set system for FEWER RESIDUAL ROWS THAN FREE UNKNOWNS (r = 4K < nf; the 6-target solve has
 // r = 24 against 75): with G = the diagonal damping (> 0, node.cpp:887-904) and J_F the free columns,
 //   (G + J_F' J_F)^-1 c = G^-1 c - G^-1 J_F' (I + J_F G^-1 J_F')^-1 J_F G^-1 c
@@ -1030,7 +1145,7 @@ __device__ inline void stage_rows(double * dst, const double * __restrict__ src,
 // Returns A^-1 c in xs[0..nf) like back_subst(). Needs r <= 63, r * nf doubles in Jf, nf in us/ginv, r in w.
 __device__ inline void solve_dual(double * M, const double * __restrict__ J, const double * rowv, double * Jf, const double * diag,
                                   const double * bpri, const int * idx, int nf, int D, int r, double * ginv, double * us, double * w,
-                                  double * xs, int * bad)
+                                  double * xs, int * bad, int dbg_stop)
 {
   const int tid = threadIdx.x;
   const int cnt = r * nf;
@@ -1053,6 +1168,7 @@ __device__ inline void solve_dual(double * M, const double * __restrict__ J, con
     }
   }
   __syncthreads();
+  if(dbg_stop == 31) return; // (timing experiments only)
   if(tid < nf)
   {
     const int a = tid, q = idx[a];
@@ -1066,6 +1182,7 @@ __device__ inline void solve_dual(double * M, const double * __restrict__ J, con
     for(int i = 0; i < r; i++) Jf[i * nf + a] *= sg;
   }
   __syncthreads();
+  if(dbg_stop == 32) return;
   {
     const int nitem = (r + 1) * (r + 2) / 2 - 1; // rows 0..r of the packed lower triangle; the (r, r) corner is never used
     for(int item = tid; item < nitem; item += 256)
@@ -1086,55 +1203,20 @@ __device__ inline void solve_dual(double * M, const double * __restrict__ J, con
     }
   }
   __syncthreads();
+  if(dbg_stop == 33) return;
   if(tid < 64)
   {
-    const int i = tid;
-    const bool act = i <= r;
-    const double * Li = M + tri_idx(act ? i : 0, 0);
-    double myrinv = 0.0;
-    bool badl = false;
-    for(int k0 = 0; k0 < r; k0++)
+    switch((r + 7) >> 3)
     {
-      const int k = __builtin_amdgcn_readfirstlane(k0);
-      const double * Lk = M + tri_idx(k, 0);
-      double s = 0.0;
-      if(act && i >= k)
-      {
-        double s1 = 0.0;
-        s = Li[k];
-        int m = 0;
-        for(; m + 1 < k; m += 2)
-        {
-          s -= Li[m] * Lk[m];
-          s1 -= Li[m + 1] * Lk[m + 1];
-        }
-        if(m < k) s -= Li[m] * Lk[m];
-        s += s1;
-      }
-      double piv = readlane_f64(s, k);
-      if(!(piv > 0.0))
-      {
-        badl = true;
-        piv = 1.0;
-      }
-      const double ri = fast_rsqrt(piv);
-      if(act && i >= k) M[tri_idx(i, k)] = (i == k) ? piv * ri : s * ri;
-      if(i == k) myrinv = ri;
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
+      case 1: chol_wave_reg<8>(M, r, w, bad); break;
+      case 2: chol_wave_reg<16>(M, r, w, bad); break;
+      case 3: chol_wave_reg<24>(M, r, w, bad); break;
+      case 4: chol_wave_reg<32>(M, r, w, bad); break;
+      default: chol_wave_lds(M, r, w, bad); break;
     }
-    double yv = (i < r) ? M[tri_idx(r, i)] : 0.0; // y = L^-1 v (the augmented row)
-    for(int k0 = r - 1; k0 >= 0; k0--)
-    {
-      const int k = __builtin_amdgcn_readfirstlane(k0);
-      const double lk = (i < k) ? M[tri_idx(k, 0) + i] : 0.0;
-      const double wk = readlane_f64(yv, k) * readlane_f64(myrinv, k);
-      yv = (i == k) ? wk : yv - lk * wk;
-    }
-    if(i < r) w[i] = yv;
-    if(badl && tid == 0) *bad = 1;
   }
   __syncthreads();
+  if(dbg_stop == 34) return;
   if(tid < nf)
   {
     const int a = tid;
@@ -1512,7 +1594,8 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     if(dual)
     {
       __syncthreads();
-      solve_dual(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, dinv, lraw, lraw + 192, xs, &s_bad);
+      solve_dual(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, dinv, lraw, lraw + 192, xs, &s_bad, dbg_stop);
+      if(dbg_stop >= 31 && dbg_stop <= 34) return;
     }
     else if(nf + 1 <= 96)
     {
@@ -1669,17 +1752,23 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
 constexpr int PROJ_LIST = 256;
 constexpr int PROJ_MAXK = IK_MAXK;
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// KPR > 0: the (at most 2 * KPR) queries live in registers as KPR packed pairs and the cull runs on packed fp32
+// (v_pk_add / v_pk_fma: two queries per instruction, no LDS read per (face, query)); KPR == 0: any K, queries from LDS.
+// `hint` (nullable): squared distance of each query to its task's own face when the evaluation already has it.
+template<int KPR>
 __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all,
-                                                         const float * __restrict__ pts, int64_t F, int K, int chunks,
-                                                         const int * __restrict__ skip, int * __restrict__ list_cnt,
+                                                         const float * __restrict__ pts, const float * __restrict__ hint, int64_t F,
+                                                         int K, int chunks, const int * __restrict__ skip, int * __restrict__ list_cnt,
                                                          float * __restrict__ list_d, int * __restrict__ list_f, int dbg_stop)
 {
   const int64_t f = blockIdx.x / chunks;
   const int chunk = blockIdx.x % chunks;
   if(skip[f]) return;
   const float * verts = verts_all + f * mv.V * 3;
-  __shared__ float sp[PROJ_MAXK][3];
-  __shared__ float sreach[PROJ_MAXK]; // sqrt of the hint distance: the cull radius of query k
+  __shared__ float sp[PROJ_MAXK + 1][3];
+  __shared__ float sreach[PROJ_MAXK + 1]; // sqrt of the hint distance: the cull radius of query k
   const int64_t tb = f * K;
   if((int)threadIdx.x < K)
   {
@@ -1688,12 +1777,36 @@ __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays
     sp[k][0] = p[0];
     sp[k][1] = p[1];
     sp[k][2] = p[2];
-    float c[3];
-    const float d = tri_sqdist_dev(verts, mv.faces, ta.face[tb + k], p, c);
+    float d;
+    if(hint)
+      d = hint[tb + k];
+    else
+    {
+      float c[3];
+      d = tri_sqdist_dev(verts, mv.faces, ta.face[tb + k], p, c);
+    }
     sreach[k] = (d == d) ? sqrtf(d) : INFINITY;
+  }
+  else if((int)threadIdx.x == K) // the odd pair's second half: a query no face can reach
+  {
+    sp[K][0] = sp[K][1] = sp[K][2] = 1e18f;
+    sreach[K] = 0.0f;
   }
   __syncthreads();
   if(dbg_stop == 10) return; // (timing experiments only: SMPLPP_IK_DBG_STOP)
+  f32x2 qx[KPR > 0 ? KPR : 1], qy[KPR > 0 ? KPR : 1], qz[KPR > 0 ? KPR : 1], qs[KPR > 0 ? KPR : 1];
+  if(KPR > 0)
+  {
+#pragma unroll
+    for(int q = 0; q < KPR; q++)
+    {
+      const int k0 = (2 * q < K) ? 2 * q : K, k1 = (2 * q + 1 < K) ? 2 * q + 1 : K;
+      qx[q] = f32x2{sp[k0][0], sp[k1][0]};
+      qy[q] = f32x2{sp[k0][1], sp[k1][1]};
+      qz[q] = f32x2{sp[k0][2], sp[k1][2]};
+      qs[q] = f32x2{sreach[k0], sreach[k1]};
+    }
+  }
   const int64_t per = (F + chunks - 1) / chunks;
   const int64_t f_lo = chunk * per, f_hi = (f_lo + per < F) ? f_lo + per : F;
   for(int64_t base = f_lo + threadIdx.x; base < f_hi; base += (int64_t)blockDim.x * CP_BATCH)
@@ -1719,11 +1832,27 @@ __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays
       const float r = __builtin_amdgcn_sqrtf(r2) * 1.000001f; // hardware sqrt (1 ulp) with its error folded into the slack
       // branch-free cull over the queries (one divergent branch per face, not per (face, query)), survivors afterwards
       uint64_t hit = 0;
-      for(int k = 0; k < K; k++)
+      if(KPR > 0)
       {
-        const float d0 = (sp[k][0] - g[0]) * (sp[k][0] - g[0]) + (sp[k][1] - g[1]) * (sp[k][1] - g[1]) + (sp[k][2] - g[2]) * (sp[k][2] - g[2]);
-        const float reach = (sreach[k] + r) * 1.00001f + 2e-6f;
-        hit |= (d0 <= reach * reach) ? (1ull << k) : 0ull;
+#pragma unroll
+        for(int q = 0; q < KPR; q++)
+        {
+          const f32x2 dx = qx[q] - g[0], dy = qy[q] - g[1], dz = qz[q] - g[2];
+          const f32x2 d0 = dx * dx + dy * dy + dz * dz;
+          const f32x2 reach = (qs[q] + r) * 1.00001f + 2e-6f;
+          const f32x2 rr = reach * reach;
+          hit |= (d0.x <= rr.x) ? (1ull << (2 * q)) : 0ull;
+          hit |= (d0.y <= rr.y) ? (1ull << (2 * q + 1)) : 0ull;
+        }
+      }
+      else
+      {
+        for(int k = 0; k < K; k++)
+        {
+          const float d0 = (sp[k][0] - g[0]) * (sp[k][0] - g[0]) + (sp[k][1] - g[1]) * (sp[k][1] - g[1]) + (sp[k][2] - g[2]) * (sp[k][2] - g[2]);
+          const float reach = (sreach[k] + r) * 1.00001f + 2e-6f;
+          hit |= (d0 <= reach * reach) ? (1ull << k) : 0ull;
+        }
       }
       while(hit)
       {
@@ -1963,6 +2092,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   A_(ta.noff, nk);
   A_(ta.apos, nk * 3);
   A_(ta.anrm, nk * 3);
+  A_(ta.hint, nk);
   A_(theta, (size_t)n * s->theta_dim);
   A_(beta, (size_t)n * NB);
   A_(theta25, (size_t)n * 75);
@@ -2250,8 +2380,14 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
       }
       int chunks = (int)(scan_blocks / s->n);
       chunks = chunks < 1 ? 1 : (chunks > 32 ? 32 : chunks);
-      proj_scan_kernel<<<dim3((unsigned)(s->n * chunks)), dim3(256), 0, pst>>>(view_of(m), s->ta, s->verts, qpts, m->F, K, chunks, s->skip,
-                                                                             s->list_cnt, s->list_d, s->list_f, dbg_stop);
+      const float * hint = beside ? s->ta.hint : nullptr; // the evaluation's distance is to the ACTUAL position
+      const dim3 sg((unsigned)(s->n * chunks));
+#define SCAN_(KPR) proj_scan_kernel<KPR><<<sg, dim3(256), 0, pst>>>(view_of(m), s->ta, s->verts, qpts, hint, m->F, K, chunks, s->skip, \
+                                                                   s->list_cnt, s->list_d, s->list_f, dbg_stop)
+      if(K <= 4) SCAN_(2);
+      else if(K <= 8) SCAN_(4);
+      else SCAN_(0);
+#undef SCAN_
       HIP_TRY(hipGetLastError());
       static int * dbg_buf = nullptr;
       if(dbg && !dbg_buf) HIP_TRY(hipMalloc((void **)&dbg_buf, sizeof(int) * 8));
