@@ -238,7 +238,7 @@ def main():
             "value": world * R * len(fr) / mt, "unit": "solved capture frames/s", "ik_iterations_per_s": world * R * iters / mt,
             "restarts_per_gpu": R, "frames": len(fr), "markers": Km, "finite": bool(np.isfinite(thm).all()),
             "workload": "configs[3]: sample_walk.c3d excerpt (32 frames x 41 markers), warm-started chains, box QP, direct theta (D = 157); "
-                        "host-driven per-frame loop (targets set from the host each frame)",
+                        "frame loop on the device (smplpp_ik_solve_sequence: targets uploaded once, no host round trip per frame)",
         }
 
         Kv = 6

@@ -100,6 +100,19 @@ public:
     check(smplpp_ik_iterate(s_, iters, enableQp ? 1 : 0, optimizeBetaFrom, minValid, e2.data(), SMPLPP_HOST, nullptr), "node");
     return e2;
   }
+  // the frame loop of solveMocapMotion (node.cpp:1369-1407, targets per frame :681-700) without a host round trip per
+  // frame: targetPos [T,n,K,3], valid [T,n,K]; returns g_theta after every frame [T,n,thetaDim]
+  std::vector<float> solveSequence(int64_t T, const std::vector<float> & targetPos, const std::vector<uint8_t> & valid,
+                                   int warmupIters = 31, int itersPerFrame = 1, bool enableQp = true, int64_t minValid = 0)
+  {
+    if((int64_t)targetPos.size() != T * n_ * K_ * 3 || (int64_t)valid.size() != T * n_ * K_)
+      throw Exception("node", "solveSequence: targetPos must be [T,n,K,3] and valid [T,n,K]");
+    std::vector<float> theta((size_t)(T * n_ * SMPLPP_THETA_DIM));
+    check(smplpp_ik_solve_sequence(s_, T, targetPos.data(), valid.data(), warmupIters, itersPerFrame, enableQp ? 1 : 0, minValid,
+                                   theta.data(), SMPLPP_HOST, nullptr),
+          "node");
+    return theta;
+  }
 
 private:
   std::shared_ptr<SMPL> smpl_;

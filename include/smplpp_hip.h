@@ -147,6 +147,15 @@ int smplpp_ik_eval(smplpp_ik * s, int optimize_beta, double * e, double * J, int
  * e_sqnorm [n] (nullable) receives |e|^2 of the last evaluation. */
 int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int optimize_beta_from, int64_t min_valid,
                       double * e_sqnorm, int space, void * stream);
+/* The frame loop of solveMocapMotion (node/node.cpp:1369-1407 with the per-frame target switch of :681-700) for n chains
+ * (sequences / restarts) in lock step, enqueued without a host round trip per frame: for t = 0..T-1 the marker targets of
+ * frame t become the task targets (valid == 0: target 0 and posTaskWeight_ 0, else posTaskWeight_ 1), then `warmup_iters`
+ * (t == 0; the reference advances once ikIter > 30) or `iters_per_frame` iterations of smplpp_ik_iterate's loop body run,
+ * warm-started from the previous frame; theta_out[t] receives g_theta after frame t. Every other task field (faces,
+ * weights, offsets, phi limits) is what smplpp_ik_set_tasks left. Layouts: target_pos [T,n,K,3], valid [T,n,K] (bytes),
+ * theta_out [T,n,theta_dim]. */
+int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * target_pos, const uint8_t * valid, int warmup_iters,
+                             int iters_per_frame, int enable_qp, int64_t min_valid, float * theta_out, int space, void * stream);
 /* Vertices of the last forward inside the solver [n,V,3] (SMPL::getVertex after the loop's launch). */
 int smplpp_ik_get_vertices(smplpp_ik * s, float * verts, int space, void * stream);
 

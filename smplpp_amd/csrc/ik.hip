@@ -1448,7 +1448,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
                                                        float * __restrict__ theta, float * __restrict__ beta, float * __restrict__ pts,
                                                        int K, int theta_dim, int beta_dim, int phi_live, int enable_qp, int use_prior,
                                                        int chunk_rows, const int * __restrict__ skip, double * __restrict__ e2_out,
-                                                       int * __restrict__ status, double * __restrict__ x_out, int dbg_stop)
+                                                       int * __restrict__ status, int * __restrict__ sticky, double * __restrict__ x_out, int dbg_stop, int m_dim)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int64_t f = blockIdx.x;
@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   const int D = theta_dim + 2 * K + beta_dim, rows = 4 * K;
   const int64_t tb = f * K;
   double * M = sm;
-  double * Jc = M + (D + 1) * (D + 2) / 2;
+  double * Jc = M + (m_dim + 1) * (m_dim + 2) / 2; // m_dim >= the number of free unknowns (host bound): phi pinned => D - 2K
   double * xs = Jc + chunk_rows * D;
   double * xfull = xs + D;
   double * diag = xfull + D;
@@ -1484,14 +1484,32 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   for(int r = tid; r < rows; r += 256) ebuf[r] = e_all[f * rows + r];
   __syncthreads();
   const double * e = ebuf;
-  if(tid == 0)
+  if(tid < 64)
   {
+    // |e|^2 in ascending order (the CPU checker sums the same way): the terms come out of registers by v_readlane — a
+    // single thread walking LDS pays a round trip per row (4.7 us for the 164 rows of a 41-marker solve)
+    double v[3];
+#pragma unroll
+    for(int a = 0; a < 3; a++) v[a] = (tid + 64 * a < rows) ? e[tid + 64 * a] : 0.0;
     double s = 0.0;
-    for(int r = 0; r < rows; r++) s += e[r] * e[r]; // ascending order (the CPU checker sums the same way)
-    s_e2 = s;
-    s_bad = 0;
-    s_done = 0;
-    if(e2_out) e2_out[f] = s;
+    if(rows <= 192)
+    {
+      for(int r0 = 0; r0 < rows; r0++)
+      {
+        const int r = __builtin_amdgcn_readfirstlane(r0);
+        const double x = readlane_f64(r < 64 ? v[0] : (r < 128 ? v[1] : v[2]), r & 63);
+        s += x * x;
+      }
+    }
+    else
+      for(int r = 0; r < rows; r++) s += e[r] * e[r];
+    if(tid == 0)
+    {
+      s_e2 = s;
+      s_bad = 0;
+      s_done = 0;
+      if(e2_out) e2_out[f] = s;
+    }
   }
   __syncthreads();
   for(int i = tid; i < D; i += 256)
@@ -1580,6 +1598,12 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     }
     __syncthreads();
     const int nf = s_nf;
+    if(nf > m_dim) // (cannot happen: the host bound counts every variable that can be free)
+    {
+      if(tid == 0) s_bad = 1;
+      __syncthreads();
+      break;
+    }
     const int nitem = (nf + 1) * (nf + 2) / 2;
     // rowv = e + J_B x_B  (b_F + A_FB x_B = J_F^T rowv); A = J^T J, b = J^T e (node.cpp:884-885), fp64
     for(int r = tid; r < rows; r += 256)
@@ -1650,8 +1674,69 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       __syncthreads();
       break;
     }
-    // candidate x_F = -xs ; ratio test against the box
-    if(tid == 0)
+    // candidate x_F = -xs ; ratio test against the box: the first variable (ascending free-set order) with the smallest
+    // step fraction below 1 blocks.  One variable per thread + a lexicographic (fraction, index) minimum — a single thread
+    // walking the free set pays five LDS round trips per variable (10 us for the 75 unknowns of a motion solve)
+    if(nf <= 256)
+    {
+      double al = 2.0;
+      int who = 0x7fffffff, side = 0;
+      if(tid < nf)
+      {
+        const int i = idx[tid];
+        const double xn = -xs[tid], xo = xfull[i], dx = xn - xo;
+        if(xn > hi[i] + 1e-14 && dx > 0)
+        {
+          al = (hi[i] - xo) / dx;
+          side = 1;
+        }
+        else if(xn < lo[i] - 1e-14 && dx < 0)
+        {
+          al = (lo[i] - xo) / dx;
+          side = -1;
+        }
+        if(side != 0 && al < 1.0)
+          who = tid;
+        else
+          al = 2.0;
+      }
+      for(int o = 32; o > 0; o >>= 1)
+      {
+        const double oal = __shfl_xor(al, o, 64);
+        const int owho = __shfl_xor(who, o, 64), oside = __shfl_xor(side, o, 64);
+        if(oal < al || (oal == al && owho < who))
+        {
+          al = oal;
+          who = owho;
+          side = oside;
+        }
+      }
+      __shared__ double s_ral[4];
+      __shared__ int s_rwho[4], s_rside[4];
+      if((tid & 63) == 0)
+      {
+        s_ral[tid >> 6] = al;
+        s_rwho[tid >> 6] = who;
+        s_rside[tid >> 6] = side;
+      }
+      __syncthreads();
+      if(tid == 0)
+      {
+        double alpha = 1.0;
+        int block = -1, bside = 0;
+        for(int w = 0; w < 4; w++)
+          if(s_rwho[w] != 0x7fffffff && s_ral[w] < alpha) // ascending wavefront order: ties keep the lower index
+          {
+            alpha = s_ral[w];
+            block = s_rwho[w];
+            bside = s_rside[w];
+          }
+        s_alpha = alpha;
+        s_block = block;
+        s_bside = bside;
+      }
+    }
+    else if(tid == 0)
     {
       double alpha = 1.0;
       int block = -1, bside = 0;
@@ -1688,13 +1773,26 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       __syncthreads();
       continue;
     }
-    // multipliers of the bound variables: g = A x + b = J^T (e + J x) + diag x + bpri
-    for(int r = tid; r < rows; r += 256)
+    // nothing sits on a bound (every motion-stage solve: phi pinned, beta fixed): the unconstrained step is the optimum
     {
-      double s = e[r];
-      for(int q = 0; q < D; q++)
+      int atb = 0;
+      for(int i = tid; i < D; i += 256) atb |= (state[i] == -1 || state[i] == 1);
+      if(!__syncthreads_or(atb))
+      {
+        if(tid == 0) s_done = 1;
+        __syncthreads();
+        break;
+      }
+    }
+    // multipliers of the bound variables: g = A x + b = J^T (e + J x) + diag x + bpri.  One wavefront per row, lanes
+    // across the columns (a thread per row reads J with a stride of D doubles: 64 cache lines per load instruction)
+    for(int r = tid >> 6; r < rows; r += 4)
+    {
+      double s = 0.0;
+      for(int q = tid & 63; q < D; q += 64)
         if(state[q] != 2) s += J[(int64_t)r * D + q] * xfull[q];
-      rowv[r] = s;
+      for(int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if((tid & 63) == 0) rowv[r] = e[r] + s;
     }
     __syncthreads();
     for(int i = tid; i < D; i += 256)
@@ -1723,7 +1821,11 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     __syncthreads();
     if(s_done) break;
   }
-  if(tid == 0) status[f] = s_bad ? 1 : ((enable_qp && !s_done) ? 2 : 0);
+  if(tid == 0)
+  {
+    status[f] = s_bad ? 1 : ((enable_qp && !s_done) ? 2 : 0);
+    if(s_bad) sticky[f] = 1; // survives later solves (sequence driver)
+  }
   const bool ok = !s_bad;
   // config update (node.cpp:945-968), fp32
   for(int i = tid; i < theta_dim; i += 256)
@@ -1749,7 +1851,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
 // frame) takes the minimum of each list, applies the tie rule (lowest face id within 1e-6 relative of the minimum — every
 // face in that band passes the cull, whose slack is larger) and writes the new face id and area-ratio weights.  A list
 // that overflows (a far-off hint, e.g. the very first iteration) falls back to the exhaustive block scan.
-constexpr int PROJ_LIST = 256;
+constexpr int PROJ_LIST = 512; // a marker 15 mm off a densely triangulated region has 100-400 faces inside its cull sphere
 constexpr int PROJ_MAXK = IK_MAXK;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1992,7 +2094,7 @@ struct smplpp_ik
   int32_t * ring = nullptr;
   int32_t * ringkey = nullptr; // [n,K] 2 * face + uses-normal the cached ring / map of a task was built for (-1: none)
   uint8_t * map = nullptr;
-  int *skip = nullptr, *status = nullptr, *list_cnt = nullptr, *list_f = nullptr;
+  int *skip = nullptr, *status = nullptr, *sticky = nullptr, *list_cnt = nullptr, *list_f = nullptr;
   float * list_d = nullptr;
   std::vector<void *> owned;
   bool have_eval = false;
@@ -2114,6 +2216,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   A_(list_f, nk * PROJ_LIST);
   A_(skip, (size_t)n);
   A_(status, (size_t)n);
+  A_(sticky, (size_t)n);
   if(vposer)
   {
     A_(Jl, nk * 4 * Dmax);
@@ -2138,6 +2241,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   HIP_TRY(hipMemset(s->skip, 0, sizeof(int) * n));
   HIP_TRY(hipMemset(s->list_cnt, 0, sizeof(int) * nk));
   HIP_TRY(hipMemset(s->status, 0, sizeof(int) * n));
+  HIP_TRY(hipMemset(s->sticky, 0, sizeof(int) * n));
   s->verts = s->vbuf[0];
   HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
@@ -2317,15 +2421,12 @@ extern "C" int smplpp_ik_eval(smplpp_ik * s, int optimize_beta, double * e, doub
   return SMPLPP_OK;
 }
 
-extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int optimize_beta_from, int64_t min_valid,
-                                 double * e_sqnorm, int space, void * stream)
+// `iters` iterations enqueued on st (+ the solver's side stream); leaves the last re-projection pending on the side
+// stream (s->side_pending) — the caller joins (ik_join) before anything else may touch the task arrays or the mesh.
+static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optimize_beta_from, int64_t min_valid, hipStream_t st)
 {
-  if(!s || iters < 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_iterate: bad argument");
-  int rc = check_space(space, "smplpp_ik_iterate");
-  if(rc) return rc;
+  int rc = SMPLPP_OK;
   smplpp_model * m = s->m;
-  HIP_TRY(hipSetDevice(m->device));
-  hipStream_t st = static_cast<hipStream_t>(stream);
   const int K = (int)s->K;
   static bool attr = false;
   if(!attr)
@@ -2358,7 +2459,10 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
     const int beta_dim = opt_beta ? NB : 0;
     // LDS plan: packed system + vectors, the rest (up to a 150 KB total) for the J row chunk
     const int D = s->theta_dim + 2 * K + beta_dim, rows = 4 * K;
-    const size_t fixed = sizeof(double) * ((size_t)(D + 1) * (D + 2) / 2 + 7 * (size_t)D + 2 * (size_t)rows + 388) + sizeof(int) * 2 * (size_t)D;
+    // the packed system is sized for the unknowns that CAN be free: a pinned phi (zero limit, node.cpp:567,699) never is,
+    // which leaves 75 of the 157 unknowns of a 41-marker motion solve and room for its 164 Jacobian rows in two chunks
+    const int m_dim = D - ((!phi_live || s->phi_locked) ? 2 * K : 0);
+    const size_t fixed = sizeof(double) * ((size_t)(m_dim + 1) * (m_dim + 2) / 2 + 7 * (size_t)D + 2 * (size_t)rows + 388) + sizeof(int) * 2 * (size_t)D;
     const size_t budget = 150 * 1024;
     int chunk_rows = (int)((budget - fixed) / (sizeof(double) * (size_t)D));
     if(chunk_rows > rows) chunk_rows = rows;
@@ -2367,7 +2471,7 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
     ik_solve_kernel<<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta,
                                                                         beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live,
                                                                         enable_qp, s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status,
-                                                                        s->xout, dbg_stop);
+                                                                        s->sticky, s->xout, dbg_stop, m_dim);
     HIP_TRY(hipGetLastError());
     DBG_SYNC("solve");
     {
@@ -2410,11 +2514,43 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
     DBG_SYNC("project");
   }
 #undef DBG_SYNC
+  return SMPLPP_OK;
+}
+
+static int ik_join(smplpp_ik * s, hipStream_t st)
+{
   if(s->side_pending) // everything the caller does next on its stream is ordered behind the last re-projection
   {
     HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
     s->side_pending = false;
   }
+  return SMPLPP_OK;
+}
+
+static int ik_check_status(smplpp_ik * s, const int * flags)
+{
+  std::vector<int> h((size_t)s->n);
+  HIP_TRY(hipMemcpy(h.data(), flags, sizeof(int) * s->n, hipMemcpyDeviceToHost));
+  for(int64_t f = 0; f < s->n; f++)
+    if(h[f] == 1) return fail(SMPLPP_ERR_NUMERIC, "LLT has numerical issue!"); // node.cpp:934-937
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int optimize_beta_from, int64_t min_valid,
+                                 double * e_sqnorm, int space, void * stream)
+{
+  if(!s || iters < 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_iterate: bad argument");
+  int rc = check_space(space, "smplpp_ik_iterate");
+  if(rc) return rc;
+  HIP_TRY(hipSetDevice(s->m->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  rc = ik_iterate_enqueue(s, iters, enable_qp, optimize_beta_from, min_valid, st);
+  if(rc)
+  {
+    (void)ik_join(s, st);
+    return rc;
+  }
+  if((rc = ik_join(s, st))) return rc;
   if(e_sqnorm)
   {
     hipMemcpyKind kind = space == SMPLPP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
@@ -2423,10 +2559,64 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
   if(space == SMPLPP_HOST)
   {
     HIP_TRY(hipStreamSynchronize(st));
-    std::vector<int> h((size_t)s->n);
-    HIP_TRY(hipMemcpy(h.data(), s->status, sizeof(int) * s->n, hipMemcpyDeviceToHost));
-    for(int64_t f = 0; f < s->n; f++)
-      if(h[f] == 1) return fail(SMPLPP_ERR_NUMERIC, "LLT has numerical issue!"); // node.cpp:934-937
+    if((rc = ik_check_status(s, s->status))) return rc;
+  }
+  return SMPLPP_OK;
+}
+
+// node/node.cpp:1369-1407 with :681-700 — the frame loop of solveMocapMotion on the device: frame t's marker targets
+// replace the task targets (a missing marker: target 0, weight 0), `warmup_iters` iterations on the first frame and
+// `iters_per_frame` on every later one, warm-started; nothing returns to the host between frames.
+__global__ void ik_seq_frame_kernel(const float * __restrict__ tpos_t, const uint8_t * __restrict__ valid_t, float * __restrict__ tpos,
+                                    float * __restrict__ posw, int64_t nk, const float * __restrict__ theta, float * __restrict__ theta_prev_out,
+                                    int64_t ntheta)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(tpos_t && i < nk)
+  {
+    const bool v = valid_t[i] != 0;
+    posw[i] = v ? 1.0f : 0.0f;
+    for(int x = 0; x < 3; x++) tpos[i * 3 + x] = v ? tpos_t[i * 3 + x] : 0.0f;
+  }
+  if(theta_prev_out && i < ntheta) theta_prev_out[i] = theta[i];
+}
+
+extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * target_pos, const uint8_t * valid, int warmup_iters,
+                                        int iters_per_frame, int enable_qp, int64_t min_valid, float * theta_out, int space, void * stream)
+{
+  if(!s || T <= 0 || !target_pos || !valid || !theta_out || warmup_iters < 0 || iters_per_frame < 0)
+    return fail(SMPLPP_ERR_INVALID, "smplpp_ik_solve_sequence: bad argument");
+  int rc = check_space(space, "smplpp_ik_solve_sequence");
+  if(rc) return rc;
+  HIP_TRY(hipSetDevice(s->m->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t nk = s->n * s->K, ntheta = s->n * s->theta_dim;
+  In<float> tp;
+  In<uint8_t> vl;
+  Out<float> th;
+  HIP_TRY(tp.init(target_pos, (size_t)(T * nk * 3), space, st));
+  HIP_TRY(vl.init(valid, (size_t)(T * nk), space, st));
+  HIP_TRY(th.init(theta_out, (size_t)(T * ntheta), space));
+  HIP_TRY(hipMemsetAsync(s->sticky, 0, sizeof(int) * s->n, st));
+  const int64_t cnt = nk > ntheta ? nk : ntheta;
+  const dim3 grid((unsigned)((cnt + 255) / 256));
+  for(int64_t t = 0; t <= T; t++)
+  {
+    ik_seq_frame_kernel<<<grid, 256, 0, st>>>(t < T ? tp.d + t * nk * 3 : nullptr, t < T ? vl.d + t * nk : nullptr, s->ta.tpos, s->ta.posw, nk,
+                                              s->theta, t > 0 ? th.d + (t - 1) * ntheta : nullptr, ntheta);
+    HIP_TRY(hipGetLastError());
+    if(t == T) break;
+    rc = ik_iterate_enqueue(s, t == 0 ? warmup_iters : iters_per_frame, enable_qp, -1, min_valid, st);
+    if(rc) break;
+  }
+  const int jrc = ik_join(s, st);
+  if(rc) return rc;
+  if(jrc) return jrc;
+  HIP_TRY(th.finish(st));
+  if(space == SMPLPP_HOST)
+  {
+    HIP_TRY(hipStreamSynchronize(st));
+    if((rc = ik_check_status(s, s->sticky))) return rc;
   }
   return SMPLPP_OK;
 }

@@ -195,9 +195,10 @@ class MocapMotionSolver:
                              phi_limit=np.zeros(K))  # :567, :699
 
     def solve(self, markers: np.ndarray, valid: np.ndarray, beta: np.ndarray, theta0: np.ndarray, frame_interval: int = 1,
-              max_frames: Optional[int] = None):
+              max_frames: Optional[int] = None, host_loop: bool = False):
         """markers [R,T,K,3] (or [T,K,3] shared), valid [R,T,K]; returns theta per solved frame [R,Ts,theta_dim]
-        and the list of solved frame indices."""
+        and the list of solved frame indices. The frame loop runs on the device (smplpp_ik_solve_sequence);
+        host_loop=True drives it frame by frame from here (same kernels, same results; kept as the cross-check)."""
         R, K = self.R, self.K
         markers = np.asarray(markers, np.float32)
         valid = np.asarray(valid, bool)
@@ -211,6 +212,12 @@ class MocapMotionSolver:
         self.solver.setConfig(np.broadcast_to(np.asarray(beta, np.float32), (R, 10)).copy(), theta0)
         out = np.empty((R, len(frames), self.solver.theta_dim), np.float32)
         min_valid = K // 2  # integer division, node.cpp:785
+        if not host_loop:
+            v = np.ascontiguousarray(valid[:, frames].transpose(1, 0, 2))  # [Ts,R,K]
+            tp = np.where(v[..., None], markers[:, frames].transpose(1, 0, 2, 3), 0.0).astype(np.float32)  # :681-690
+            th = self.solver.solveSequence(tp, v, warmup_iters=self.WARMUP_ITERS, iters_per_frame=1, enable_qp=True,
+                                           min_valid=min_valid)
+            return np.ascontiguousarray(th.transpose(1, 0, 2)), frames
         for i, t in enumerate(frames):
             v = valid[:, t]
             tp = np.where(v[..., None], markers[:, t], 0.0).astype(np.float32)  # :681-690

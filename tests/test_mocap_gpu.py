@@ -92,3 +92,28 @@ def test_reference_capture_excerpt_runs(smpl, tmp_path):
             assert np.abs(th[:, t] - th[:, t - 1]).max() == 0
     mocap.write_motion_text(str(tmp_path / "motion.txt"), ms.decode_theta(th[0]))
     assert len(open(str(tmp_path / "motion.txt")).read().splitlines()) == len(frames)
+
+
+def test_device_frame_loop_matches_host_driven_loop(smpl, synth_model):
+    """smplpp_ik_solve_sequence (frame loop enqueued on the device, node.cpp:1369-1407) against the same loop driven frame
+    by frame through set_tasks + iterate: same kernels in the same order, so the trajectories are bit-identical —
+    including missing markers and a skipped frame."""
+    from smplpp_amd import mocap
+
+    T, K, R = 12, 41, 4
+    names, faces, hid, markers = _synthetic_sequence(smpl, synth_model, T, K, seed=3)
+    valid = np.ones((R, T, K), bool)
+    valid[1, 3, :5] = False
+    valid[2, 6, : K - 8] = False  # chain 2 skips frame 6
+    rng = np.random.default_rng(2)
+    theta0 = np.tile(hid[0], (R, 1, 1)) + rng.normal(0, 0.03, (R, 25, 3)).astype(np.float32)
+    mk = np.broadcast_to(markers, (R,) + markers.shape)
+    out = []
+    for host_loop in (True, False):
+        ms = mocap.MocapMotionSolver(smpl, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R)
+        th, frames = ms.solve(mk, valid, np.zeros(10, np.float32), theta0, host_loop=host_loop)
+        out.append((th, ms.solver.getTasks()["face_idx"]))
+    assert np.isfinite(out[0][0]).all()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.abs(out[1][0][2, 6] - out[1][0][2, 5]).max() == 0
