@@ -43,6 +43,23 @@ int main(int argc, char ** argv)
     solver.eval(false, e, J);
     auto e2 = solver.iterate(3);
     std::printf("ik: |e|^2 after 3 iterations = %.3g (rows %zu, J %zu)\n", e2[0], e.size(), J.size());
+    // the capture-fitting frame loop on the device: 3 frames, the second with a missing marker
+    const int64_t T = 3;
+    std::vector<float> tp((size_t)(T * 1 * 2 * 3));
+    std::vector<uint8_t> valid((size_t)(T * 1 * 2), 1);
+    for(int64_t t = 0; t < T; t++)
+      for(int k = 0; k < 2; k++)
+      {
+        tp[(size_t)((t * 2 + k) * 3 + 0)] = 0.1f + 0.01f * (float)t;
+        tp[(size_t)((t * 2 + k) * 3 + 1)] = 0.2f;
+        tp[(size_t)((t * 2 + k) * 3 + 2)] = 0.3f;
+      }
+    valid[3] = 0;
+    auto seq = solver.solveSequence(T, tp, valid, 4, 1, true, 0);
+    bool finite = true;
+    for(float x : seq) finite = finite && std::isfinite(x);
+    std::printf("sequence: %zu values, finite %d\n", seq.size(), finite ? 1 : 0);
+    if(!finite || seq.size() != (size_t)(T * 75)) return 3;
     std::printf("OK\n");
     return 0;
   }
