@@ -249,6 +249,22 @@ def main():
         hidv[:, 1:22] = rng.normal(0, 0.15, (nv, 21, 3))
         hvv = smpl.launch(np.zeros((nv, 10), np.float32), hidv, want=("verts",))["verts"]
         tpv = hvv[:, model["face_indices"][vfaces] - 1].mean(axis=2)
+        # the reference's own capture setting (node.cpp:316-322 forces VPoser + QP on): 44-d layout, D = 44 + 2 * 41
+        msv = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R, vposer=vp)
+        gv0 = np.zeros((R, 44), np.float32)
+        gv0[:, 6:38] = rng.normal(0, 0.05, (R, 32))
+        msv.solve(pts, g["valid"], np.zeros(10, np.float32), gv0, max_frames=2)
+        torch.cuda.synchronize()
+        D.barrier()
+        t1 = time.perf_counter()
+        thv, frv = msv.solve(pts, g["valid"], np.zeros(10, np.float32), gv0)
+        torch.cuda.synchronize()
+        D.barrier()
+        mtv = D.max_over_ranks(time.perf_counter() - t1)
+        mocap_leg["vposer_latent"] = {
+            "value": world * R * len(frv) / mtv, "unit": "solved capture frames/s", "finite": bool(np.isfinite(thv).all()),
+            "workload": "same excerpt with the 44-d VPoser layout the reference forces on capture solves (D = 126), synthetic decoder weights",
+        }
         vs = IkSolver(smpl, nv, Kv, vposer=vp)
         vs.setTasks(face_idx=vfaces, target_pos=tpv, phi_limit=np.zeros(Kv), normal_task_weight=np.zeros(Kv))
         g0 = np.zeros((nv, vs.theta_dim), np.float32)

@@ -117,3 +117,28 @@ def test_device_frame_loop_matches_host_driven_loop(smpl, synth_model):
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])
     assert np.abs(out[1][0][2, 6] - out[1][0][2, 5]).max() == 0
+
+
+def test_latent_capture_fit_device_loop_matches_host_loop(smpl, synth_model):
+    """The reference forces VPoser + QP on in every capture solve (node.cpp:316-322): 44-d layout (D = 44 + 2K), decoder
+    inside the loop, synthetic decoder weights. Device frame loop == host-driven loop, and the fit follows the markers."""
+    from smplpp_amd import mocap
+    from smplpp_amd.ik import VPoserDecoder
+
+    T, K, R = 8, 41, 2
+    names, faces, hid, markers = _synthetic_sequence(smpl, synth_model, T, K, seed=5)
+    valid = np.ones((R, T, K), bool)
+    valid[0, 2, :4] = False
+    vp = VPoserDecoder(VPoserDecoder.synthetic_params(seed=3), device=0)
+    mk = np.broadcast_to(markers, (R,) + markers.shape)
+    out = []
+    for host_loop in (True, False):
+        ms = mocap.MocapMotionSolver(smpl, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R, vposer=vp)
+        g0 = np.zeros((R, 44), np.float32)
+        g0[:, :3] = hid[0, 0]
+        th, frames = ms.solve(mk, valid, np.zeros(10, np.float32), g0, host_loop=host_loop)
+        out.append(th)
+    assert out[0].shape == (R, T, 44) and np.isfinite(out[0]).all()
+    assert np.array_equal(out[0], out[1])
+    full = ms.decode_theta(out[1])
+    assert full.shape == (R, T, 25, 3) and np.isfinite(full).all()
