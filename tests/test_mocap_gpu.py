@@ -142,3 +142,28 @@ def test_latent_capture_fit_device_loop_matches_host_loop(smpl, synth_model):
     assert np.array_equal(out[0], out[1])
     full = ms.decode_theta(out[1])
     assert full.shape == (R, T, 25, 3) and np.isfinite(full).all()
+
+
+def test_capture_fit_two_stream_schedule_is_bit_identical(smpl, synth_model, monkeypatch):
+    """41 markers with a normal offset (cull radius 15 mm, lists of 100-400 faces), 16 chains: the side-stream schedule of
+    the re-projection against the single-stream order (SMPLPP_IK_OVERLAP=0)."""
+    from smplpp_amd import mocap
+
+    T, K, R = 10, 41, 16
+    names, faces, hid, markers = _synthetic_sequence(smpl, synth_model, T, K, seed=7)
+    valid = np.ones((R, T, K), bool)
+    rng = np.random.default_rng(9)
+    valid[rng.integers(0, R, 20), rng.integers(0, T, 20), rng.integers(0, K, 20)] = False
+    theta0 = np.tile(hid[0], (R, 1, 1)) + rng.normal(0, 0.03, (R, 25, 3)).astype(np.float32)
+    mk = np.broadcast_to(markers, (R,) + markers.shape)
+    out = []
+    for env in ("0", None):
+        if env is None:
+            monkeypatch.delenv("SMPLPP_IK_OVERLAP", raising=False)
+        else:
+            monkeypatch.setenv("SMPLPP_IK_OVERLAP", env)
+        ms = mocap.MocapMotionSolver(smpl, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R)
+        th, _ = ms.solve(mk, valid, np.zeros(10, np.float32), theta0)
+        out.append((th, ms.solver.getTasks()["face_idx"], ms.solver.getTasks()["vertex_weights"]))
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)
