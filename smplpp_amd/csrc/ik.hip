@@ -1444,6 +1444,11 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
 // One workgroup per frame.  Everything is built from J (staged through LDS in row chunks) — no D x D matrix in HBM.
 // LDS (doubles): M packed (D+1)(D+2)/2 | Jc [chunk][D] | xs, xfull, diag, bpri, lo, hi [D each] | rowv [rows] | lraw [2][96],
 // ldiag [2] ; ints idx, state [D].
+// DUAL_ONLY: the instantiation for launches whose every pass is known on the host to take the dual form (4K < theta_dim:
+// theta is always free, so the free set never shrinks below the residual rows). It does not carry the register-tiled
+// primal factorisation, which is what sizes the general kernel's register file footprint (247 of the SIMD's 512
+// registers per lane: the face scan that runs beside the solve then keeps one wavefront per SIMD instead of three).
+template<bool DUAL_ONLY>
 __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const double * __restrict__ e_all, const double * __restrict__ J_all,
                                                        float * __restrict__ theta, float * __restrict__ beta, float * __restrict__ pts,
                                                        int K, int theta_dim, int beta_dim, int phi_live, int enable_qp, int use_prior,
@@ -1614,12 +1619,21 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
           if(state[q] == -1 || state[q] == 1) s += J[(int64_t)r * D + q] * xfull[q];
       rowv[r] = s;
     }
-    const bool dual = rows < nf && rows <= 63 && chunk_rows >= rows && nf <= 192 && dbg_stop != 9;
+    const bool dual = rows < nf && rows <= 63 && chunk_rows >= rows && nf <= 192 && (DUAL_ONLY || dbg_stop != 9);
+    if(DUAL_ONLY && !dual) // (cannot happen: the host selects this instantiation only when every pass qualifies)
+    {
+      if(tid == 0) s_bad = 1;
+      __syncthreads();
+      break;
+    }
     if(dual)
     {
       __syncthreads();
       solve_dual(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, dinv, lraw, lraw + 192, xs, &s_bad, dbg_stop);
       if(dbg_stop >= 31 && dbg_stop <= 34) return;
+    }
+    else if constexpr(DUAL_ONLY)
+    {
     }
     else if(nf + 1 <= 96)
     {
@@ -1666,7 +1680,8 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       chol_aug(M, nf, &s_bad, dinv);
     }
     if(dbg_stop == 2) return;
-    if(!dual) back_subst(M, nf, xs, dinv);
+    if constexpr(!DUAL_ONLY)
+      if(!dual) back_subst(M, nf, xs, dinv);
     if(dbg_stop == 3) return;
     if(!enable_qp)
     {
@@ -2431,7 +2446,8 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
   static bool attr = false;
   if(!attr)
   {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ik_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ik_solve_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ik_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     attr = true;
   }
   const bool dbg = getenv("SMPLPP_DEBUG_SYNC") != nullptr;
@@ -2468,10 +2484,17 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
     if(chunk_rows > rows) chunk_rows = rows;
     if(chunk_rows < 4) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_iterate: system too large for the in-LDS solver");
     const size_t solve_shmem = fixed + sizeof(double) * (size_t)chunk_rows * D;
-    ik_solve_kernel<<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta,
-                                                                        beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live,
-                                                                        enable_qp, s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status,
-                                                                        s->sticky, s->xout, dbg_stop, m_dim);
+    // theta is never bound, so the free set keeps at least theta_dim unknowns: with fewer residual rows than that every pass
+    // (also every active-set pass of the QP) takes the dual form
+    const bool dual_only = rows < s->theta_dim && rows <= 63 && chunk_rows >= rows && D <= 192 && dbg_stop != 9;
+#define SOLVE_(DO) ik_solve_kernel<DO><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
+    s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
+    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim)
+    if(dual_only)
+      SOLVE_(true);
+    else
+      SOLVE_(false);
+#undef SOLVE_
     HIP_TRY(hipGetLastError());
     DBG_SYNC("solve");
     {
