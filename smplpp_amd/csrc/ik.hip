@@ -205,7 +205,7 @@ constexpr int L_J = L_R + NJ * 9;              // [24][3]
 constexpr int L_G = L_J + NJ * 3;              // [24][12]  relative transforms [A | b]
 constexpr int L_T = L_G + NJ * 12;             // [24][3]   local translations j_i - j_p(i)
 constexpr int L_DR = L_T + NJ * 3;             // [72][9]
-constexpr int L_DAB = L_DR + 72 * 9;           // [24*12][72]  (joint, entry) major, column fastest
+constexpr int L_DAB = L_DR + 72 * 9;           // [24][72][3][4]  per (joint, column): rows [dA_r | db_r] (one 16-byte LDS access per row)
 constexpr int L_DBB = L_DAB + NJ * 12 * 72;    // [24*3][10]
 constexpr int L_RV = L_DBB + NJ * 3 * NB;      // [MAXRING][16]  rest(3) Ablend(9) wsum(1)
 constexpr int RVS = 24;                         // floats per ring vertex: rest 3 | Ablend 9 | wsum 1 | posed 3 | weights 4 | joints 4
@@ -214,13 +214,19 @@ constexpr int L_VN = L_DP + MAXRING * 3 * NQ;  // [3][3] vertex normals + [3] th
 constexpr int L_END = L_VN + 12;
 constexpr int L_ANC_BYTES = NJ * 4;            // int anc[24] after the float region
 
+#ifndef SMPLPP_EVAL_NT
+#define SMPLPP_EVAL_NT 1024
+#endif
+// threads per workgroup of ik_eval_kernel: one workgroup per frame owns a CU (152 KB of LDS), and its phases are bound by
+// memory latency and per-item instruction count, so more wavefronts per SIMD both hide latency and shorten the item loops
+constexpr int EVAL_NT = SMPLPP_EVAL_NT;
 #ifdef SMPLPP_EVAL_STAMPS
 __device__ unsigned long long g_eval_stamps[64 * 16];
 #define EVAL_STAMP(i) do { if(tid == 0 && blockIdx.x < 64) g_eval_stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while(0)
 #else
 #define EVAL_STAMP(i) do {} while(0)
 #endif
-__global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ theta25,
+__global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ theta25,
                                                       const float * __restrict__ verts_all, const float * __restrict__ rest_all,
                                                       const float * __restrict__ Gp, const float * __restrict__ joints,
                                                       const float * __restrict__ poserot, int K, int optimize_beta,
@@ -259,13 +265,13 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
   }
 
   // ---- frame constants into LDS
-  for(int i = tid; i < NJ * 9; i += 256) lds[L_R + i] = poserot[f * NJ * 9 + i];
-  for(int i = tid; i < NJ * 3; i += 256) lds[L_J + i] = joints[f * NJ * 3 + i];
-  for(int i = tid; i < NJ * 12; i += 256) lds[L_G + i] = Gp[f * NJ * 12 + i];
+  for(int i = tid; i < NJ * 9; i += EVAL_NT) lds[L_R + i] = poserot[f * NJ * 9 + i];
+  for(int i = tid; i < NJ * 3; i += EVAL_NT) lds[L_J + i] = joints[f * NJ * 3 + i];
+  for(int i = tid; i < NJ * 12; i += EVAL_NT) lds[L_G + i] = Gp[f * NJ * 12 + i];
   if(tid == 0)
     for(int i = 0; i < NJ; i++) sAnc[i] = (1 << i) | (i ? sAnc[mv.parent[i]] : 0);
   __syncthreads();
-  for(int i = tid; i < NJ * 3; i += 256)
+  for(int i = tid; i < NJ * 3; i += EVAL_NT)
   {
     const int j = i / 3, x = i % 3, p = mv.parent[j];
     lds[L_T + i] = (j == 0) ? lds[L_J + x] : lds[L_J + i] - lds[L_J + p * 3 + x];
@@ -307,18 +313,16 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       else
       {
         // parent's dA row and dg (dg_p = db_p + dA_p . j_p)
-        float dAp[3];
-        for(int q = 0; q < 3; q++) dAp[q] = lds[L_DAB + (p * 12 + r * 4 + q) * 72 + c];
-        const float dgp = lds[L_DAB + (p * 12 + r * 4 + 3) * 72 + c]
-                          + (dAp[0] * lds[L_J + p * 3] + dAp[1] * lds[L_J + p * 3 + 1] + dAp[2] * lds[L_J + p * 3 + 2]);
+        const float4 pr = *reinterpret_cast<const float4 *>(lds + L_DAB + ((p * 72 + c) * 3 + r) * 4);
+        const float dAp[3] = {pr.x, pr.y, pr.z};
+        const float dgp = pr.w + (dAp[0] * lds[L_J + p * 3] + dAp[1] * lds[L_J + p * 3 + 1] + dAp[2] * lds[L_J + p * 3 + 2]);
         const float * Ri = lds + L_R + i * 9;
         const float * ti = lds + L_T + i * 3;
         for(int cc = 0; cc < 3; cc++) dA[cc] = dAp[0] * Ri[cc] + dAp[1] * Ri[3 + cc] + dAp[2] * Ri[6 + cc];
         dg = (dAp[0] * ti[0] + dAp[1] * ti[1] + dAp[2] * ti[2]) + dgp;
       }
-      for(int cc = 0; cc < 3; cc++) lds[L_DAB + (i * 12 + r * 4 + cc) * 72 + c] = dA[cc];
-      lds[L_DAB + (i * 12 + r * 4 + 3) * 72 + c] =
-          dg - (dA[0] * lds[L_J + i * 3] + dA[1] * lds[L_J + i * 3 + 1] + dA[2] * lds[L_J + i * 3 + 2]);
+      *reinterpret_cast<float4 *>(lds + L_DAB + ((i * 72 + c) * 3 + r) * 4) =
+          make_float4(dA[0], dA[1], dA[2], dg - (dA[0] * lds[L_J + i * 3] + dA[1] * lds[L_J + i * 3 + 1] + dA[2] * lds[L_J + i * 3 + 2]));
     }
   }
   else if(tid < 216 + NB && optimize_beta) // beta columns: joints move, rotations do not
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
   __threadfence_block(); // a rebuilt map is read by other threads below
   EVAL_STAMP(3);
   if(dbg_stop == 23) return;
-  for(int item = tid; item < ntask * MAXRING; item += 256) // A1
+  for(int item = tid; item < ntask * MAXRING; item += EVAL_NT) // A1
   {
     const int t = item / MAXRING, q = item % MAXRING;
     if(q < s_ringb[t][0])
@@ -575,6 +579,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       }
     }
     __syncthreads();
+    if(k_lo == k_begin) EVAL_STAMP(8);
 
     if(tid < total) // B1: per ring vertex rest position, blended rotation, blended w
     {
@@ -610,7 +615,8 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       s_cnt[tid - 192] = mv.adjOff[u + 1] - mv.adjOff[u];
     }
     __syncthreads();
-    for(int item = tid; item < total * nq; item += 256) // B2: dp[rv][:, q]  
+    if(k_lo == k_begin) EVAL_STAMP(9);
+    for(int item = tid; item < total * nq; item += EVAL_NT) // B2: dp[rv][:, q]  
     {
       const int r_ = item / nq, q = item % nq;
       const int v = s_rvert[r_];
@@ -627,9 +633,12 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
           const float wm = wlds ? rv[16 + m] : mv.wVal[(int64_t)v * mv.maxw + m];
           if(wm == 0.0f) continue;
           const int i = wlds ? __float_as_int(rv[20 + m]) : (int)mv.wIdx[(int64_t)v * mv.maxw + m];
-          const float * d = lds + L_DAB + (i * 12) * 72 + c;
+          const float4 * d = reinterpret_cast<const float4 *>(lds + L_DAB + (i * 72 + c) * 12);
           for(int r = 0; r < 3; r++)
-            acc[r] += wm * (((d[(r * 4) * 72] * rv[0] + d[(r * 4 + 1) * 72] * rv[1]) + d[(r * 4 + 2) * 72] * rv[2]) + d[(r * 4 + 3) * 72]);
+          {
+            const float4 dr4 = d[r];
+            acc[r] += wm * (((dr4.x * rv[0] + dr4.y * rv[1]) + dr4.z * rv[2]) + dr4.w);
+          }
         }
         if(jc >= 1) // pose correctives; the root joint has none (src/BlendShape.cpp:884-887)
         {
@@ -662,6 +671,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       for(int r = 0; r < 3; r++) lds[L_DP + (r_ * 3 + r) * NQ + q] = acc[r] / rv[12];
     }
     __syncthreads();
+    if(k_lo == k_begin) EVAL_STAMP(10);
     // B3n (a task with a normal term / offset is alone in its group): the derivative of each of the three vertex normals,
     // one thread per (column, triangle vertex) — the chain n_f -> vn over ~6 adjacent faces is the long part of the
     // kernel for such tasks, and only nq of the 256 threads worked when a column's thread walked all three vertices
@@ -669,7 +679,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
     if(group_normal) // d vertexNormal_i / dq  
     {
       const float * dp = lds + L_DP; // ring offset 0
-      for(int item = tid; item < nq * 3; item += 256)
+      for(int item = tid; item < nq * 3; item += EVAL_NT)
       {
         const int q = item / 3, i = item % 3;
         int cnt = s_cnt[i];
@@ -719,7 +729,8 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       }
       __syncthreads();
     }
-    for(int item = tid; item < (k_hi - k_lo) * nq; item += 256) // B3: one (task, differentiation column) per thread
+    if(k_lo == k_begin) EVAL_STAMP(11);
+    for(int item = tid; item < (k_hi - k_lo) * nq; item += EVAL_NT) // B3: one (task, differentiation column) per thread
     {
       const int k = k_lo + item / nq, q = item % nq;
       const float off = ta.noff[tb + k], wp = ta.posw[tb + k], wn = ta.nrmw[tb + k];
@@ -754,7 +765,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       Jk[(int64_t)3 * D + jcol] = (wn > 0.0f) ? (double)(wn * nd) : 0.0;
     }
     // phi columns of every task are zero except the task's own two (node.cpp:792, :834-839)
-    for(int item = tid; item < (k_hi - k_lo) * 2 * K; item += 256)
+    for(int item = tid; item < (k_hi - k_lo) * 2 * K; item += EVAL_NT)
     {
       const int k = k_lo + item / (2 * K), c = item % (2 * K);
       const float plim = ta.philim[tb + k];
@@ -763,6 +774,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
         for(int r = 0; r < 4; r++) Jk[(int64_t)r * D + TD75 + c] = 0.0;
     }
     __syncthreads();
+    if(k_lo == k_begin) EVAL_STAMP(12);
     if(tid < 2 * (k_hi - k_lo)) // B4: d/dphi through calcTriangleVertexWeights (vertices detached)
     {
       const int k = k_lo + tid / 2, c = tid % 2;
@@ -819,6 +831,7 @@ __global__ __launch_bounds__(256) void ik_eval_kernel(ModelView mv, TaskArrays t
       }
     }
     __syncthreads();
+    if(k_lo == k_begin) EVAL_STAMP(13);
     k_lo = k_hi;
   }
   EVAL_STAMP(7);
@@ -2405,7 +2418,7 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   int tsplit = (n < 256) ? (int)(256 / n) : 1; // one round of workgroups (one per CU: 83 KB of LDS each)
   if(tsplit > K) tsplit = K;
   if(tsplit < 1) tsplit = 1;
-  hipExtLaunchKernelGGL(ik_eval_kernel, dim3((unsigned)(n * tsplit)), dim3(256), shmem, st, nullptr, eval_done, 0, view_of(m), s->ta, th25,
+  hipExtLaunchKernelGGL(ik_eval_kernel, dim3((unsigned)(n * tsplit)), dim3(EVAL_NT), shmem, st, nullptr, eval_done, 0, view_of(m), s->ta, th25,
                         (const float *)s->verts, (const float *)s->rest, (const float *)m->ws.Gp.as<float>(), (const float *)s->joints,
                         (const float *)s->poserot, K, optimize_beta, phi_live, (int)min_valid, s->ring, s->ringkey, s->map, s->pts, s->e,
                         s->J, s->skip, getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0, tsplit);
