@@ -205,7 +205,9 @@ def main():
         ik = {
             "value": world * args.ik_frames * args.ik_iters / ik_t, "unit": "IK iterations/s", "frames_per_gpu": args.ik_frames,
             "iters": args.ik_iters, "tasks": K, "ms_per_iter_batch": ik_t / args.ik_iters * 1e3,
-            "final_max_e_sqnorm": float(np.max(e2)), "workload": "configs[2]: 6-target IK (position + normal term per target), 50 iterations, direct theta (D = 87)",
+            "final_max_e_sqnorm": float(np.max(e2)), "final_median_e_sqnorm": float(np.median(e2)),
+            "frames_below_1e-3": int((e2 < 1e-3).sum()),  # the normal terms make the problem non-convex: a start can end in a local minimum
+            "workload": "configs[2]: 6-target IK (position + normal term per target), 50 iterations, direct theta (D = 87)",
         }
 
     # ---- configs[3]: the capture excerpt (tests/golden/sample_walk_excerpt.npz: 32 frames x 41 Baseline markers of

@@ -210,8 +210,9 @@ constexpr int L_DBB = L_DAB + NJ * 12 * 72;    // [24*3][10]
 constexpr int L_RV = L_DBB + NJ * 3 * NB;      // [MAXRING][16]  rest(3) Ablend(9) wsum(1)
 constexpr int RVS = 24;                         // floats per ring vertex: rest 3 | Ablend 9 | wsum 1 | posed 3 | weights 4 | joints 4
 constexpr int L_DP = L_RV + MAXRING * RVS;     // [MAXRING][3][NQ]
-constexpr int L_VN = L_DP + MAXRING * 3 * NQ;  // [3][3] vertex normals + [3] their weighted sum
-constexpr int L_END = L_VN + 12;
+constexpr int NGN = 2;                          // tasks with a normal term / offset per group (their rings share L_RV / L_DP)
+constexpr int L_VN = L_DP + MAXRING * 3 * NQ;  // per such task: [3][3] vertex normals + [3] their weighted sum
+constexpr int L_END = L_VN + 12 * NGN;
 constexpr int L_ANC_BYTES = NJ * 4;            // int anc[24] after the float region
 
 #ifndef SMPLPP_EVAL_NT
@@ -551,21 +552,29 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   __shared__ int s_roff[IK_MAXK + 1]; // ring offset of task k inside its group's buffers
   __shared__ int s_rtask[MAXRING];      // ring slot -> task
   __shared__ int s_rvert[MAXRING];      // ring slot -> vertex
-  __shared__ uint8_t s_map[3 * MAXADJ * 3]; // (vertex of the face, adjacent face, corner) -> ring slot, of a normal task
-  __shared__ int s_cnt[3];              // adjacent-face count of the face's three vertices
-  __shared__ float s_nrm[NQ * 3 * 6];   // per (column, triangle vertex): vertex normal (3) and its derivative (3)
+  __shared__ uint8_t s_map[NGN][3 * MAXADJ * 3]; // (vertex of the face, adjacent face, corner) -> slot in the task's ring, per normal task
+  __shared__ int s_cnt[NGN][3];         // adjacent-face count of the face's three vertices
+  __shared__ float s_nrm[NGN][NQ * 3 * 6]; // per (column, triangle vertex): vertex normal (3) and its derivative (3)
+  static_assert(EVAL_NT >= 64 + NGN * 128 + NGN * 4, "B1 hands the map / count loads to thread ranges beyond the ring threads");
   for(int k_lo = k_begin; k_lo < k_end;)
   {
     // group [k_lo, k_hi): greedy by ring size (every thread computes the same bounds)
+    // Tasks with a normal term or offset (ring: the face's vertices and those of their adjacent faces) go NGN to a group when
+    // their rings fit together, position-only tasks (ring 3) as many as fit; the two kinds are not mixed.
     int k_hi = k_lo, total = 0;
+    bool grp_normal = false;
     while(k_hi < k_end)
     {
       const int nrk = s_ringb[k_hi - k_begin][0];
-      // a task with a normal term (ring > 3) keeps the vertex-normal scratch L_VN to itself: a group of its own
-      if(k_hi > k_lo && (total + nrk > MAXRING || nrk > 3 || total > 3 * (k_hi - k_lo))) break;
+      const bool isn = (ta.noff[tb + k_hi] > 0.0f) || (ta.nrmw[tb + k_hi] > 0.0f); // the task differentiates a normal
+      if(k_hi == k_lo)
+        grp_normal = isn;
+      else if(total + nrk > MAXRING || isn != grp_normal || (grp_normal && k_hi - k_lo >= (dbg_stop == 40 ? 1 : NGN))) // (40: dev switch, one per group)
+        break;
       total += nrk;
       k_hi++;
     }
+    const int ngn = grp_normal ? k_hi - k_lo : 0; // normal tasks of this group (their index in the group: k - k_lo)
     if((int)tid >= k_lo && (int)tid < k_hi) // ring tables of the group
     {
       int off0 = 0;
@@ -607,12 +616,19 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
       rv[14] = verts[v * 3 + 1];
       rv[15] = verts[v * 3 + 2];
     }
-    else if(tid >= 64 && tid < 64 + 3 * MAXADJ * 3) // ring-slot map of the group's (single) normal task
-      s_map[tid - 64] = map_buf[(f * K + k_lo) * (3 * MAXADJ * 3) + (tid - 64)];
-    else if(tid >= 192 && tid < 195)
+    else if(tid >= 64 && tid < 64 + NGN * 128) // ring-slot maps of the group's normal tasks
     {
-      const int u = mv.faces[ta.face[tb + k_lo] * 3 + (tid - 192)];
-      s_cnt[tid - 192] = mv.adjOff[u + 1] - mv.adjOff[u];
+      const int gi = (tid - 64) >> 7, j = (tid - 64) & 127;
+      if(gi < ngn && j < 3 * MAXADJ * 3) s_map[gi][j] = map_buf[(f * K + k_lo + gi) * (3 * MAXADJ * 3) + j];
+    }
+    else if(tid >= 64 + NGN * 128 && tid < 64 + NGN * 128 + NGN * 4)
+    {
+      const int gi = (tid - 64 - NGN * 128) >> 2, j = (tid - 64 - NGN * 128) & 3;
+      if(gi < ngn && j < 3)
+      {
+        const int u = mv.faces[ta.face[tb + k_lo + gi] * 3 + j];
+        s_cnt[gi][j] = mv.adjOff[u + 1] - mv.adjOff[u];
+      }
     }
     __syncthreads();
     if(k_lo == k_begin) EVAL_STAMP(9);
@@ -675,14 +691,16 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
     // B3n (a task with a normal term / offset is alone in its group): the derivative of each of the three vertex normals,
     // one thread per (column, triangle vertex) — the chain n_f -> vn over ~6 adjacent faces is the long part of the
     // kernel for such tasks, and only nq of the 256 threads worked when a column's thread walked all three vertices
-    const bool group_normal = (ta.noff[tb + k_lo] > 0.0f) || (ta.nrmw[tb + k_lo] > 0.0f); // uniform
-    if(group_normal) // d vertexNormal_i / dq  
+    if(ngn > 0) // d vertexNormal_i / dq  
     {
-      const float * dp = lds + L_DP; // ring offset 0
-      for(int item = tid; item < nq * 3; item += EVAL_NT)
+      for(int item = tid; item < ngn * nq * 3; item += EVAL_NT)
       {
-        const int q = item / 3, i = item % 3;
-        int cnt = s_cnt[i];
+        const int gi = item / (nq * 3), qi = item % (nq * 3);
+        const int q = qi / 3, i = qi % 3;
+        const int roff = s_roff[k_lo + gi];
+        const float * dp = lds + L_DP + (roff * 3) * NQ; // this task's ring rows
+        const float * rvb = lds + L_RV + roff * RVS;
+        int cnt = s_cnt[gi][i];
         float sum = 0.f;
         for(int a = 0; a < cnt; a++) sum += 1.0f;
         const float aw = 1.0f / sum;
@@ -691,10 +709,10 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
         for(int a = 0; a < cnt; a++)
         {
           // the adjacent face's corners by ring slot: positions staged in LDS by B1
-          const uint8_t * mp = s_map + (i * MAXADJ + a) * 3;
-          const float * p0 = lds + L_RV + mp[0] * RVS + 13;
-          const float * p1 = lds + L_RV + mp[1] * RVS + 13;
-          const float * p2 = lds + L_RV + mp[2] * RVS + 13;
+          const uint8_t * mp = s_map[gi] + (i * MAXADJ + a) * 3;
+          const float * p0 = rvb + mp[0] * RVS + 13;
+          const float * p1 = rvb + mp[1] * RVS + 13;
+          const float * p2 = rvb + mp[2] * RVS + 13;
           const float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
           const float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
           float cr[3];
@@ -722,9 +740,9 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
         for(int x = 0; x < 3; x++)
         {
           const float vnx = mu[x] / mn;
-          s_nrm[(q * 3 + i) * 6 + x] = vnx;
-          s_nrm[(q * 3 + i) * 6 + 3 + x] = dvn[x];
-          if(q == 0) lds[L_VN + i * 3 + x] = vnx;
+          s_nrm[gi][(q * 3 + i) * 6 + x] = vnx;
+          s_nrm[gi][(q * 3 + i) * 6 + 3 + x] = dvn[x];
+          if(q == 0) lds[L_VN + gi * 12 + i * 3 + x] = vnx;
         }
       }
       __syncthreads();
@@ -746,12 +764,12 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
         for(int i = 0; i < 3; i++)
           for(int x = 0; x < 3; x++)
           {
-            msum[x] += wv[i] * s_nrm[(q * 3 + i) * 6 + x];
-            dm[x] += wv[i] * s_nrm[(q * 3 + i) * 6 + 3 + x];
+            msum[x] += wv[i] * s_nrm[k - k_lo][(q * 3 + i) * 6 + x];
+            dm[x] += wv[i] * s_nrm[k - k_lo][(q * 3 + i) * 6 + 3 + x];
           }
         dnormalize_dev(msum, dm, dn);
         if(q == 0)
-          for(int x = 0; x < 3; x++) lds[L_VN + 9 + x] = msum[x];
+          for(int x = 0; x < 3; x++) lds[L_VN + (k - k_lo) * 12 + 9 + x] = msum[x];
       }
       const int jcol = (q < TD75) ? q : TD75 + 2 * K + (q - TD75);
       float nd = 0.f;
@@ -817,8 +835,8 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
         {
           float dmm[3] = {0.f, 0.f, 0.f};
           for(int i = 0; i < 3; i++)
-            for(int x = 0; x < 3; x++) dmm[x] += dw[i] * lds[L_VN + i * 3 + x];
-          dnormalize_dev(lds + L_VN + 9, dmm, dnn);
+            for(int x = 0; x < 3; x++) dmm[x] += dw[i] * lds[L_VN + (k - k_lo) * 12 + i * 3 + x];
+          dnormalize_dev(lds + L_VN + (k - k_lo) * 12 + 9, dmm, dnn);
         }
         float ndot = 0.f;
         for(int x = 0; x < 3; x++)
