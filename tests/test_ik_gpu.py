@@ -315,3 +315,31 @@ def test_ik_dual_form_solve_matches_the_primal_factorisation(smpl, golden_ik_syn
     assert np.abs(a[1] - b[1]).max() < 2e-6
     assert np.array_equal(a[2], b[2])
     assert np.abs(a[4] - b[4]).max() == 0
+
+
+def test_ik_paired_normal_task_groups_are_bit_identical(smpl, golden_ik_synth, monkeypatch):
+    """ik_eval_kernel takes tasks with a normal term two to a group when their rings fit the LDS buffers together
+    (SMPLPP_IK_DBG_STOP=40: one per group). The arithmetic of every task is unchanged: e, J and the trajectories agree bit
+    for bit."""
+    from smplpp_amd.ik import IkSolver
+
+    g = golden_ik_synth
+    K = len(g["face_idx"])
+    rng = np.random.default_rng(21)
+    n = 24
+    theta0 = np.tile(g["traj_theta"][0], (n, 1, 1)) + rng.normal(0, 0.05, (n, 25, 3)).astype(np.float32)
+    out = []
+    for env in ("40", None):
+        if env is None:
+            monkeypatch.delenv("SMPLPP_IK_DBG_STOP", raising=False)
+        else:
+            monkeypatch.setenv("SMPLPP_IK_DBG_STOP", env)
+        s = IkSolver(smpl, n, K)
+        s.setTasks(face_idx=g["face_idx"], target_pos=g["target_pos"], target_normal=g["target_normal"], phi_limit=np.zeros(K),
+                   normal_task_weight=np.ones(K))
+        s.setConfig(np.zeros((n, 10), np.float32), theta0)
+        e, J = s.eval()
+        e2 = s.iterate(8)
+        out.append((e, J, e2, s.getConfig()[1], s.getTasks()["face_idx"]))
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)
