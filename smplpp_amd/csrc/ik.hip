@@ -360,7 +360,8 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   //   A2  one thread per (task, triangle vertex): vertex normal from those positions (tasks with a normal offset / term)
   //   A3  one thread per task: tangents, weight refresh, residual rows (node.cpp:803-820)
   __shared__ float s_vn[IK_MAXK][9];
-  __shared__ int32_t s_ringb[IK_MAXK][MAXRING + 1];
+  __shared__ uint16_t s_ringb[IK_MAXK][MAXRING + 1]; // (vertex ids fit 16 bits: smplpp_ik_create checks V)
+  __shared__ uint8_t s_usen[IK_MAXK];               // the task differentiates a normal (normal term or normal offset)
   // posed positions of the ring vertices of every task of this workgroup: [task][MAXRING][3], in the dp buffer of phase B
   // (free until then)
   static_assert(IK_MAXK * MAXRING * 3 <= MAXRING * 3 * NQ, "s_rpos must fit the L_DP region");
@@ -371,7 +372,8 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
     const int k = k_begin + tid;
     const int face = ta.face[tb + k];
     const bool use_normal = (ta.noff[tb + k] > 0.0f) || (ta.nrmw[tb + k] > 0.0f);
-    int32_t * ring = s_ringb[tid];
+    uint16_t * ring = s_ringb[tid];
+    s_usen[tid] = use_normal ? 1 : 0;
     uint8_t * map = map_buf + (f * K + k) * (3 * MAXADJ * 3);
     int32_t * ring_out = ring_buf + (f * K + k) * (MAXRING + 1);
     const int key = face * 2 + (use_normal ? 1 : 0);
@@ -555,6 +557,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   __shared__ uint8_t s_map[NGN][3 * MAXADJ * 3]; // (vertex of the face, adjacent face, corner) -> slot in the task's ring, per normal task
   __shared__ int s_cnt[NGN][3];         // adjacent-face count of the face's three vertices
   __shared__ float s_nrm[NGN][NQ * 3 * 6]; // per (column, triangle vertex): vertex normal (3) and its derivative (3)
+  __shared__ __attribute__((aligned(16))) float s_geo[NGN][3 * MAXADJ][12]; // per adjacent face of a triangle vertex: unit normal, |cross|, edges e1, e2
   static_assert(EVAL_NT >= 64 + NGN * 128 + NGN * 4, "B1 hands the map / count loads to thread ranges beyond the ring threads");
   for(int k_lo = k_begin; k_lo < k_end;)
   {
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
     while(k_hi < k_end)
     {
       const int nrk = s_ringb[k_hi - k_begin][0];
-      const bool isn = (ta.noff[tb + k_hi] > 0.0f) || (ta.nrmw[tb + k_hi] > 0.0f); // the task differentiates a normal
+      const bool isn = s_usen[k_hi - k_begin] != 0; // the task differentiates a normal
       if(k_hi == k_lo)
         grp_normal = isn;
       else if(total + nrk > MAXRING || isn != grp_normal || (grp_normal && k_hi - k_lo >= (dbg_stop == 40 ? 1 : NGN))) // (40: dev switch, one per group)
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
     {
       int off0 = 0;
       for(int kk = k_lo; kk < (int)tid; kk++) off0 += s_ringb[kk - k_begin][0];
-      const int32_t * rg = s_ringb[tid - k_begin];
+      const uint16_t * rg = s_ringb[tid - k_begin];
       s_roff[tid] = off0;
       for(int i = 0; i < rg[0]; i++)
       {
@@ -686,6 +689,38 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
       }
       for(int r = 0; r < 3; r++) lds[L_DP + (r_ * 3 + r) * NQ + q] = acc[r] / rv[12];
     }
+    // the column-independent half of B3n, once per adjacent face instead of once per (face, column): edges, unit normal and
+    // |cross| of every face around the three vertices of each normal task (positions staged by B1)
+    if((int)tid < ngn * 3 * MAXADJ)
+    {
+      const int gi = tid / (3 * MAXADJ), ia = tid % (3 * MAXADJ), i = ia / MAXADJ, a = ia % MAXADJ;
+      int cnt = s_cnt[gi][i];
+      if(cnt > MAXADJ) cnt = MAXADJ;
+      if(a < cnt)
+      {
+        const float * rvb = lds + L_RV + s_roff[k_lo + gi] * RVS;
+        const uint8_t * mp = s_map[gi] + ia * 3;
+        const float * p0 = rvb + mp[0] * RVS + 13;
+        const float * p1 = rvb + mp[1] * RVS + 13;
+        const float * p2 = rvb + mp[2] * RVS + 13;
+        const float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+        const float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+        float cr[3];
+        cross3(e1, e2, cr);
+        const float cn = fmaxf(sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]), 1e-12f);
+        float * ge = s_geo[gi][ia];
+        ge[0] = cr[0] / cn;
+        ge[1] = cr[1] / cn;
+        ge[2] = cr[2] / cn;
+        ge[3] = cn;
+        ge[7] = 1.0f / cn;
+        for(int x = 0; x < 3; x++)
+        {
+          ge[4 + x] = e1[x];
+          ge[8 + x] = e2[x];
+        }
+      }
+    }
     __syncthreads();
     if(k_lo == k_begin) EVAL_STAMP(10);
     // B3n (a task with a normal term / offset is alone in its group): the derivative of each of the three vertex normals,
@@ -699,7 +734,6 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
         const int q = qi / 3, i = qi % 3;
         const int roff = s_roff[k_lo + gi];
         const float * dp = lds + L_DP + (roff * 3) * NQ; // this task's ring rows
-        const float * rvb = lds + L_RV + roff * RVS;
         int cnt = s_cnt[gi][i];
         float sum = 0.f;
         for(int a = 0; a < cnt; a++) sum += 1.0f;
@@ -708,15 +742,12 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
         float mu[3] = {0.f, 0.f, 0.f}, dmu[3] = {0.f, 0.f, 0.f};
         for(int a = 0; a < cnt; a++)
         {
-          // the adjacent face's corners by ring slot: positions staged in LDS by B1
+          // the adjacent face's corners by ring slot; its geometry from s_geo (the same values every column used to recompute)
           const uint8_t * mp = s_map[gi] + (i * MAXADJ + a) * 3;
-          const float * p0 = rvb + mp[0] * RVS + 13;
-          const float * p1 = rvb + mp[1] * RVS + 13;
-          const float * p2 = rvb + mp[2] * RVS + 13;
-          const float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
-          const float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
-          float cr[3];
-          cross3(e1, e2, cr);
+          const float4 * ge = reinterpret_cast<const float4 *>(s_geo[gi][i * MAXADJ + a]);
+          const float4 g0 = ge[0], g1 = ge[1], g2 = ge[2];
+          const float nh[3] = {g0.x, g0.y, g0.z}, icn = g1.w;
+          const float e1[3] = {g1.x, g1.y, g1.z}, e2[3] = {g2.x, g2.y, g2.z};
           const float * d0 = dp + (mp[0] * 3) * NQ + q;
           const float * d1 = dp + (mp[1] * 3) * NQ + q;
           const float * d2 = dp + (mp[2] * 3) * NQ + q;
@@ -726,11 +757,16 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
           cross3(de1, e2, t1);
           cross3(e1, de2, t2);
           const float dc[3] = {t1[0] + t2[0], t1[1] + t2[1], t1[2] + t2[2]};
-          dnormalize_dev(cr, dc, dnf);
-          float cn = fmaxf(sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]), 1e-12f);
+          {
+            // dnormalize_dev(cross, dc) with the unit normal and the norm taken from the table
+            const float dd = nh[0] * dc[0] + nh[1] * dc[1] + nh[2] * dc[2];
+            dnf[0] = (dc[0] - nh[0] * dd) * icn; // (a division per column and face before: one reciprocal per face now)
+            dnf[1] = (dc[1] - nh[1] * dd) * icn;
+            dnf[2] = (dc[2] - nh[2] * dd) * icn;
+          }
           for(int x = 0; x < 3; x++)
           {
-            mu[x] += aw * (cr[x] / cn);
+            mu[x] += aw * nh[x];
             dmu[x] += aw * dnf[x];
           }
         }
@@ -2203,6 +2239,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   if(!m || !out || n <= 0 || K <= 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: bad argument");
   *out = nullptr;
   if(m->F <= 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: the model has no faces");
+  if(m->V > 65535) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: at most 65535 vertices are supported (ring tables hold 16-bit ids)");
   if(K > PROJ_MAXK) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: at most 48 tasks per frame are supported");
   if(TD75 + 2 * K + NB > MAXD)
     return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: too many tasks for the in-LDS solver (75 + 2K + 10 must be <= 170)");
