@@ -637,7 +637,8 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
     if(k_lo == k_begin) EVAL_STAMP(9);
     for(int item = tid; item < total * nq; item += EVAL_NT) // B2: dp[rv][:, q]  
     {
-      const int r_ = item / nq, q = item % nq;
+      const int r_ = (nq == TD75) ? item / TD75 : item / NQ; // (nq is one of the two: constant divisions)
+      const int q = item - r_ * nq;
       const int v = s_rvert[r_];
       const float * rv = lds + L_RV + r_ * RVS;
       float acc[3] = {0.f, 0.f, 0.f};
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
     {
       for(int item = tid; item < ngn * nq * 3; item += EVAL_NT)
       {
-        const int gi = item / (nq * 3), qi = item % (nq * 3);
+        const int gi = (nq == TD75) ? item / (TD75 * 3) : item / (NQ * 3), qi = item - gi * (nq * 3);
         const int q = qi / 3, i = qi % 3;
         const int roff = s_roff[k_lo + gi];
         const float * dp = lds + L_DP + (roff * 3) * NQ; // this task's ring rows
@@ -786,7 +787,8 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
     if(k_lo == k_begin) EVAL_STAMP(11);
     for(int item = tid; item < (k_hi - k_lo) * nq; item += EVAL_NT) // B3: one (task, differentiation column) per thread
     {
-      const int k = k_lo + item / nq, q = item % nq;
+      const int kq = (nq == TD75) ? item / TD75 : item / NQ;
+      const int k = k_lo + kq, q = item - kq * nq;
       const float off = ta.noff[tb + k], wp = ta.posw[tb + k], wn = ta.nrmw[tb + k];
       const bool use_normal = (off > 0.0f) || (wn > 0.0f);
       const float w0 = ta.vw[(tb + k) * 3], w1 = ta.vw[(tb + k) * 3 + 1], w2 = ta.vw[(tb + k) * 3 + 2];
