@@ -913,16 +913,26 @@ extern "C" int smplpp_debug_eval_stamps(unsigned long long * out)
 
 // J over the 44-d latent layout from J over theta75 (node.cpp:761-772): columns 0..5 and 69..74 pass through,
 // columns 6..68 (joints 1..21) are pulled back through d(vposer out)/dz [63,32].
-__global__ void ik_latent_jacobian_kernel(const double * __restrict__ J75, const float * __restrict__ vjac, double * __restrict__ Jl,
-                                          int K, int beta_dim, const int * __restrict__ skip)
+constexpr int LJ_ROWS = 8; // Jacobian rows per workgroup of ik_latent_jacobian_kernel
+__global__ __launch_bounds__(256) void ik_latent_jacobian_kernel(const double * __restrict__ J75, const float * __restrict__ vjac,
+                                                                  double * __restrict__ Jl, int K, int beta_dim,
+                                                                  const int * __restrict__ skip)
 {
+  // grid (frames, row chunks): the decoder Jacobian [63,32] of the frame and the chunk's rows of J75[:, 6:69] are staged in
+  // LDS once; one workgroup per frame walked 4K x (44 + 2K) entries with 63 dependent global loads per latent entry
+  // (145 us for a 41-marker frame)
   const int64_t f = blockIdx.x;
   if(skip[f]) return;
+  const int rows = 4 * K, r0 = blockIdx.y * LJ_ROWS, nr = (rows - r0 < LJ_ROWS) ? rows - r0 : LJ_ROWS;
   const int D75 = TD75 + 2 * K + beta_dim, Dl = TD44 + 2 * K + beta_dim;
-  const double * Jf = J75 + f * 4 * K * (int64_t)D75;
-  double * Lf = Jl + f * 4 * K * (int64_t)Dl;
-  const float * vj = vjac + f * 63 * 32;
-  for(int item = threadIdx.x; item < 4 * K * Dl; item += blockDim.x)
+  const double * Jf = J75 + (f * rows + r0) * (int64_t)D75;
+  double * Lf = Jl + (f * rows + r0) * (int64_t)Dl;
+  __shared__ float svj[63 * 32];
+  __shared__ double sJ[LJ_ROWS][63];
+  for(int i = threadIdx.x; i < 63 * 32; i += 256) svj[i] = vjac[f * 63 * 32 + i];
+  for(int i = threadIdx.x; i < nr * 63; i += 256) sJ[i / 63][i % 63] = Jf[(int64_t)(i / 63) * D75 + 6 + i % 63];
+  __syncthreads();
+  for(int item = threadIdx.x; item < nr * Dl; item += 256)
   {
     const int r = item / Dl, c = item % Dl;
     double v;
@@ -931,7 +941,7 @@ __global__ void ik_latent_jacobian_kernel(const double * __restrict__ J75, const
     else if(c < 6 + 32)
     {
       double s = 0.0;
-      for(int q = 0; q < 63; q++) s += Jf[(int64_t)r * D75 + 6 + q] * (double)vj[q * 32 + (c - 6)];
+      for(int q = 0; q < 63; q++) s += sJ[r][q] * (double)svj[q * 32 + (c - 6)];
       v = s;
     }
     else if(c < TD44)
@@ -2482,7 +2492,8 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   HIP_TRY(hipGetLastError());
   if(s->vp)
   {
-    ik_latent_jacobian_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(s->J, s->vjac, s->Jl, K, optimize_beta ? NB : 0, s->skip);
+    ik_latent_jacobian_kernel<<<dim3((unsigned)n, (unsigned)((4 * K + LJ_ROWS - 1) / LJ_ROWS)), dim3(256), 0, st>>>(s->J, s->vjac, s->Jl, K,
+                                                                                                                    optimize_beta ? NB : 0, s->skip);
     HIP_TRY(hipGetLastError());
   }
   s->have_eval = true;
