@@ -205,15 +205,21 @@ constexpr int L_J = L_R + NJ * 9;              // [24][3]
 constexpr int L_G = L_J + NJ * 3;              // [24][12]  relative transforms [A | b]
 constexpr int L_T = L_G + NJ * 12;             // [24][3]   local translations j_i - j_p(i)
 constexpr int L_DR = L_T + NJ * 3;             // [72][9]
-constexpr int L_DAB = L_DR + 72 * 9;           // [24][72][3][4]  per (joint, column): rows [dA_r | db_r] (one 16-byte LDS access per row)
-constexpr int L_DBB = L_DAB + NJ * 12 * 72;    // [24*3][10]
-constexpr int L_RV = L_DBB + NJ * 3 * NB;      // [MAXRING][16]  rest(3) Ablend(9) wsum(1)
-constexpr int RVS = 24;                         // floats per ring vertex: rest 3 | Ablend 9 | wsum 1 | posed 3 | weights 4 | joints 4
-constexpr int L_DP = L_RV + MAXRING * RVS;     // [MAXRING][3][NQ]
-constexpr int NGN = 2;                          // tasks with a normal term / offset per group (their rings share L_RV / L_DP)
-constexpr int L_VN = L_DP + MAXRING * 3 * NQ;  // per such task: [3][3] vertex normals + [3] their weighted sum
+// d[A_i | b_i]/d theta_c is non-zero only when joint(c) is an ancestor of i (or i itself), and a joint has exactly one
+// ancestor per depth: the table keeps, per joint, three columns per DEPTH (column slot 3 depth(joint(c)) + axis(c)) instead of
+// all 72 — 41 KB instead of 83 KB of LDS, which is what lets three tasks with a normal term share the ring buffers below.
+constexpr int DMAX = 12;                       // deepest kinematic tree served (SMPL: 9 levels); smplpp_ik_create checks
+constexpr int CS = 3 * DMAX;                   // column slots per joint
+constexpr int L_DAB = L_DR + 72 * 9;           // [24][CS][3][4]  per (joint, column slot): rows [dA_r | db_r] (one 16-byte LDS access per row)
+constexpr int L_DBB = L_DAB + NJ * 12 * CS;    // [24*3][10]
+constexpr int RCAP = 64;                        // ring vertices a task group can hold (one task: at most MAXRING = 40)
+constexpr int L_RV = L_DBB + NJ * 3 * NB;      // [RCAP][RVS]
+constexpr int RVS = 28;                         // floats per ring vertex: rest 3 | Ablend 9 | wsum 1 | posed 3 | weights 4 | joints 4 | their ancestor masks 4
+constexpr int L_DP = L_RV + RCAP * RVS;        // [RCAP][3][NQ]
+constexpr int NGN = 3;                          // tasks with a normal term / offset per group (their rings share L_RV / L_DP)
+constexpr int L_VN = L_DP + RCAP * 3 * NQ;     // per such task: [3][3] vertex normals + [3] their weighted sum
 constexpr int L_END = L_VN + 12 * NGN;
-constexpr int L_ANC_BYTES = NJ * 4;            // int anc[24] after the float region
+constexpr int L_ANC_BYTES = NJ * 4;            // int anc[24] (ancestor bit masks; depth = popcount - 1) after the float region
 
 #ifndef SMPLPP_EVAL_NT
 #define SMPLPP_EVAL_NT 1024
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   for(int i = tid; i < NJ * 3; i += EVAL_NT) lds[L_J + i] = joints[f * NJ * 3 + i];
   for(int i = tid; i < NJ * 12; i += EVAL_NT) lds[L_G + i] = Gp[f * NJ * 12 + i];
   if(tid == 0)
-    for(int i = 0; i < NJ; i++) sAnc[i] = (1 << i) | (i ? sAnc[mv.parent[i]] : 0);
+    for(int i = 0; i < NJ; i++) sAnc[i] = (1 << i) | (i ? sAnc[mv.parent[i]] : 0); // depth(i) = popcount(anc) - 1
   __syncthreads();
   for(int i = tid; i < NJ * 3; i += EVAL_NT)
   {
@@ -293,14 +299,13 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   if(tid < 216)
   {
     const int c = tid % 72, r = tid / 72, jc = c / 3;
-    for(int i = 0; i < NJ; i++)
+    const int cs = 3 * (__popc(sAnc[jc]) - 1) + c % 3; // this column's slot (3 depth + axis) in the table of every descendant of joint jc
+    for(int i = jc; i < NJ; i++)           // (descendants follow their ancestors in the joint order)
     {
       float dA[3] = {0.f, 0.f, 0.f}, dg = 0.f;
       const int p = mv.parent[i];
-      if(!((sAnc[i] >> jc) & 1))
-      {
-      }
-      else if(i == jc)
+      if(!((sAnc[i] >> jc) & 1)) continue; // not a descendant: no entry (the slot of this depth belongs to i's own ancestor)
+      if(i == jc)
       {
         const float * dR = lds + L_DR + c * 9;
         if(i == 0)
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
       else
       {
         // parent's dA row and dg (dg_p = db_p + dA_p . j_p)
-        const float4 pr = *reinterpret_cast<const float4 *>(lds + L_DAB + ((p * 72 + c) * 3 + r) * 4);
+        const float4 pr = *reinterpret_cast<const float4 *>(lds + L_DAB + ((p * CS + cs) * 3 + r) * 4);
         const float dAp[3] = {pr.x, pr.y, pr.z};
         const float dgp = pr.w + (dAp[0] * lds[L_J + p * 3] + dAp[1] * lds[L_J + p * 3 + 1] + dAp[2] * lds[L_J + p * 3 + 2]);
         const float * Ri = lds + L_R + i * 9;
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
         for(int cc = 0; cc < 3; cc++) dA[cc] = dAp[0] * Ri[cc] + dAp[1] * Ri[3 + cc] + dAp[2] * Ri[6 + cc];
         dg = (dAp[0] * ti[0] + dAp[1] * ti[1] + dAp[2] * ti[2]) + dgp;
       }
-      *reinterpret_cast<float4 *>(lds + L_DAB + ((i * 72 + c) * 3 + r) * 4) =
+      *reinterpret_cast<float4 *>(lds + L_DAB + ((i * CS + cs) * 3 + r) * 4) =
           make_float4(dA[0], dA[1], dA[2], dg - (dA[0] * lds[L_J + i * 3] + dA[1] * lds[L_J + i * 3 + 1] + dA[2] * lds[L_J + i * 3 + 2]));
     }
   }
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   __shared__ uint8_t s_usen[IK_MAXK];               // the task differentiates a normal (normal term or normal offset)
   // posed positions of the ring vertices of every task of this workgroup: [task][MAXRING][3], in the dp buffer of phase B
   // (free until then)
-  static_assert(IK_MAXK * MAXRING * 3 <= MAXRING * 3 * NQ, "s_rpos must fit the L_DP region");
+  static_assert(IK_MAXK * MAXRING * 3 <= RCAP * 3 * NQ, "s_rpos must fit the L_DP region");
   float(*s_rpos)[MAXRING][3] = reinterpret_cast<float(*)[MAXRING][3]>(lds + L_DP);
   const int ntask = k_end - k_begin;
   if(tid < ntask) // A0
@@ -552,8 +557,8 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   // touches up to MAXRING and forms a group of its own): each barrier-separated step then serves the whole group, and the
   // global-memory latencies of the tasks overlap instead of queueing.
   __shared__ int s_roff[IK_MAXK + 1]; // ring offset of task k inside its group's buffers
-  __shared__ int s_rtask[MAXRING];      // ring slot -> task
-  __shared__ int s_rvert[MAXRING];      // ring slot -> vertex
+  __shared__ int s_rtask[RCAP];         // ring slot -> task
+  __shared__ int s_rvert[RCAP];         // ring slot -> vertex
   __shared__ uint8_t s_map[NGN][3 * MAXADJ * 3]; // (vertex of the face, adjacent face, corner) -> slot in the task's ring, per normal task
   __shared__ int s_cnt[NGN][3];         // adjacent-face count of the face's three vertices
   __shared__ float s_nrm[NGN][NQ * 3 * 6]; // per (column, triangle vertex): vertex normal (3) and its derivative (3)
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
       const bool isn = s_usen[k_hi - k_begin] != 0; // the task differentiates a normal
       if(k_hi == k_lo)
         grp_normal = isn;
-      else if(total + nrk > MAXRING || isn != grp_normal || (grp_normal && k_hi - k_lo >= (dbg_stop == 40 ? 1 : NGN))) // (40: dev switch, one per group)
+      else if(total + nrk > RCAP || isn != grp_normal || (grp_normal && k_hi - k_lo >= (dbg_stop == 40 ? 1 : NGN))) // (40: dev switch, one per group)
         break;
       total += nrk;
       k_hi++;
@@ -613,7 +618,9 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
       for(int m = 0; m < 4; m++) // the (first four) skinning weights and joints, so that B2 does not re-read them per column
       {
         rv[16 + m] = (m < mv.maxw) ? mv.wVal[(int64_t)v * mv.maxw + m] : 0.0f;
-        rv[20 + m] = __int_as_float((m < mv.maxw) ? (int)mv.wIdx[(int64_t)v * mv.maxw + m] : 0);
+        const int jm = (m < mv.maxw) ? (int)mv.wIdx[(int64_t)v * mv.maxw + m] : 0;
+        rv[20 + m] = __int_as_float(jm);
+        rv[24 + m] = __int_as_float(sAnc[jm]);
       }
       rv[13] = verts[v * 3]; // posed position: the normal chain of B3 reads its triangles from here, not from HBM
       rv[14] = verts[v * 3 + 1];
@@ -647,13 +654,15 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
       else if(q < TD75)
       {
         const int c = q - 3, jc = c / 3;
+        const int cslot = 3 * (__popc(sAnc[jc]) - 1) + c % 3, jbit = 1 << jc;
         const bool wlds = mv.maxw <= 4;
         for(int m = 0; m < mv.maxw; m++)
         {
           const float wm = wlds ? rv[16 + m] : mv.wVal[(int64_t)v * mv.maxw + m];
           if(wm == 0.0f) continue;
           const int i = wlds ? __float_as_int(rv[20 + m]) : (int)mv.wIdx[(int64_t)v * mv.maxw + m];
-          const float4 * d = reinterpret_cast<const float4 *>(lds + L_DAB + (i * 72 + c) * 12);
+          if(!((wlds ? __float_as_int(rv[24 + m]) : sAnc[i]) & jbit)) continue; // joint(c) does not move joint i: the term is exactly zero
+          const float4 * d = reinterpret_cast<const float4 *>(lds + L_DAB + (i * CS + cslot) * 12);
           for(int r = 0; r < 3; r++)
           {
             const float4 dr4 = d[r];
@@ -2251,6 +2260,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   if(!m || !out || n <= 0 || K <= 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: bad argument");
   *out = nullptr;
   if(m->F <= 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: the model has no faces");
+  if(m->nlev > DMAX) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: kinematic trees deeper than 12 levels are not supported");
   if(m->V > 65535) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: at most 65535 vertices are supported (ring tables hold 16-bit ids)");
   if(K > PROJ_MAXK) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: at most 48 tasks per frame are supported");
   if(TD75 + 2 * K + NB > MAXD)
