@@ -23,7 +23,7 @@ nw = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 sol = IkSolver(s, n, K)
 sol.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, phi_limit=np.zeros(K), normal_task_weight=np.full(K, nw))
 sol.setConfig(np.zeros((n, 10), np.float32), th0)
-sol.iterate(10)
+sol.iterate(int(sys.argv[2]) if len(sys.argv) > 2 else 10)
 L = _lib.load(); buf = (ctypes.c_ulonglong * (64 * 16))()
 L.smplpp_debug_eval_stamps.restype = ctypes.c_int
 assert L.smplpp_debug_eval_stamps(buf) == 0
@@ -32,4 +32,6 @@ names = ["const", "chain", "A0", "A1", "A2", "A3", "B(all)"]
 d = np.diff(T[:, :8], axis=1)
 print("ticks (100 MHz): " + "  ".join("%s %d" % (nm, np.median(d[:, i])) for i, nm in enumerate(names)), " total", np.median(T[:, 7] - T[:, 0]))
 g = T[:, 8:14]
+tot = T[:, 7] - T[:, 0]
+print("total per workgroup: median %d  p90 %d  max %d ; B(all) median %d max %d ; A0 median %d max %d" % (np.median(tot), np.percentile(tot, 90), tot.max(), np.median(d[:, 6]), d[:, 6].max(), np.median(d[:, 2]), d[:, 2].max()))
 print("first group: tables %d  B1 %d  B2 %d  B3n %d  B3 %d  B4 %d" % tuple([np.median(g[:, 0] - T[:, 6])] + [np.median(g[:, i + 1] - g[:, i]) for i in range(5)]))
