@@ -232,9 +232,12 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
   // tangent columns are a [512 x 512] . [512 x 32] GEMM on v_mfma_f32_32x32x2_f32 (exact fp32): wavefront w owns the four
   // 32-row tiles 4w..4w+3, lane l feeds A[row = l % 32][k = l / 32] = W1[row][k] (K-major weights: coalesced) and
   // B[k = l / 32][col = l % 32] = D1[k][col] from LDS, weights prefetched eight k ahead.
+  // With a Jacobian the activation column rides in the tangent loop below instead (same weights, VALU work in the MFMA
+  // shadows); both forms sum the even and the odd k separately and add the halves (they agree to the last bits: 4e-8 rad).
+  if(!want_jac)
   {
     const int r0 = tid, r1 = tid + 256;
-    float h0 = 0.f, h1 = 0.f;
+    float h0 = 0.f, h1 = 0.f, h0o = 0.f, h1o = 0.f;
     constexpr int KU = 16;
     float wa[KU], wb[KU], wan[KU], wbn[KU];
 #pragma unroll
@@ -253,11 +256,13 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
         wbn[u] = w1t[(kn + u) * HID + r1];
       }
 #pragma unroll
-      for(int u = 0; u < KU; u++)
+      for(int u = 0; u < KU; u += 2)
       {
-        const float dv = L1[(k0 + u) * VS + 32];
+        const float dv = L1[(k0 + u) * VS + 32], dvo = L1[(k0 + u + 1) * VS + 32];
         h0 += wa[u] * dv;
         h1 += wb[u] * dv;
+        h0o += wa[u + 1] * dvo;
+        h1o += wb[u + 1] * dvo;
       }
 #pragma unroll
       for(int u = 0; u < KU; u++)
@@ -266,8 +271,8 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
         wb[u] = wbn[u];
       }
     }
-    h0 += b1[r0];
-    h1 += b1[r1];
+    h0 = (h0 + h0o) + b1[r0];
+    h1 = (h1 + h1o) + b1[r1];
     const float s0 = (h0 > 0.0f) ? 1.0f : 0.01f, s1 = (h1 > 0.0f) ? 1.0f : 0.01f;
     L2[r0 * VS + 32] = h0 * s0;
     L2[r1 * VS + 32] = h1 * s1;
@@ -279,6 +284,7 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     const int wave = tid >> 6, l = tid & 63, l31 = l & 31, lh = l >> 5;
     f32x16 acc[4];
+    float hq[4] = {0.f, 0.f, 0.f, 0.f}; // activation of row 32 (4 wave + t) + l31 over this lane's k parity (lh)
 #pragma unroll
     for(int t = 0; t < 4; t++)
 #pragma unroll
@@ -299,14 +305,31 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
 #pragma unroll
       for(int u = 0; u < KU; u++)
       {
-        const float bv = L1[(2 * (k2 + u) + lh) * VS + l31];
+        const float bv = L1[(2 * (k2 + u) + lh) * VS + l31], av = L1[(2 * (k2 + u) + lh) * VS + 32];
 #pragma unroll
-        for(int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[u][t], bv, acc[t], 0, 0, 0);
+        for(int t = 0; t < 4; t++)
+        {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[u][t], bv, acc[t], 0, 0, 0);
+          hq[t] += wq[u][t] * av;
+        }
       }
 #pragma unroll
       for(int u = 0; u < KU; u++)
 #pragma unroll
         for(int t = 0; t < 4; t++) wq[u][t] = wn[u][t];
+    }
+#pragma unroll
+    for(int t = 0; t < 4; t++)
+    {
+      const int row = 32 * (4 * wave + t) + l31;
+      const float ho = __shfl_xor(hq[t], 32, 64); // the other k parity of the same row
+      const float h = ((lh ? ho + hq[t] : hq[t] + ho)) + b1[row]; // (even + odd) + bias, like the VALU form
+      const float sl = (h > 0.0f) ? 1.0f : 0.01f;
+      if(lh == 0)
+      {
+        L2[row * VS + 32] = h * sl;
+        sSlope[row] = sl;
+      }
     }
     __syncthreads(); // slopes are in LDS
 #pragma unroll
@@ -320,9 +343,9 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
   }
   __syncthreads();
   // layer 2: 126 rows (activation column on the VALU, tangents on the matrix pipe: wavefront w owns rows 32w..32w+31)
-  if(tid < OUT6)
+  if(!want_jac && tid < OUT6)
   {
-    float h = 0.f;
+    float h = 0.f, ho = 0.f;
     constexpr int KU = 16;
     float wv[KU], wvn[KU];
 #pragma unroll
@@ -333,11 +356,15 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
 #pragma unroll
       for(int u = 0; u < KU; u++) wvn[u] = w2t[(kn + u) * OUT6 + tid];
 #pragma unroll
-      for(int u = 0; u < KU; u++) h += wv[u] * L2[(k0 + u) * VS + 32];
+      for(int u = 0; u < KU; u += 2)
+      {
+        h += wv[u] * L2[(k0 + u) * VS + 32];
+        ho += wv[u + 1] * L2[(k0 + u + 1) * VS + 32];
+      }
 #pragma unroll
       for(int u = 0; u < KU; u++) wv[u] = wvn[u];
     }
-    so[tid * 33 + 32] = h + b2[tid];
+    so[tid * 33 + 32] = (h + ho) + b2[tid];
   }
   if(want_jac)
   {
@@ -347,6 +374,7 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
     const bool alive = arow < OUT6;
     const int acol = alive ? arow : 0;
     f32x16 acc;
+    float hq = 0.f; // activation of row arow over this lane's k parity
 #pragma unroll
     for(int r = 0; r < 16; r++) acc[r] = 0.0f;
     constexpr int KU = 8;
@@ -363,9 +391,18 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
         wn[u] = alive ? wv : 0.0f;
       }
 #pragma unroll
-      for(int u = 0; u < KU; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[u], L2[(2 * (k2 + u) + lh) * VS + l31], acc, 0, 0, 0);
+      for(int u = 0; u < KU; u++)
+      {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[u], L2[(2 * (k2 + u) + lh) * VS + l31], acc, 0, 0, 0);
+        hq += wq[u] * L2[(2 * (k2 + u) + lh) * VS + 32];
+      }
 #pragma unroll
       for(int u = 0; u < KU; u++) wq[u] = wn[u];
+    }
+    {
+      const float hx = __shfl_xor(hq, 32, 64);
+      const float h = (lh ? hx + hq : hq + hx) + b2[acol];
+      if(alive && lh == 0) so[arow * 33 + 32] = h;
     }
 #pragma unroll
     for(int r = 0; r < 16; r++)

@@ -42,8 +42,8 @@ def test_decoder_forward_and_jacobian(decoders):
     # fp32 vs fp32: 1.3e-5 rad observed on angles near pi (acos/sqrt conditioning); the IK tolerance is 1e-4 rad
     assert np.abs(out - rout).max() < 5e-5
     assert np.abs(jac - rjac).max() < 2e-4 * max(1.0, np.abs(rjac).max())
-    out2 = gpu.forward(z)
-    assert np.abs(out2 - out).max() == 0
+    out2 = gpu.forward(z)  # forward only: the activation columns run on the VALU instead of riding in the tangent loops
+    assert np.abs(out2 - out).max() < 1e-6
 
 
 def test_latent_ik_eval_and_step(decoders, synth_model, oracle_synth, golden_ik_synth):
