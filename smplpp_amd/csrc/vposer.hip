@@ -412,7 +412,9 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
     }
   }
   __syncthreads();
-  // rotation tail: one thread per joint
+  // rotation tail: 6D -> axis-angle and its 3 x 6 Jacobian, one thread per joint; the chain rule into the 32 latent columns
+  // (63 x 32 entries, six terms each) by all threads, coalesced over the columns
+  float * sj = L2; // [21][18]  (the a2/D2 region is dead once layer 2 is done)
   if(tid < 21)
   {
     float o6[6], aa[3], j36[18];
@@ -420,13 +422,18 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
     sixd_to_aa(o6, aa, want_jac ? j36 : nullptr);
     for(int i = 0; i < 3; i++) out[f * out_stride + tid * 3 + i] = aa[i];
     if(want_jac)
-      for(int i = 0; i < 3; i++)
-        for(int c = 0; c < LAT; c++)
-        {
-          float s = 0.f;
-          for(int q = 0; q < 6; q++) s += j36[i * 6 + q] * so[(tid * 6 + q) * 33 + c];
-          jac[(f * 63 + tid * 3 + i) * LAT + c] = s;
-        }
+      for(int q = 0; q < 18; q++) sj[tid * 18 + q] = j36[q];
+  }
+  if(want_jac)
+  {
+    __syncthreads();
+    for(int item = tid; item < 63 * LAT; item += 256)
+    {
+      const int row = item / LAT, c = item % LAT, j = row / 3, i = row % 3;
+      float s = 0.f;
+      for(int q = 0; q < 6; q++) s += sj[j * 18 + i * 6 + q] * so[(j * 6 + q) * 33 + c];
+      jac[(f * 63 + row) * LAT + c] = s;
+    }
   }
 }
 
