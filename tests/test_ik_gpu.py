@@ -343,3 +343,40 @@ def test_ik_paired_normal_task_groups_are_bit_identical(smpl, golden_ik_synth, m
         out.append((e, J, e2, s.getConfig()[1], s.getTasks()["face_idx"]))
     for x, y in zip(out[0], out[1]):
         assert np.array_equal(x, y)
+
+
+def test_ik_eval_mixed_task_kinds_vs_oracle(smpl, oracle_synth):
+    """13 tasks per frame, every third one position-only (no normal term, no offset): the evaluation kernel groups the two
+    kinds separately (three normal tasks or any number of position-only ones per pass) in task order."""
+    from oracle import cpu
+    from smplpp_amd import model_io
+    from smplpp_amd.ik import IkSolver
+
+    rng = np.random.default_rng(33)
+    n, K = 3, 13
+    beta, theta = model_io.synthetic_inputs(n, seed=78)
+    theta[:, 1:] *= 0.5
+    faces = rng.integers(0, 13776, (n, K))
+    tp = rng.normal(0, 0.4, (n, K, 3)).astype(np.float32)
+    tn = rng.normal(0, 1, (n, K, 3)).astype(np.float32)
+    tn /= np.linalg.norm(tn, axis=2, keepdims=True)
+    bary = rng.dirichlet(np.ones(3), (n, K)).astype(np.float32)
+    plain = (np.arange(K) % 3 == 0)
+    nw = np.where(plain, 0.0, 1.3)
+    noff = np.where(plain, 0.0, 0.015)
+    s = IkSolver(smpl, n, K)
+    s.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, vertex_weights=bary, phi_limit=np.full((n, K), 0.04),
+               normal_offset=np.tile(noff, (n, 1)), normal_task_weight=np.tile(nw, (n, 1)))
+    s.setConfig(beta, theta)
+    e, J = s.eval(optimize_beta=False)
+    for f in range(n):
+        ts = cpu.TaskSet(faces[f], tp[f], tn[f], vertex_weights=bary[f], phi_limit=np.full(K, 0.04), normal_offset=noff)
+        ts.normal_task_weight[:] = nw
+        r = oracle_synth.ik_eval(beta[f], theta[f], ts, False)
+        de = np.abs(r["e"] - e[f]).reshape(K, 4)
+        assert de[:, :3].max() < 5e-6 and de[:, 3].max() < 1e-4
+        dJ = np.abs(r["J"] - J[f]).reshape(K, 4, -1)
+        scale = max(1.0, np.abs(r["J"]).max())
+        assert dJ[:, :3].max() < 1e-4 * scale, f
+        assert dJ[:, 3].max() < 6e-4 * scale, f
+        assert np.abs(J[f].reshape(K, 4, -1)[plain, 3]).max() == 0  # no normal row for a position-only task
