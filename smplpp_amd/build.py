@@ -11,9 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsmplpp_hip.so")
 ARCH = "gfx950"
+# skin_h.hip: accumulators in arch VGPRs (its VALU epilogue reads them; the A operand takes the AGPRs).
 # skin_p.hip places its VALU work by hand in MFMA shadows: SLP-packing adjacent f32 FMAs into v_pk_fma_f32 (+ the v_mov
 # shuffles that feeds them) is an anti-lever beside MFMAs (cdna_hip_programming.md, per-instruction constants).
-PER_FILE_FLAGS = {"skin_p.hip": ["-fno-slp-vectorize"], "skin_b.hip": ["-fno-slp-vectorize"], "skin_q.hip": ["-fno-slp-vectorize"], "fk.hip": ["-fno-slp-vectorize"]}
+PER_FILE_FLAGS = {"skin_p.hip": ["-fno-slp-vectorize"], "skin_b.hip": ["-fno-slp-vectorize"], "skin_h.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"], "fk.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -60,6 +60,31 @@ __host__ __device__ inline void split_bf16x3(float x, uint16_t & p0, uint16_t & 
   p2 = bf16_rn_bits(r2);
 }
 
+// ---- fp16x2 form of the fused kernel (skin_h.hip, the default): every fp32 operand value x is carried as TWO fp16
+// pieces of s.x (s a power of two chosen per operand so that the pieces stay in fp16's normal range):
+// hi = fp16(s x), lo = fp16(s x - hi), |s x - hi - lo| <= 2^-22 |s x|; a product is the three MFMAs
+// lo.hi + hi.lo + hi.hi (the dropped lo.lo term is < 2^-22 |a||b|).  All arrays are in MFMA fragment order for
+// v_mfma_f32_32x32x16_f16: a "piece" is 1 KiB, lane l = 32 h + r holds k = 16 ks + 8 h + j (j = 0..7) of row/column r.
+//   A2h [ceil(n/64)][HB_KS][fh 2][piece 2][64 lanes][8 fp16]                 frame = 64 ft + 32 fh + r; value sA.a
+//   B2h [ceil(V/64)][HB_SLOTS][12 KiB]: slots 0..13 = k-steps: [vh 2][coordinate 3][piece 2][64][8]  (value sB.b)
+//                                       slot 14 = skinning weights of the group: [ks 2][vh 2][piece 2][64][8] fp16 of
+//                                       sW.W[v][joint k] (k >= 24: 0), then cw[64] fp32 = 1 / (sG sW sum_j W[v,j]), then padding
+//   G2h [ceil(n/64)][fh 2][entry 12][3 KiB]: relative transforms as the A operand of the blend MFMAs (rows = frames,
+//                                       k = joint): ks 0: [piece 2][64][8]; ks 1 (joints 16..23): [piece 2][32 lanes][8]
+constexpr int HB_KS = 14;
+constexpr int HB_SLOTS = 15;
+constexpr int HB_A_BYTES = 4 * 1024;   // A pieces of one (frame tile, k-step)
+constexpr int HB_IMG = 12 * 1024;      // one slot of B2h = one LDS ring image
+constexpr int HB_G_BYTES = 72 * 1024;  // G2h of one frame tile
+constexpr int HB_CW_OFF = 8 * 1024;    // cw[64] inside slot 14
+constexpr float HB_SA = 64.0f;         // scale of the A operand (|c| <= 2, |beta| < 1023)
+constexpr float HB_SW = 16384.0f;      // scale of the skinning weights (|W| <= 1)
+__host__ __device__ inline void split_f16x2(float xs, _Float16 & hi, _Float16 & lo) // xs: already scaled
+{
+  hi = (_Float16)xs;
+  lo = (_Float16)(xs - (float)hi);
+}
+
 void set_error(const std::string & msg);
 int fail(int code, const std::string & msg);
 int hip_fail(hipError_t e, const char * what, const char * file, int line);
@@ -70,6 +95,30 @@ int hip_fail(hipError_t e, const char * what, const char * file, int line);
     hipError_t _e = (expr);                                                        \
     if(_e != hipSuccess) return smplpp_hip::hip_fail(_e, #expr, __FILE__, __LINE__); \
   } while(0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is an opt-in per DEVICE: one flag per (call site, device)
+struct PerDeviceOnce
+{
+  bool done[64] = {};
+};
+inline hipError_t lds_opt_in(PerDeviceOnce & o, int device, const void * fn, int bytes)
+{
+  if(o.done[device & 63]) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if(e == hipSuccess) o.done[device & 63] = true;
+  return e;
+}
+inline int device_cus(int device) // compute units of a device (cached per device)
+{
+  static int cus[64] = {};
+  int & c = cus[device & 63];
+  if(!c)
+  {
+    hipDeviceProp_t prop;
+    c = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return c;
+}
 
 // Growable device buffer
 struct DevBuf
@@ -104,15 +153,14 @@ struct Workspace
 {
   DevBuf AT;      // [KP][ldA] fp32, K-major A operand (pose coefficients | beta | 1)
   DevBuf A3;      // the same coefficients as bf16x3 pieces in fragment order (skin_b.hip)
+  DevBuf A2h;     // the same coefficients as fp16x2 pieces in fragment order (skin_h.hip)
+  DevBuf G2h;     // relative transforms as fp16x2 pieces, the A operand of the blend MFMAs (skin_h.hip)
   DevBuf Gp;      // [n][24][12] relative transforms, 3x4 row-major
   DevBuf joints;  // [n][24][3]
   DevBuf poserot; // [n][24][9]
   DevBuf beta, theta, verts, rest, xf44; // staging for host-pointer calls
   int64_t ldA = 0;
-  // work queues of the persistent fused kernel (skin_q.hip)
-  DevBuf q_ctr, q_desc, dummy; // dummy: write-only sink for masked-off lanes of branch-free epilogues
-  int64_t q_n = -1;
-  int q_grid = 0;
+  DevBuf dummy;   // write-only sink for masked-off lanes of branch-free epilogues (skin_p.hip)
 };
 } // namespace smplpp_hip
 
@@ -127,6 +175,9 @@ struct smplpp_model
   float * Bm = nullptr;        // [KP][ldB]
   uint8_t * B3 = nullptr;      // Bm as bf16x3 pieces in MFMA fragment order (layout above)
   int64_t VGPn = 0;            // vertex-group pairs: ceil(V / 64)
+  uint8_t * B2h = nullptr;     // bases + skinning weights as fp16x2 pieces in MFMA fragment order (layout above)
+  float sB = 1.0f, sG = 1.0f;  // power-of-two scales of the basis operand and of the relative transforms (fp16 range)
+  char form = 'h';             // fused-kernel form (SMPLPP_SKIN, read once at model creation): h | b | p | v
   uint8_t * wIdx = nullptr;    // [VGn*32][maxw]
   float * wVal = nullptr;      // [VGn*32][maxw]
   float * wSum = nullptr;      // [VGn*32]  sum_j W[v,j] in ascending j (the blended homogeneous w)

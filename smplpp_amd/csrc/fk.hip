@@ -17,11 +17,10 @@
 // given to one XCD, consecutively, so each 338 KB slice of Bm is pulled into that XCD's L2 once per launch.
 #include "common.h"
 
-#include <cstdlib>
-
 namespace smplpp_hip
 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------------------------------------- pose kernel
 __device__ inline void rodrigues_dev(float t0, float t1, float t2, float * R)
@@ -70,7 +69,8 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
                                                    const int32_t * __restrict__ lvl_joint, int nlev, float * __restrict__ AT, int64_t ldA,
                                                    float * __restrict__ Gp, float * __restrict__ joints_out,
                                                    float * __restrict__ rot_out, float * __restrict__ xf44_out, int64_t n,
-                                                   uint16_t * __restrict__ A3)
+                                                   uint16_t * __restrict__ A3, _Float16 * __restrict__ A2h,
+                                                   _Float16 * __restrict__ G2h, float gscale)
 {
   const int64_t f = blockIdx.x;
   const int tid = threadIdx.x;
@@ -158,6 +158,26 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
     w.w = pc[6] | ((uint32_t)pc[7] << 16);
     *reinterpret_cast<uint4 *>(dst) = w;
   }
+  if(A2h && tid >= 96 && tid < 96 + 28)
+  {
+    // fp16x2 pieces in MFMA fragment order (layout: common.h): chunk c = k / 8 is element block j of MFMA lane 32 h + r in
+    // k-step ks = c / 2, h = c % 2; both pieces of the chunk by one thread
+    const int c = tid - 96, ks = c >> 1, h = c & 1;
+    const int64_t ft = f >> 6;
+    const int fh = (int)((f >> 5) & 1), r = (int)(f & 31);
+    f16x8 hi, lo;
+#pragma unroll
+    for(int j = 0; j < 8; j++)
+    {
+      _Float16 a, b;
+      split_f16x2(sCoef[8 * c + j] * HB_SA, a, b);
+      hi[j] = a;
+      lo[j] = b;
+    }
+    _Float16 * dst = A2h + ((((ft * HB_KS + ks) * 2 + fh) * 2) * 64 + (32 * h + r)) * 8;
+    *reinterpret_cast<f16x8 *>(dst) = hi;
+    *reinterpret_cast<f16x8 *>(dst + 64 * 8) = lo;
+  }
   if(tid >= 192)
   {
     // chain: G_0 = L_0, G_i = G_p(i) . L_i with L_i = [R_i | j_i - j_p(i)] (src/WorldTransformation.cpp:508-610), level by
@@ -198,6 +218,37 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
     if(xf44_out) xf44_out[(f * NJ + i) * 16 + q] = v;
   }
   if(xf44_out && tid < NJ * 4) xf44_out[(f * NJ + tid / 4) * 16 + 12 + tid % 4] = (tid % 4 == 3) ? 1.0f : 0.0f;
+  if(G2h && tid >= 64 && tid < 64 + 36)
+  {
+    // the relative transforms once more as the A operand of the blend MFMAs of skin_h.hip (rows = frames, k = joint):
+    // thread (entry e, chunk c) writes both fp16x2 pieces of joints 8 c .. 8 c + 7 of entry e (layout: common.h)
+    const int e = (tid - 64) / 3, c = (tid - 64) % 3, r4 = e / 4, cc = e % 4;
+    const int64_t ft = f >> 6;
+    const int fh = (int)((f >> 5) & 1), r = (int)(f & 31);
+    f16x8 hi, lo;
+#pragma unroll
+    for(int j = 0; j < 8; j++)
+    {
+      const int i = 8 * c + j;
+      float v = sG[i][e];
+      if(cc == 3) v -= sG[i][r4 * 4 + 0] * sJ[i][0] + sG[i][r4 * 4 + 1] * sJ[i][1] + sG[i][r4 * 4 + 2] * sJ[i][2];
+      _Float16 a, b;
+      split_f16x2(v * gscale, a, b);
+      hi[j] = a;
+      lo[j] = b;
+    }
+    _Float16 * blk = G2h + (((ft * 2 + fh) * 12 + e) * 3072) / 2;
+    if(c < 2)
+    {
+      *reinterpret_cast<f16x8 *>(blk + (32 * c + r) * 8) = hi;
+      *reinterpret_cast<f16x8 *>(blk + 512 + (32 * c + r) * 8) = lo;
+    }
+    else
+    {
+      *reinterpret_cast<f16x8 *>(blk + 1024 + r * 8) = hi;
+      *reinterpret_cast<f16x8 *>(blk + 1024 + 256 + r * 8) = lo;
+    }
+  }
 }
 
 // rows [n, ldA) of AT are padding for the last 32-frame tile: keep them zero (re-zeroed whenever n changes)
@@ -218,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void skin_kernel(const float * __restrict__
                                                    int64_t ldB, const float * __restrict__ Gp, const float * __restrict__ theta,
                                                    const uint8_t * __restrict__ wIdx, const float * __restrict__ wVal,
                                                    const float * __restrict__ wSum, float * __restrict__ verts,
-                                                   float * __restrict__ rest, int64_t n, int64_t V, int VGn, int nft, int dbg_mode)
+                                                   float * __restrict__ rest, int64_t n, int64_t V, int VGn, int nft)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[]; // [32*FT][24][12] G' + [32*FT][3] root translation
   constexpr int FRAMES = 32 * FT;
@@ -260,16 +311,11 @@ __global__ __launch_bounds__(256, 2) void skin_kernel(const float * __restrict__
 #pragma unroll
       for(int r = 0; r < 16; r++) acc[t][x][r] = 0.0f;
 
-  if(vg < VGn && dbg_mode != 2)
+  if(vg < VGn)
   {
     // operand pointers: lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31]
     const float * Ap = AT + (int64_t)(lane >> 5) * ldA + f0 + (lane & 31);
     const float * Bp = Bm + (int64_t)(lane >> 5) * ldB + (int64_t)vg * (3 * VG) + (lane & 31);
-    if(dbg_mode == 3) // timing experiment: every wavefront reads the same operand rows (pure L1 hits)
-    {
-      Ap = AT + (int64_t)(lane >> 5) * ldA + (lane & 31);
-      Bp = Bm + (int64_t)(lane >> 5) * ldB + (lane & 31);
-    }
     // Ping-pong operand buffers P/Q, each one chunk (UNR k-steps) deep, loop unrolled by two chunks so that no register
     // copies exist for the compiler to fold the two buffers back into one: the loads of a chunk are issued a full chunk
     // of MFMAs (UNR * FT * 3 * 64 cycles) before their first use.
@@ -296,16 +342,6 @@ __global__ __launch_bounds__(256, 2) void skin_kernel(const float * __restrict__
     };
     constexpr int NCH = KSTEPS / UNR; // 22 (even)
     load_chunk(0, aP, bP);
-    if(dbg_mode == 4) // timing experiment: no operand loads inside the loop at all
-    {
-      load_chunk(1, aQ, bQ);
-      for(int c = 0; c < NCH; c += 2)
-      {
-        mfma_chunk(aP, bP);
-        mfma_chunk(aQ, bQ);
-      }
-    }
-    else
     for(int c = 0; c < NCH; c += 2)
     {
       load_chunk(c + 1, aQ, bQ);
@@ -319,14 +355,6 @@ __global__ __launch_bounds__(256, 2) void skin_kernel(const float * __restrict__
   if(vg >= VGn) return;
   const int64_t v = (int64_t)vg * VG + (lane & 31);
   if(v >= V) return;
-  if(dbg_mode == 1 || dbg_mode == 3 || dbg_mode == 4) // timing experiment: MFMA loop only (keep the accumulators alive)
-  {
-    float s = 0.f;
-    for(int t = 0; t < FT; t++)
-      for(int x = 0; x < 3; x++) s += acc[t][x][0] + acc[t][x][15];
-    if(s == 12345.678f) verts[0] = s;
-    return;
-  }
   // this lane's skinning weights
   int jidx[MAXW];
   float jw[MAXW];
@@ -389,19 +417,15 @@ static hipError_t launch_skin(const smplpp_model * m, int64_t n, const float * t
   const int nft = (int)((n + 32 * FT - 1) / (32 * FT));
   const int nq = (int)((m->VGn + 3) / 4);
   const int grid = 8 * ((nq + 7) / 8) * nft;
-  size_t shmem = sizeof(float) * (size_t)(32 * FT) * (NJ * 12 + 3);
-  if(getenv("SMPLPP_SKIN_ONE_PER_CU")) shmem = 100 * 1024; // timing experiment: one workgroup per CU
-  static bool attr_set = false;
-  if(!attr_set)
+  const size_t shmem = sizeof(float) * (size_t)(32 * FT) * (NJ * 12 + 3);
+  static PerDeviceOnce once;
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&skin_kernel<FT, MAXW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipError_t e = lds_opt_in(once, m->device, reinterpret_cast<const void *>(&skin_kernel<FT, MAXW>), (int)shmem);
     if(e != hipSuccess) return e;
-    attr_set = true;
   }
   skin_kernel<FT, MAXW><<<dim3(grid), dim3(256), shmem, st>>>(m->ws.AT.as<float>(), m->ws.ldA, m->Bm, m->ldB,
                                                               m->ws.Gp.as<float>(), theta, m->wIdx, m->wVal, m->wSum, verts,
-                                                              rest, n, m->V, (int)m->VGn, nft, getenv("SMPLPP_SKIN_DBG") ? atoi(getenv("SMPLPP_SKIN_DBG")) : 0);
+                                                              rest, n, m->V, (int)m->VGn, nft);
   return hipGetLastError();
 }
 
@@ -421,30 +445,38 @@ static hipError_t launch_skin_w(const smplpp_model * m, int64_t n, const float *
 }
 
 hipError_t launch_skin_persistent(const smplpp_model * m, int64_t n, const float * theta, const float * Gp_padded, float * verts,
-                                  float * rest, hipStream_t st); // skin_p.hip (experimental: one wave/SIMD, epilogue in the MFMA shadow)
+                                  float * rest, hipStream_t st); // skin_p.hip (fp32 MFMA, one wave/SIMD, epilogue in the MFMA shadow)
 hipError_t launch_skin_bf16x3(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st); // skin_b.hip
-hipError_t launch_skin_queue(smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st); // skin_q.hip
+hipError_t launch_skin_f16x2(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st);  // skin_h.hip
 
 // Device-pointer FK (enqueue only).  Used by smplpp_fk and by the IK solver.
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
               float * xforms44, float * rest, float * poserot, hipStream_t st)
 {
   Workspace & ws = m->ws;
-  // SMPLPP_SKIN = b | p | q | v1 selects the form of the fused kernel for A/B runs.  Default b (skin_b.hip): bf16x3
-  // operand pieces on the bf16 matrix pipe, fp32-exact; p (skin_p.hip): fp32 MFMA, one wavefront per SIMD, persistent,
-  // skinning rows issued in MFMA shadows; q (skin_q.hip, staggered work queue) and v1 (skin_kernel above) are kept for
-  // comparison.  p (32-bit output offsets) falls back to v1 for outputs of 2 GiB and more; b splits such batches itself.
-  const char * form_env = getenv("SMPLPP_SKIN"); // read per call: the parity tests switch forms inside one process
-  char form = form_env ? form_env[0] : 'b';
-  if(m->maxw > 8) form = 'v';
-  if(form == 'p' && n * m->V * 12 >= 0x7fffff00LL) form = 'v'; // (b splits such batches into launches of <= 2 GiB itself)
+  // Form of the fused kernel (m->form, from SMPLPP_SKIN at model creation; smplpp_model_set_form for A/B runs): h (default,
+  // skin_h.hip): fp16x2 operand pieces on the f16 matrix pipe, skinning on the matrix pipe too; b (skin_b.hip): bf16x3
+  // pieces, VALU skinning in MFMA shadows; p (skin_p.hip): exact fp32 MFMA; v (skin_kernel above): the first form.
+  // b needs <= 8 weights per vertex; p (32-bit output offsets) falls back to v for outputs of 2 GiB and more.
+  char form = m->form;
+  if(m->maxw > 8 && (form == 'b' || form == 'p')) form = 'v';
+  if(form == 'p' && n * m->V * 12 >= 0x7fffff00LL) form = 'v';
   const int64_t n64 = ((n + 63) / 64) * 64;
   HIP_TRY(ws.Gp.reserve(sizeof(float) * (size_t)n64 * NJ * 12)); // b / p stage whole frame tiles of G' (padding never stored)
-  if(form == 'b')
+  if(form == 'h')
+  {
+    HIP_TRY(ws.A2h.reserve((size_t)(n64 / 64) * HB_KS * HB_A_BYTES));
+    HIP_TRY(ws.G2h.reserve((size_t)(n64 / 64) * HB_G_BYTES));
+    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
+                                                         ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr,
+                                                         (verts || rest) ? ws.A2h.as<_Float16>() : nullptr,
+                                                         (verts || rest) ? ws.G2h.as<_Float16>() : nullptr, m->sG);
+  }
+  else if(form == 'b')
   {
     HIP_TRY(ws.A3.reserve((size_t)(n64 / 64) * BB_KS * BB_A_BYTES));
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
-                                                         ws.Gp.as<float>(), joints, poserot, xforms44, n, ws.A3.as<uint16_t>());
+                                                         ws.Gp.as<float>(), joints, poserot, xforms44, n, ws.A3.as<uint16_t>(), nullptr, nullptr, 1.0f);
   }
   else
   {
@@ -458,7 +490,7 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
       zero_pad_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(ws.AT.as<float>(), ldA, n);
     }
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, ws.AT.as<float>(),
-                                                         ldA, ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr);
+                                                         ldA, ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr, nullptr, nullptr, 1.0f);
   }
   HIP_TRY(hipGetLastError());
   if(verts || rest)
@@ -470,10 +502,10 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
       HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, st));
     }
-    if(form == 'b')
+    if(form == 'h')
+      HIP_TRY(launch_skin_f16x2(m, n, theta, verts, rest, st));
+    else if(form == 'b')
       HIP_TRY(launch_skin_bf16x3(m, n, theta, verts, rest, st));
-    else if(form == 'q')
-      HIP_TRY(launch_skin_queue(m, n, theta, verts, rest, st));
     else if(form == 'p' && ws.dummy.reserve(4096) == hipSuccess)
       HIP_TRY(launch_skin_persistent(m, n, theta, ws.Gp.as<float>(), verts, rest, st));
     else if(n <= 32)

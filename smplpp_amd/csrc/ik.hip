@@ -2212,6 +2212,11 @@ struct smplpp_ik
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool phi_locked = false;
   bool side_pending = false; // a finish kernel is in flight on the side stream; ev_join marks its end
+  // development switches, read ONCE at creation (never in the per-call path): SMPLPP_DEBUG_SYNC, SMPLPP_IK_DBG_STOP,
+  // SMPLPP_IK_OVERLAP=0 (re-projection behind the solve on one stream), SMPLPP_SCAN_BLOCKS
+  bool dbg_sync = false, overlap_ok = true;
+  int dbg_stop = 0;
+  int64_t scan_blocks = 1536;
   float * vbuf[2] = {nullptr, nullptr};
   int vcur = 0;
 };
@@ -2275,6 +2280,14 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   s->n = n;
   s->K = K;
   s->theta_dim = vposer ? TD44 : TD75;
+  {
+    const char * e;
+    s->dbg_sync = getenv("SMPLPP_DEBUG_SYNC") != nullptr;
+    if((e = getenv("SMPLPP_IK_DBG_STOP"))) s->dbg_stop = atoi(e);
+    if((e = getenv("SMPLPP_IK_OVERLAP"))) s->overlap_ok = e[0] != '0';
+    if(s->dbg_sync) s->overlap_ok = false;
+    if((e = getenv("SMPLPP_SCAN_BLOCKS"))) s->scan_blocks = atoll(e);
+  }
   const size_t nk = (size_t)n * K;
   const size_t Dmax = TD75 + 2 * K + NB;
 #define A_(field, count)                                         \
@@ -2486,19 +2499,15 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
     s->side_pending = false;
   }
   const size_t shmem = sizeof(float) * L_END + L_ANC_BYTES;
-  static bool attr = false;
-  if(!attr)
-  {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ik_eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr = true;
-  }
+  static PerDeviceOnce once_eval;
+  HIP_TRY(lds_opt_in(once_eval, m->device, reinterpret_cast<const void *>(&ik_eval_kernel), (int)shmem));
   int tsplit = (n < 256) ? (int)(256 / n) : 1; // one round of workgroups (one per CU: 83 KB of LDS each)
   if(tsplit > K) tsplit = K;
   if(tsplit < 1) tsplit = 1;
   hipExtLaunchKernelGGL(ik_eval_kernel, dim3((unsigned)(n * tsplit)), dim3(EVAL_NT), shmem, st, nullptr, eval_done, 0, view_of(m), s->ta, th25,
                         (const float *)s->verts, (const float *)s->rest, (const float *)m->ws.Gp.as<float>(), (const float *)s->joints,
                         (const float *)s->poserot, K, optimize_beta, phi_live, (int)min_valid, s->ring, s->ringkey, s->map, s->pts, s->e,
-                        s->J, s->skip, getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0, tsplit);
+                        s->J, s->skip, s->dbg_stop, tsplit);
   HIP_TRY(hipGetLastError());
   if(s->vp)
   {
@@ -2534,18 +2543,13 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
   int rc = SMPLPP_OK;
   smplpp_model * m = s->m;
   const int K = (int)s->K;
-  static bool attr = false;
-  if(!attr)
-  {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ik_solve_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ik_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    attr = true;
-  }
-  const bool dbg = getenv("SMPLPP_DEBUG_SYNC") != nullptr;
-  const int dbg_stop = getenv("SMPLPP_IK_DBG_STOP") ? atoi(getenv("SMPLPP_IK_DBG_STOP")) : 0;
-  const char * ov = getenv("SMPLPP_IK_OVERLAP"); // dev switch: 0 keeps the scan behind the solve
-  const bool overlap_ok = !(ov && ov[0] == '0') && !dbg;
-  const int64_t scan_blocks = getenv("SMPLPP_SCAN_BLOCKS") ? atoll(getenv("SMPLPP_SCAN_BLOCKS")) : 1536; // dev switch
+  static PerDeviceOnce once_solve[2];
+  HIP_TRY(lds_opt_in(once_solve[0], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false>), 152 * 1024));
+  HIP_TRY(lds_opt_in(once_solve[1], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<true>), 152 * 1024));
+  const bool dbg = s->dbg_sync;
+  const int dbg_stop = s->dbg_stop;
+  const bool overlap_ok = s->overlap_ok;
+  const int64_t scan_blocks = s->scan_blocks;
 #define DBG_SYNC(tag)                                                            \
   if(dbg)                                                                        \
   {                                                                              \

@@ -16,9 +16,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace smplpp_hip
 {
+typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
 static thread_local std::string g_last_error;
 
 void set_error(const std::string & msg)
@@ -91,6 +93,71 @@ __global__ void relayout_basis_bf16x3_kernel(const float * __restrict__ Bm, int6
   }
 }
 
+// B2h <- Bm and the skinning weights as fp16x2 pieces in MFMA fragment order (layout: common.h).  One thread per 16-byte
+// chunk pair (hi, lo): slots 0..13: ((vg * 15 + ks) * 6 + vh * 3 + x) * 64 + lane; slot 14: weights, cw, padding.
+__global__ void relayout_basis_f16x2_kernel(const float * __restrict__ Bm, int64_t ldB, const float * __restrict__ W,
+                                            const float * __restrict__ wSum, int64_t V, int64_t nvg, float sB, float sG,
+                                            uint8_t * __restrict__ B2h)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_vg = HB_KS * 6 * 64 + 4 * 64 + 64; // basis chunk pairs + weight chunk pairs + cw entries
+  if(i >= nvg * per_vg) return;
+  const int64_t vg = i / per_vg;
+  const int q = (int)(i % per_vg);
+  uint8_t * base = B2h + vg * (int64_t)(HB_SLOTS * HB_IMG);
+  f16x8h hi, lo;
+  if(q < HB_KS * 6 * 64)
+  {
+    const int lane = q % 64, h = lane >> 5, r = lane & 31;
+    const int vx = (q / 64) % 6, vh = vx / 3, x = vx % 3, ks = q / (64 * 6);
+    const int64_t v = vg * 64 + vh * 32 + r;
+    for(int j = 0; j < 8; j++)
+    {
+      const int k = ks * 16 + 8 * h + j;
+      const float val = (v < V && k < KP) ? Bm[(int64_t)k * ldB + bcol(v, x)] : 0.0f;
+      _Float16 a, b;
+      split_f16x2(val * sB, a, b);
+      hi[j] = a;
+      lo[j] = b;
+    }
+    uint8_t * dst = base + ks * HB_IMG + ((vh * 3 + x) * 2) * 1024 + lane * 16;
+    *reinterpret_cast<f16x8h *>(dst) = hi;
+    *reinterpret_cast<f16x8h *>(dst + 1024) = lo;
+  }
+  else if(q < HB_KS * 6 * 64 + 4 * 64)
+  {
+    const int w = q - HB_KS * 6 * 64, lane = w % 64, h = lane >> 5, r = lane & 31, vh = (w / 64) % 2, ks = w / 128;
+    const int64_t v = vg * 64 + vh * 32 + r;
+    for(int j = 0; j < 8; j++)
+    {
+      const int k = ks * 16 + 8 * h + j; // joint
+      const float val = (v < V && k < NJ) ? W[v * NJ + k] : 0.0f;
+      _Float16 a, b;
+      split_f16x2(val * HB_SW, a, b);
+      hi[j] = a;
+      lo[j] = b;
+    }
+    uint8_t * dst = base + HB_KS * HB_IMG + ((ks * 2 + vh) * 2) * 1024 + lane * 16;
+    *reinterpret_cast<f16x8h *>(dst) = hi;
+    *reinterpret_cast<f16x8h *>(dst + 1024) = lo;
+  }
+  else
+  {
+    // cw = 1 / (sG sW h[3]) with h[3] = sum_j W[v,j], the homogeneous coordinate the reference divides by
+    // (src/LinearBlendSkinning.cpp:545-550): one reciprocal per vertex (<= 1 ulp from the division)
+    const int c = q - (HB_KS * 6 * 64 + 4 * 64);
+    const int64_t v = vg * 64 + c;
+    float * cw = reinterpret_cast<float *>(base + HB_KS * HB_IMG + HB_CW_OFF);
+    cw[c] = v < V ? (1.0f / wSum[v]) / (sG * HB_SW) : 0.0f;
+    if(c < 60) // padding of the slot (its DMA copies whole 12 KiB images): 4096 - 256 bytes = 60 x 64 bytes
+    {
+      uint4 z = {0u, 0u, 0u, 0u};
+      uint4 * pad = reinterpret_cast<uint4 *>(base + HB_KS * HB_IMG + HB_CW_OFF + 256 + c * 64);
+      pad[0] = z; pad[1] = z; pad[2] = z; pad[3] = z;
+    }
+  }
+}
+
 // One block per (joint j, coordinate x, term t): t < 10 -> JS[j][x][t] = sum_v Jreg[j,v] S[v,x,t];
 // t == 10 -> J0[j][x] = sum_v Jreg[j,v] T[v,x].  Wavefront (64-lane) shuffle reduction, then across the 4 waves.
 __global__ __launch_bounds__(256) void fold_regressor_kernel(const float * __restrict__ Jreg, const float * __restrict__ S,
@@ -157,11 +224,11 @@ extern "C" int smplpp_model_destroy(smplpp_model * m)
 {
   if(!m) return SMPLPP_OK;
   (void)hipSetDevice(m->device);
-  void * ptrs[] = {m->Bm, m->B3, m->lvl, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm};
+  void * ptrs[] = {m->Bm, m->B3, m->B2h, m->lvl, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm};
   for(void * p : ptrs)
     if(p) (void)hipFree(p);
   Workspace & w = m->ws;
-  for(DevBuf * b : {&w.AT, &w.A3, &w.Gp, &w.joints, &w.poserot, &w.beta, &w.theta, &w.verts, &w.rest, &w.xf44, &w.q_ctr, &w.q_desc, &w.dummy}) b->release();
+  for(DevBuf * b : {&w.AT, &w.A3, &w.A2h, &w.G2h, &w.Gp, &w.joints, &w.poserot, &w.beta, &w.theta, &w.verts, &w.rest, &w.xf44, &w.dummy}) b->release();
   delete m;
   return SMPLPP_OK;
 }
@@ -211,29 +278,54 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   } while(0)
 
   // --- blend bases -> Bm, regressor fold (device side; the raw arrays are only needed transiently) ---
-  float *dP = nullptr, *dS = nullptr, *dT = nullptr, *dJreg = nullptr;
-  TRY_OR_FREE(upload(&dP, P, (size_t)V * 3 * NP));
-  TRY_OR_FREE(upload(&dS, S, (size_t)V * 3 * NB));
-  TRY_OR_FREE(upload(&dT, vt, (size_t)V * 3));
-  TRY_OR_FREE(upload(&dJreg, Jreg, (size_t)NJ * V));
-  TRY_OR_FREE(hipMalloc((void **)&m->Bm, sizeof(float) * (size_t)KP * m->ldB));
-  TRY_OR_FREE(hipMalloc((void **)&m->J0, sizeof(float) * NJ * 3));
-  TRY_OR_FREE(hipMalloc((void **)&m->JS, sizeof(float) * NJ * 3 * NB));
-  relayout_basis_kernel<<<dim3((unsigned)((m->ldB + 255) / 256)), dim3(256)>>>(dP, dS, dT, m->Bm, V, m->ldB);
-  fold_regressor_kernel<<<dim3(NJ * 3 * (NB + 1)), dim3(256)>>>(dJreg, dS, dT, m->J0, m->JS, V);
-  m->VGPn = (V + 63) / 64;
-  TRY_OR_FREE(hipMalloc((void **)&m->B3, (size_t)m->VGPn * BB_KS * BB_B_BYTES));
+  // Form of the fused kernel: read once, here (SMPLPP_SKIN = h | b | p | v; default h).  Only the operand layouts the
+  // chosen form needs stay resident.
   {
+    const char * form_env = getenv("SMPLPP_SKIN");
+    const char f = form_env ? form_env[0] : 'h';
+    m->form = (f == 'b' || f == 'p' || f == 'v') ? f : 'h';
+  }
+  // (the vertex-major uploads are owned by the handle from the start, so a failure below frees them with it)
+  TRY_OR_FREE(upload(&m->Pvm, P, (size_t)V * 3 * NP)); // kept: vertex-major copies serve the sparse IK Jacobian (contiguous 2.5 KB per vertex)
+  TRY_OR_FREE(upload(&m->Svm, S, (size_t)V * 3 * NB));
+  DevBuf dT, dJreg;
+  auto free_tmp = [&]() {
+    dT.release();
+    dJreg.release();
+  };
+#define TRY_TMP(expr)                                          \
+  do                                                           \
+  {                                                            \
+    hipError_t _e = (expr);                                    \
+    if(_e != hipSuccess)                                       \
+    {                                                          \
+      int _rc = hip_fail(_e, #expr, __FILE__, __LINE__);       \
+      free_tmp();                                              \
+      smplpp_model_destroy(m);                                 \
+      return _rc;                                              \
+    }                                                          \
+  } while(0)
+  TRY_TMP(dT.reserve(sizeof(float) * (size_t)V * 3));
+  TRY_TMP(dJreg.reserve(sizeof(float) * (size_t)NJ * V));
+  TRY_TMP(hipMemcpy(dT.p, vt, sizeof(float) * (size_t)V * 3, hipMemcpyHostToDevice));
+  TRY_TMP(hipMemcpy(dJreg.p, Jreg, sizeof(float) * (size_t)NJ * V, hipMemcpyHostToDevice));
+  TRY_TMP(hipMalloc((void **)&m->Bm, sizeof(float) * (size_t)KP * m->ldB));
+  TRY_TMP(hipMalloc((void **)&m->J0, sizeof(float) * NJ * 3));
+  TRY_TMP(hipMalloc((void **)&m->JS, sizeof(float) * NJ * 3 * NB));
+  relayout_basis_kernel<<<dim3((unsigned)((m->ldB + 255) / 256)), dim3(256)>>>(m->Pvm, m->Svm, dT.as<float>(), m->Bm, V, m->ldB);
+  fold_regressor_kernel<<<dim3(NJ * 3 * (NB + 1)), dim3(256)>>>(dJreg.as<float>(), m->Svm, dT.as<float>(), m->J0, m->JS, V);
+  m->VGPn = (V + 63) / 64;
+  if(m->form == 'b')
+  {
+    TRY_TMP(hipMalloc((void **)&m->B3, (size_t)m->VGPn * BB_KS * BB_B_BYTES));
     const int64_t cnt = m->VGPn * BB_KS * 6 * 64;
     relayout_basis_bf16x3_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256)>>>(m->Bm, m->ldB, V, m->VGPn,
                                                                                   reinterpret_cast<uint16_t *>(m->B3));
   }
-  TRY_OR_FREE(hipGetLastError());
-  TRY_OR_FREE(hipDeviceSynchronize());
-  m->Pvm = dP; // kept: vertex-major copies serve the sparse IK Jacobian (contiguous 2.5 KB per vertex)
-  m->Svm = dS;
-  (void)hipFree(dT);
-  (void)hipFree(dJreg);
+  TRY_TMP(hipGetLastError());
+  TRY_TMP(hipDeviceSynchronize());
+  free_tmp();
+#undef TRY_TMP
 
   // --- skinning weights: keep the non-zeros (real SMPL has <= 4 per vertex), dense fallback otherwise ---
   int maxnz = 0;
@@ -273,6 +365,35 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   TRY_OR_FREE(upload(&m->wVal, hVal.data(), hVal.size()));
   TRY_OR_FREE(upload(&m->wSum, hSum.data(), hSum.size()));
   TRY_OR_FREE(upload(&m->Wdense, W, (size_t)V * NJ));
+  if(m->form == 'h')
+  {
+    // fp16x2 operands: power-of-two scales that put the largest basis entry / a generous bound of the relative
+    // translations (16 x the template's extent) just under fp16's range, so that both pieces of every value that matters
+    // are normal fp16 numbers
+    float bmax = 0.0f, tmax = 0.0f;
+    for(int64_t i = 0; i < V * 3 * NP; i++) bmax = std::max(bmax, std::fabs(P[i]));
+    for(int64_t i = 0; i < V * 3 * NB; i++) bmax = std::max(bmax, std::fabs(S[i]));
+    for(int64_t i = 0; i < V * 3; i++) tmax = std::max(tmax, std::fabs(vt[i]));
+    bmax = std::max(bmax, tmax);
+    if(!(bmax > 0.0f) || !std::isfinite(bmax))
+    {
+      smplpp_model_destroy(m);
+      return fail(SMPLPP_ERR_INVALID, "Cannot initialize a SMPL model!");
+    }
+    m->sB = std::exp2(std::floor(std::log2(32768.0f / bmax)));
+    m->sG = std::exp2(std::floor(std::log2(32768.0f / (16.0f * tmax > 1.0f ? 16.0f * tmax : 1.0f))));
+    TRY_OR_FREE(hipMalloc((void **)&m->B2h, (size_t)m->VGPn * HB_SLOTS * HB_IMG));
+    const int64_t cnt = m->VGPn * (HB_KS * 6 * 64 + 4 * 64 + 64);
+    relayout_basis_f16x2_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256)>>>(m->Bm, m->ldB, m->Wdense, m->wSum, V, m->VGPn,
+                                                                                 m->sB, m->sG, m->B2h);
+    TRY_OR_FREE(hipGetLastError());
+    TRY_OR_FREE(hipDeviceSynchronize());
+  }
+  if(m->form == 'h' || m->form == 'b')
+  {
+    (void)hipFree(m->Bm); // only the fp32-MFMA forms read the K-major fp32 basis
+    m->Bm = nullptr;
+  }
   TRY_OR_FREE(upload(&m->parent, parent.data(), parent.size()));
   {
     // joints by depth: the FK chain advances one tree level per step (SMPL: 9 levels)

@@ -575,12 +575,7 @@ static hipError_t launch_b(const smplpp_model * m, int64_t n, const float * thet
   const int nftp = (int)((n + 63) / 64);
   const int nvgp = (int)m->VGPn;
   const int total = nvgp * nftp;
-  static int cus = 0;
-  if(!cus)
-  {
-    hipDeviceProp_t prop;
-    cus = (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
+  const int cus = device_cus(m->device);
   // per XCD: ceil(nvgp / 8) * nftp items at most; no more workgroups per XCD than that, and no more than the CUs it has
   const int per_xcd_items = ((nvgp + 7) / 8) * nftp;
   int nbx = cus / 8;
@@ -589,13 +584,10 @@ static hipError_t launch_b(const smplpp_model * m, int64_t n, const float * thet
   const int blocks = nbx * 8;
   const int ipb = 0;
   (void)total;
-  static bool attr_set = false;
-  if(!attr_set)
+  static PerDeviceOnce once;
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&skin_kernel_b<MAXW, WANT_REST>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL);
+    hipError_t e = lds_opt_in(once, m->device, reinterpret_cast<const void *>(&skin_kernel_b<MAXW, WANT_REST>), B_LDS_TOTAL);
     if(e != hipSuccess) return e;
-    attr_set = true;
   }
   // f_off (a multiple of 64): first frame of this launch inside the workspace / caller arrays of a longer batch
   skin_kernel_b<MAXW, WANT_REST><<<dim3(blocks), dim3(256), B_LDS_TOTAL, st>>>(

@@ -360,33 +360,20 @@ static hipError_t launch_p(const smplpp_model * m, int64_t n, const float * thet
 {
   const int nft = (int)((n + 31) / 32);
   const int total = (int)m->VGn * nft;
-  int cus = 256;
-  {
-    static int cached = 0;
-    if(!cached)
-    {
-      hipDeviceProp_t prop;
-      if(hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) cached = prop.multiProcessorCount;
-      else cached = 256;
-    }
-    cus = cached;
-  }
+  const int cus = device_cus(m->device);
   int blocks = (total + 3) / 4;
   if(blocks > cus) blocks = cus;
   blocks = (blocks + 7) & ~7; // the XCD-aware run assignment wants a multiple of 8 (idle runs exit at once)
   const int ipb = (total + blocks - 1) / blocks;
   const size_t shmem = sizeof(float) * 4 * P_LDS_WAVE;
-  static bool attr_set = false;
-  if(!attr_set)
+  static PerDeviceOnce once;
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&skin_kernel_p<MAXW, WANT_REST>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipError_t e = lds_opt_in(once, m->device, reinterpret_cast<const void *>(&skin_kernel_p<MAXW, WANT_REST>), (int)shmem);
     if(e != hipSuccess) return e;
-    attr_set = true;
   }
   skin_kernel_p<MAXW, WANT_REST><<<dim3(blocks), dim3(256), shmem, st>>>(m->ws.AT.as<float>(), m->ws.ldA, m->Bm, m->ldB, Gp_padded, theta,
                                                                         m->wIdx, m->wVal, m->wSum, verts, rest, m->ws.dummy.as<float>(), n, m->V,
-                                                                        (int)m->VGn, nft, ipb, getenv("SMPLPP_SKIN_DBG") ? atoi(getenv("SMPLPP_SKIN_DBG")) : 0);
+                                                                        (int)m->VGn, nft, ipb, 0);
   return hipGetLastError();
 }
 

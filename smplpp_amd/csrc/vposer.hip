@@ -452,12 +452,8 @@ int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t
                           float * jac, hipStream_t st)
 {
   const size_t shmem = sizeof(float) * (size_t)(2 * HID * VS + LAT + HID);
-  static bool attr = false;
-  if(!attr)
-  {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&vposer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr = true;
-  }
+  static PerDeviceOnce once;
+  HIP_TRY(lds_opt_in(once, v->device, reinterpret_cast<const void *>(&vposer_kernel), (int)shmem));
   vposer_kernel<<<dim3((unsigned)n), dim3(256), shmem, st>>>(z, z_stride, v->w0t, v->b0, v->w1t, v->b1, v->w2t, v->b2, out, out_stride,
                                                             jac, jac ? 1 : 0);
   HIP_TRY(hipGetLastError());

@@ -107,10 +107,11 @@ def test_fk_dense_weights_and_ragged_vertex_count():
         assert np.abs(o[k] - g[k]).max() < VERT_TOL, k
 
 
-@pytest.mark.parametrize("form", ["b", "p"])
+@pytest.mark.parametrize("form", ["h", "b", "p"])
 def test_fk_eight_weights_per_vertex(synth_model, form, monkeypatch):
-    """Models with 5..8 skinning weights per vertex take the MAXW = 8 instantiations of the fused kernels (real SMPL has
-    at most 4); ragged frame counts exercise partial frame tiles and the single-item / multi-item paths."""
+    """Models with 5..8 skinning weights per vertex: the default form (h) skins on the matrix pipe with dense weights,
+    the b / p forms take their MAXW = 8 instantiations (real SMPL has at most 4); ragged frame counts exercise partial
+    frame tiles and the single-item / multi-item paths.  (The form is read from SMPLPP_SKIN when a model is created.)"""
     from smplpp_amd.smpl import SMPL
     from oracle.cpu import OracleModel
 
@@ -216,24 +217,69 @@ def test_fk_writes_only_its_frames(smpl, n):
         assert bool((big[k][:n] != 777.0).all()), k
 
 
-def test_fk_bf16x3_form_is_fp32_exact(smpl, oracle_synth, monkeypatch):
-    """The default fused kernel carries every fp32 operand as three bf16 pieces on the bf16 matrix pipe (skin_b.hip).
-    Its error against the fp64-accumulating oracle must be of the same size as that of the fp32-MFMA form (skin_p.hip),
-    far inside the 1e-5 m parity bar, on shaped vertices and skinned vertices alike."""
+def test_fk_split_operand_forms_are_fp32_exact(synth_model, oracle_synth, monkeypatch):
+    """The default fused kernel (h, skin_h.hip) carries every fp32 operand as two fp16 pieces on the f16 matrix pipe and
+    skins on the matrix pipe; b (skin_b.hip) uses three bf16 pieces. Their error against the fp64-accumulating oracle must
+    be of the same size as that of the exact fp32-MFMA form (p, skin_p.hip), far inside the 1e-5 m parity bar, on shaped
+    vertices and skinned vertices alike."""
     from smplpp_amd import model_io
+    from smplpp_amd.smpl import SMPL
 
     beta, theta = model_io.synthetic_inputs(200, seed=11)
     beta = (beta * 3.0).astype(np.float32)  # large shape coefficients: stresses the low pieces
     r = oracle_synth.fk(beta, theta)
     err = {}
-    for form in ("b", "p"):
+    for form in ("h", "b", "p"):
         monkeypatch.setenv("SMPLPP_SKIN", form)
-        o = smpl.launch(beta, theta)
+        s = SMPL()
+        s.setDevice("cuda:0")
+        s.init(synth_model)
+        o = s.launch(beta, theta)
         err[form] = {k: float(np.abs(o[k] - r[k]).max()) for k in ("verts", "rest")}
     monkeypatch.delenv("SMPLPP_SKIN")
-    for k in ("verts", "rest"):
-        assert err["b"][k] < 2e-6, err
-        assert err["b"][k] <= 3.0 * err["p"][k] + 2e-7, err
+    for form in ("h", "b"):
+        for k in ("verts", "rest"):
+            assert err[form][k] < 2e-6, err
+            assert err[form][k] <= 3.0 * err["p"][k] + 2e-7, err
+
+
+def test_fk_fp16x2_at_real_smpl_magnitudes(synth_model):
+    """Error budget of the fp16x2 operands where it is tightest: posedirs up to 5e-2 (25x the synthetic model's, the
+    size of real SMPL's largest entries), |beta| = 3, rotations up to ~1.5 rad, root translations of several metres.
+    Reference: float64 numpy restatement of rest = T + S.beta + P.c and of the skinning, from the fp32 joints / relative
+    transforms the engine itself returns (those stages are covered by the golden tests)."""
+    from smplpp_amd import model_io
+    from smplpp_amd.smpl import SMPL
+
+    md = {k: v.copy() for k, v in synth_model.items()}
+    rng = np.random.default_rng(77)
+    md["pose_blend_shapes"] = np.clip(rng.normal(0, 5e-2 / 3, md["pose_blend_shapes"].shape), -5e-2, 5e-2).astype(np.float32)
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(md)
+    n = 96
+    beta = rng.choice([-3.0, 3.0], size=(n, 10)).astype(np.float32)
+    theta = np.zeros((n, 25, 3), np.float32)
+    theta[:, 1:] = rng.normal(0, 0.9, (n, 24, 3))
+    theta[:, 0] = rng.uniform(-5, 5, (n, 3))
+    o = s.launch(beta, theta)
+    from scipy.spatial.transform import Rotation
+
+    th = theta[:, 1:].astype(np.float64) + 1e-8  # src/BlendShape.cpp:813-815 (angle from theta + eps, axis from theta)
+    ang = np.linalg.norm(th, axis=-1, keepdims=True)
+    axis = theta[:, 1:].astype(np.float64) / ang
+    R = Rotation.from_rotvec((axis * ang).reshape(-1, 3)).as_matrix().reshape(n, 24, 3, 3)
+    c = (R[:, 1:] - np.eye(3)).reshape(n, 207)
+    rest = (md["vertices_template"].astype(np.float64)[None] + np.einsum("vxk,nk->nvx", md["shape_blend_shapes"].astype(np.float64), beta.astype(np.float64))
+            + np.einsum("vxk,nk->nvx", md["pose_blend_shapes"].astype(np.float64), c))
+    # c above comes from fp64 Rodrigues; the engine's rotations are fp32: compare `rest` at the fp32 level of c
+    assert np.abs(o["rest"] - rest).max() < 5e-6
+    G = o["xforms"].astype(np.float64)  # [n, 24, 4, 4] relative transforms
+    W = md["weights"].astype(np.float64)
+    M = np.einsum("vj,njab->nvab", W, G)
+    h = np.einsum("nvab,nvb->nva", M[:, :, :3, :3], o["rest"].astype(np.float64)) + M[:, :, :3, 3]
+    verts = h / W.sum(axis=1)[None, :, None] + theta[:, :1].astype(np.float64)
+    assert np.abs(o["verts"] - verts).max() < 3e-6, float(np.abs(o["verts"] - verts).max())
 
 
 def test_stage_kats_on_gpu(kats):
