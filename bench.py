@@ -13,9 +13,13 @@ barrier + synchronize on both sides, max over ranks.  Rank 0 prints ONE JSON lin
 Also reported in the same line:
   roofline      dominant kernel (skin_kernel): algorithmic FLOPs / bytes per launch divided by
                 the kernel's mean duration measured with HIP events on its launch stream over the timed region;
-  ik            IK iterations/s on BASELINE.json configs[2] (6 targets, 50 iterations, 256 frames per GPU);
+  ik            IK iterations/s on BASELINE.json configs[2] (6 targets, 50 iterations, 256 frames per GPU), with its own
+                cpu_baseline (the reference's per-row autograd Jacobian + fp64 solve on the host cores);
+  mocap         configs[3]: sample_walk.c3d, every frame, 64 restarts in all sharded over the GPUs, both layouts;
+  vposer_ik     configs[4]: VPoser-latent IK, 512 frames in all sharded over the GPUs;
   cpu_baseline  the reference's own compiled FK stages (oracle/_ref, libtorch-CPU) — or the C port when that
-                library is absent — timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+                library is absent — timed on this box's host cores on a bounded sample (rank 0, N = 1 only);
+  final_gather_ms  (N > 1) the one RCCL all-gather of the results, the path's only exchange.
 """
 from __future__ import annotations
 
@@ -39,9 +43,17 @@ ALG_MFMA_FLOPS_PER_FRAME = 2 * 20670 * 217
 ALG_FLOPS_PER_FRAME = 15.5e6  # whole FK
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
-PEAK_MFMA_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
-# The default fused kernel (skin_b.hip) evaluates every fp32 product as 6 bf16 piece products, K padded 220 -> 224
-BF16X3_ISSUE_FACTOR = 6.0 * 224.0 / 217.0
+PEAK_MFMA_16BIT_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 MFMA (no sparsity)
+MFMA_32X32X16_FLOPS = 2 * 32 * 32 * 16
+
+
+def issued_mfma_flops(form, n):
+    """FLOPs of the matrix instructions the fused kernel actually ISSUES per launch.
+    h (skin_h.hip): per 64 x 64 item and wavefront 126 GEMM MFMAs (14 k-steps x 3 coordinates x 3 piece products) + 72
+    skinning MFMAs (12 entries x 2 k-steps x 3 products); b (skin_b.hip): 252 (14 x 3 x 6)."""
+    items = ((n + 63) // 64) * ((V + 63) // 64)
+    per_wave = {"h": 126 + 72, "b": 252}[form]
+    return items * 4 * per_wave * MFMA_32X32X16_FLOPS
 
 
 def usable_cpus():
@@ -102,6 +114,36 @@ def cpu_baseline(model, frames, budget_s=12.0):
     }
 
 
+def ik_cpu_baseline(model, faces, tp, tn, theta0, budget_s=12.0):
+    """configs[2] on the host: one IK iteration per frame as the reference computes it — residual and Jacobian by libtorch
+    autograd, one backward() per Jacobian row, through the reference's own compiled FK stages (oracle/_ref,
+    node/node.cpp:823-869), then the fp64 normal equations and LLT (node/node.cpp:883-943, restated in oracle/cpu.py).
+    Bounded sample: whole frame-iterations until the budget is spent (at least one)."""
+    from oracle import cpu, ref
+
+    if not ref.available():
+        return None
+    R = ref.RefModel(model)
+    ref.lib().ref_set_num_threads(usable_cpus())
+    cores = ref.lib().ref_get_num_threads()
+    K = len(faces)
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        f = done % len(theta0)
+        r = R.ik_eval(np.zeros(10, np.float32), theta0[f], faces, tp[f], tn[f], np.ones(K), np.ones(K), np.zeros(K), np.zeros(K),
+                      np.full((K, 3), 1 / 3, np.float32))
+        A, b = cpu.normal_equations(r["e"], r["J"], 75, 2 * K, 0)
+        cpu.llt_solve(A, b)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 16:
+            break
+    return {"value": done / el, "unit": "IK iterations/s", "cores": int(cores), "kind": "reference",
+            "sample": "%d frame-iterations (%.1f s) of configs[2]: 24 autograd backward() calls per frame through the reference's "
+                      "compiled FK stages + fp64 normal equations and LLT" % (done, el)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,9 +155,10 @@ def main():
     ap.add_argument("--no-ik", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[3] (mocap excerpt) and configs[4] (VPoser-latent IK) legs")
-    ap.add_argument("--mocap-restarts", type=int, default=8, help="restarts per GPU of the capture excerpt (BASELINE: 64 over 8 GPUs)")
-    ap.add_argument("--vposer-frames", type=int, default=128, help="frames per GPU of the VPoser-latent IK leg (BASELINE: 512 over 4 GPUs)")
-    ap.add_argument("--gather", action="store_true", help="also time one final RCCL gather of all vertices to rank 0")
+    ap.add_argument("--mocap-restarts", type=int, default=64, help="restarts of the capture fit IN ALL (BASELINE configs[3]: 64, sharded over the GPUs)")
+    ap.add_argument("--mocap-frames", type=int, default=0, help="frames of the capture sequence to fit (0 = all 3163)")
+    ap.add_argument("--vposer-frames", type=int, default=512, help="frames of the VPoser-latent IK leg IN ALL (BASELINE configs[4]: 512, sharded over the GPUs)")
+    ap.add_argument("--profile-steps", type=int, default=40, help="launches of the separate loop that times the fused kernel with HIP events")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses GPU 0 (use with --backend gloo)")
@@ -155,18 +198,21 @@ def main():
         step()
     torch.cuda.synchronize()
     D.barrier()
-    smpl.profileEnable(True)
-    smpl.profileRead()
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed)
+    # the fused kernel's own duration: a separate short loop with HIP events on the launch stream (not inside the timed region)
+    smpl.profileEnable(True)
+    smpl.profileRead()
+    for _ in range(max(1, args.profile_steps)):
+        step()
+    torch.cuda.synchronize()
     launches, skin_ms = smpl.profileRead()
     smpl.profileEnable(False)
-    elapsed = D.max_over_ranks(elapsed)
     skin_ms = D.max_over_ranks(skin_ms)
 
     # ---- IK leg (BASELINE.json configs[2]): 6 targets, 50 iterations, 256 frames per GPU
@@ -210,89 +256,112 @@ def main():
             "workload": "configs[2]: 6-target IK (position + normal term per target), 50 iterations, direct theta (D = 87)",
         }
 
-    # ---- configs[3]: the capture excerpt (tests/golden/sample_walk_excerpt.npz: 32 frames x 41 Baseline markers of
-    # data/sample_walk.c3d), R warm-started chains per GPU, marker-thickness normal offsets, QP on, 31 warm-up iterations
-    # on frame 0 then one iteration per frame (node.cpp:1369-1407); configs[4]: VPoser-latent IK (44-d layout, synthetic
-    # decoder: the real weights cannot travel), 6 targets, 50 iterations
+    # ---- configs[3]: sample_walk.c3d, every frame (tests/golden/sample_walk_full.npz: 3163 frames x 41 Baseline markers),
+    # 64 restarts IN ALL sharded over the GPUs (dist.shard_sizes), each a serial warm-started chain: 32 iterations on frame 0
+    # then one per frame (node.cpp:1369-1407), marker-thickness normal offsets, QP on; in both layouts (direct theta, and
+    # the 44-d VPoser layout the reference forces on capture solves).  configs[4]: VPoser-latent IK, 512 frames IN ALL
+    # sharded over the GPUs, 6 targets, 50 iterations (synthetic decoder: the real weights cannot travel).
     mocap_leg = vposer_leg = None
     if not args.no_ik and not args.no_extra:
         from smplpp_amd import mocap
         from smplpp_amd.ik import VPoserDecoder
 
-        g = np.load(os.path.join(ROOT, "tests", "golden", "sample_walk_excerpt.npz"))
+        g = np.load(os.path.join(ROOT, "tests", "golden", "sample_walk_full.npz"))
         names = list(g["task_names"])
         mfaces = np.array([mocap.BASELINE41[nm] for nm in names], np.int64)
         Km = len(names)
-        pts = g["points"] - g["points"][0][g["valid"][0]].mean(axis=0) + np.array([0, -0.3, 0], np.float32)
-        R = args.mocap_restarts
+        T = int(args.mocap_frames) if args.mocap_frames > 0 else g["points"].shape[0]
+        pts = (g["points"][:T] - g["points"][0][g["valid"][0]].mean(axis=0) + np.array([0, -0.3, 0], np.float32)).astype(np.float32)
+        mvalid = g["valid"][:T]
+        R = D.shard_sizes(args.mocap_restarts, world)[rank]
         rng = np.random.default_rng(200 + rank)
-        th0 = np.zeros((R, 25, 3), np.float32)
-        th0[:, 1:] = rng.normal(0, 0.03, (R, 24, 3))  # the restarts differ in their initial pose
-        ms = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R)
-        ms.solve(pts, g["valid"], np.zeros(10, np.float32), th0, max_frames=2)  # warm-up of the code path
+        if R > 0:
+            th0 = np.zeros((R, 25, 3), np.float32)
+            th0[:, 1:] = rng.normal(0, 0.03, (R, 24, 3))  # the restarts differ in their initial pose
+            ms = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R)
+            ms.solve(pts, mvalid, np.zeros(10, np.float32), th0, max_frames=2)  # warm-up of the code path
         torch.cuda.synchronize()
         D.barrier()
         t1 = time.perf_counter()
-        thm, fr = ms.solve(pts, g["valid"], np.zeros(10, np.float32), th0)
+        if R > 0:
+            thm, fr = ms.solve(pts, mvalid, np.zeros(10, np.float32), th0)
         torch.cuda.synchronize()
         D.barrier()
         mt = D.max_over_ranks(time.perf_counter() - t1)
-        iters = mocap.MocapMotionSolver.WARMUP_ITERS + len(fr) - 1
+        nfr = T
+        iters = mocap.MocapMotionSolver.WARMUP_ITERS + nfr - 1
+        skipped = int((mvalid.sum(axis=1) < Km // 2).sum())
         mocap_leg = {
-            "value": world * R * len(fr) / mt, "unit": "solved capture frames/s", "ik_iterations_per_s": world * R * iters / mt,
-            "restarts_per_gpu": R, "frames": len(fr), "markers": Km, "finite": bool(np.isfinite(thm).all()),
-            "workload": "configs[3]: sample_walk.c3d excerpt (32 frames x 41 markers), warm-started chains, box QP, direct theta (D = 157); "
-                        "frame loop on the device (smplpp_ik_solve_sequence: targets uploaded once, no host round trip per frame)",
+            "value": args.mocap_restarts * nfr / mt, "unit": "solved capture frames/s", "ik_iterations_per_s": args.mocap_restarts * iters / mt,
+            "restarts_total": args.mocap_restarts, "restarts_this_rank": R, "frames": nfr, "markers": Km, "seconds": mt,
+            "frames_with_missing_markers": int((~mvalid).any(axis=1).sum()), "frames_skipped_below_20_valid": skipped,
+            "finite": bool(np.isfinite(thm).all()) if R > 0 else True,
+            "workload": "configs[3]: sample_walk.c3d, all %d frames x 41 markers, %d restarts sharded x%d, warm-started chains, box QP, "
+                        "direct theta (D = 157); frame loop on the device (smplpp_ik_solve_sequence)" % (nfr, args.mocap_restarts, world),
         }
 
-        Kv = 6
-        nv = args.vposer_frames
         vp = VPoserDecoder(VPoserDecoder.synthetic_params(seed=3), device=local)
-        _, vfaces = reference_task_faces(Kv)
-        hidv = np.zeros((nv, 25, 3), np.float32)
-        hidv[:, 1:22] = rng.normal(0, 0.15, (nv, 21, 3))
-        hvv = smpl.launch(np.zeros((nv, 10), np.float32), hidv, want=("verts",))["verts"]
-        tpv = hvv[:, model["face_indices"][vfaces] - 1].mean(axis=2)
         # the reference's own capture setting (node.cpp:316-322 forces VPoser + QP on): 44-d layout, D = 44 + 2 * 41
-        msv = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R, vposer=vp)
-        gv0 = np.zeros((R, 44), np.float32)
-        gv0[:, 6:38] = rng.normal(0, 0.05, (R, 32))
-        msv.solve(pts, g["valid"], np.zeros(10, np.float32), gv0, max_frames=2)
+        if R > 0:
+            msv = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R, vposer=vp)
+            gv0 = np.zeros((R, 44), np.float32)
+            gv0[:, 6:38] = rng.normal(0, 0.05, (R, 32))
+            msv.solve(pts, mvalid, np.zeros(10, np.float32), gv0, max_frames=2)
         torch.cuda.synchronize()
         D.barrier()
         t1 = time.perf_counter()
-        thv, frv = msv.solve(pts, g["valid"], np.zeros(10, np.float32), gv0)
+        if R > 0:
+            thv, frv = msv.solve(pts, mvalid, np.zeros(10, np.float32), gv0)
         torch.cuda.synchronize()
         D.barrier()
         mtv = D.max_over_ranks(time.perf_counter() - t1)
         mocap_leg["vposer_latent"] = {
-            "value": world * R * len(frv) / mtv, "unit": "solved capture frames/s", "finite": bool(np.isfinite(thv).all()),
-            "workload": "same excerpt with the 44-d VPoser layout the reference forces on capture solves (D = 126), synthetic decoder weights",
+            "value": args.mocap_restarts * nfr / mtv, "unit": "solved capture frames/s", "seconds": mtv,
+            "finite": bool(np.isfinite(thv).all()) if R > 0 else True,
+            "workload": "same sequence with the 44-d VPoser layout the reference forces on capture solves (D = 126), synthetic decoder weights",
         }
-        vs = IkSolver(smpl, nv, Kv, vposer=vp)
-        vs.setTasks(face_idx=vfaces, target_pos=tpv, phi_limit=np.zeros(Kv), normal_task_weight=np.zeros(Kv))
-        g0 = np.zeros((nv, vs.theta_dim), np.float32)
-        vt = 0.0
+
+        Kv = 6
+        nv = D.shard_sizes(args.vposer_frames, world)[rank]
+        _, vfaces = reference_task_faces(Kv)
+        vt, ev = 0.0, np.zeros(1)
+        if nv > 0:
+            hidv = np.zeros((nv, 25, 3), np.float32)
+            hidv[:, 1:22] = rng.normal(0, 0.15, (nv, 21, 3))
+            hvv = smpl.launch(np.zeros((nv, 10), np.float32), hidv, want=("verts",))["verts"]
+            tpv = hvv[:, model["face_indices"][vfaces] - 1].mean(axis=2)
+            vs = IkSolver(smpl, nv, Kv, vposer=vp)
+            vs.setTasks(face_idx=vfaces, target_pos=tpv, phi_limit=np.zeros(Kv), normal_task_weight=np.zeros(Kv))
+            g0 = np.zeros((nv, vs.theta_dim), np.float32)
         for rep in range(3):
-            vs.setTasks(face_idx=vfaces, vertex_weights=np.full((Kv, 3), 1 / 3, np.float32))
-            vs.setConfig(np.zeros((nv, 10), np.float32), g0)
+            if nv > 0:
+                vs.setTasks(face_idx=vfaces, vertex_weights=np.full((Kv, 3), 1 / 3, np.float32))
+                vs.setConfig(np.zeros((nv, 10), np.float32), g0)
             torch.cuda.synchronize()
             D.barrier()
             t1 = time.perf_counter()
-            ev = vs.iterate(args.ik_iters)
+            if nv > 0:
+                ev = vs.iterate(args.ik_iters)
             torch.cuda.synchronize()
             D.barrier()
             if rep > 0:
                 vt += time.perf_counter() - t1
         vt = D.max_over_ranks(vt / 2)
         vposer_leg = {
-            "value": world * nv * args.ik_iters / vt, "unit": "IK iterations/s", "frames_per_gpu": nv, "iters": args.ik_iters, "tasks": Kv,
+            "value": args.vposer_frames * args.ik_iters / vt, "unit": "IK iterations/s", "frames_total": args.vposer_frames,
+            "frames_this_rank": nv, "iters": args.ik_iters, "tasks": Kv,
             "ms_per_iter_batch": vt / args.ik_iters * 1e3, "final_max_e_sqnorm": float(np.max(ev)),
-            "workload": "configs[4]: VPoser-latent IK (32-d latent + decoder in the loop, 44-d layout, D = 56), synthetic decoder weights",
+            "workload": "configs[4]: VPoser-latent IK (32-d latent + decoder in the loop, 44-d layout, D = 56), %d frames sharded x%d, "
+                        "synthetic decoder weights" % (args.vposer_frames, world),
         }
 
+    # the only exchange of the path: the final gather of the results (one RCCL all-gather over xGMI), always timed when N > 1
     gather_ms = None
-    if args.gather and world > 1:
+    ranks_reported = 1
+    if world > 1:
+        import torch.distributed as tdist
+
+        ranks_reported = int(tdist.get_world_size())
         torch.cuda.synchronize()
         D.barrier()
         t1 = time.perf_counter()
@@ -305,48 +374,56 @@ def main():
         return
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n * args.steps / elapsed
-    mfma_tflops = ALG_MFMA_FLOPS_PER_FRAME * n / (skin_ms * 1e-3) / 1e12 if skin_ms > 0 else 0.0
-    hbm_gbs = (ALG_BYTES_CONST + ALG_BYTES_PER_FRAME * n) / (skin_ms * 1e-3) / 1e9 if skin_ms > 0 else 0.0
+    form = (os.environ.get("SMPLPP_SKIN") or "h")[0]
+    if form not in ("h", "b", "p", "v"):
+        form = "h"
+    t_k = skin_ms * 1e-3
+    alg_bytes = ALG_BYTES_CONST + ALG_BYTES_PER_FRAME * n
+    f32_equiv_tflops = ALG_MFMA_FLOPS_PER_FRAME * n / t_k / 1e12 if t_k > 0 else 0.0
+    hbm_gbs = alg_bytes / t_k / 1e9 if t_k > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
+    if os.path.exists(tpath):  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_fk.sh, profiles/README.md)
         try:
-            traffic = json.load(open(tpath)).get("skin_kernel_hbm_bytes_per_launch_n%d" % n)
+            traffic = json.load(open(tpath)).get("skin_kernel_%s_hbm_bytes_per_launch_n%d" % (form, n))
         except Exception:
             traffic = None
-    form = (os.environ.get("SMPLPP_SKIN") or "b")[0]
-    if form == "b":
-        issued = mfma_tflops * BF16X3_ISSUE_FACTOR
-        roofline = {
-            "kernel": "skin_kernel_b<4,false> (fused blend-shape GEMM + linear blend skinning; fp32 operands as exact bf16x3 "
-                      "pieces on the bf16 matrix pipe, fp32 accumulate)",
-            "bound": "mfma", "achieved": mfma_tflops, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": mfma_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": traffic,
-            "kernel_ms": skin_ms, "launches_timed": launches,
-            "issued": {"dtype": "bf16", "achieved": issued, "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
-                       "frac": issued / PEAK_MFMA_BF16_TFLOPS,
-                       "note": "6 bf16 MFMA products per fp32 product (a1b1 a1b2 a2b1 a1b3 a2b2 a3b1), K 220 padded to 224"},
-            "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
-                    "algorithmic_bytes_per_launch": ALG_BYTES_CONST + ALG_BYTES_PER_FRAME * n},
-            "note": "achieved = ALGORITHMIC fp32 FLOPs of the blend-shape contraction (2*20670*217 per frame) / kernel time, "
-                    "priced against the fp32 matrix peak (the arithmetic type of the path: results carry fp32 accuracy — max error vs "
-                    "the fp64 oracle 7e-7 m, same as the fp32-MFMA form); 'issued' prices the bf16 instructions actually "
-                    "executed against the dense bf16 peak. Dense bf16 MFMA holds ~1.6 GHz on this chip (tools/micro/mfma_lds.hip), "
-                    "so the issued-rate ceiling is ~2/3 of the datasheet figure. Batch 1024 has 152 FLOP/B: the matrix pipe, "
-                    "LDS and issue slots bind long before HBM",
-        }
+    kernel_names = {
+        "h": "skin_kernel_h<false> (fused blend-shape GEMM + linear blend skinning; fp32 operands as fp16x2 pieces, 3 MFMA products "
+             "per fp32 product; skinning as MFMA products too; fp32 accumulate)",
+        "b": "skin_kernel_b<4,false> (bf16x3 operand pieces, 6 MFMA products per fp32 product; VALU skinning in MFMA shadows)",
+        "p": "skin_kernel_p<4,false> (exact fp32 MFMA, persistent)", "v": "skin_kernel<2,4> (exact fp32 MFMA, first form)",
+    }
+    hbm = {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg_bytes}
+    if form in ("h", "b"):
+        issued = issued_mfma_flops(form, n)
+        issued_tflops = issued / t_k / 1e12 if t_k > 0 else 0.0
+        t_mfma, t_hbm = issued / (PEAK_MFMA_16BIT_TFLOPS * 1e12), alg_bytes / (PEAK_HBM_GBS * 1e9)
+        # the roof the kernel sits under: the slower of (issued matrix FLOPs at the dense 16-bit MFMA peak, algorithmic bytes at
+        # the HBM peak); frac = that time / measured time
+        if t_mfma >= t_hbm:
+            roofline = {"kernel": kernel_names[form], "bound": "mfma", "achieved": issued_tflops, "peak": PEAK_MFMA_16BIT_TFLOPS,
+                        "unit": "TFLOP/s", "frac": issued_tflops / PEAK_MFMA_16BIT_TFLOPS}
+        else:
+            roofline = {"kernel": kernel_names[form], "bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": hbm_gbs / PEAK_HBM_GBS}
+        roofline.update({
+            "traffic": traffic, "kernel_ms": skin_ms, "launches_timed": launches,
+            "issued_mfma_flops_per_launch": issued, "roof_us": {"mfma": t_mfma * 1e6, "hbm": t_hbm * 1e6},
+            "hbm": hbm,
+            "fp32_equivalent": {"achieved": f32_equiv_tflops, "unit": "TFLOP/s",
+                                "note": "algorithmic fp32 FLOPs of the blend-shape contraction (2*20670*217 per frame) / kernel time — a "
+                                        "side note, not a roof (the fp32 MFMA peak is 157.3 TF; this kernel does not run on that pipe)"},
+            "note": "achieved = matrix FLOPs the kernel ISSUES (v_mfma_f32_32x32x16_f16/bf16 count x 32768, DESIGN.md §3.2) / kernel time, "
+                    "against the dense 16-bit MFMA peak (2.5 PF, no sparsity); 152 FLOP/B at batch 1024 puts the HBM roof (13 us) under "
+                    "the matrix roof. The chip holds ~1.7-1.8 GHz of its 2.4 GHz under this kernel (power-limited; in-kernel stamps, "
+                    "DESIGN.md §3.2), so the practical ceiling of an MFMA-only stream is ~0.72 of the datasheet figure",
+        })
     else:
         roofline = {
-            "kernel": "skin_kernel_p<4,false> (fused blend-shape GEMM + linear blend skinning, fp32 MFMA, persistent)"
-                      if form == "p" else "fp32-MFMA fused kernel, form %s" % form,
-            "bound": "mfma", "achieved": mfma_tflops, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": mfma_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": traffic,
-            "kernel_ms": skin_ms, "launches_timed": launches,
-            "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
-                    "algorithmic_bytes_per_launch": ALG_BYTES_CONST + ALG_BYTES_PER_FRAME * n},
-            "note": "batch 1024 in exact fp32 has 152 FLOP/B: the fp32 MFMA pipe binds before HBM (ridge ~20 FLOP/B); "
-                    "peak is the 157.3 TF datasheet figure at 2.4 GHz — under sustained fp32 MFMA the chip holds ~1.7 GHz "
-                    "(profiles/README.md), i.e. a practical ceiling near 110 TF",
+            "kernel": kernel_names[form], "bound": "mfma", "achieved": f32_equiv_tflops, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+            "frac": f32_equiv_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": traffic, "kernel_ms": skin_ms, "launches_timed": launches, "hbm": hbm,
+            "note": "exact fp32 on v_mfma_f32_32x32x2_f32 (1/16 of the 16-bit MFMA rate): the fp32 matrix pipe binds",
         }
     line = {
         "metric": "SMPL FK evals/s + IK iters/s, batch 1024 frames, 1/2/4/8 MI355X",
@@ -359,7 +436,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if form != "b" else "f32 (exact bf16x3 operand pieces, fp32 accumulate)",
+        "dtype": {"h": "f32 (fp16x2 operand pieces on the f16 matrix pipe, fp32 accumulate: 22-bit operands, error 3e-7 m)",
+                  "b": "f32 (exact bf16x3 operand pieces, fp32 accumulate)"}.get(form, "f32"),
         "data": "synthetic",
         "config": {
             "workload": "configs[1]: batch-%d random beta/theta FK+LBS per GPU, synthetic SMPL-shaped model "
@@ -376,8 +454,17 @@ def main():
         line["vposer_ik"] = vposer_leg
     if gather_ms is not None:
         line["final_gather_ms"] = gather_ms
+        line["ranks_reported_by_rccl"] = ranks_reported
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(model, n)
+        if ik is not None:
+            try:
+                ikb = ik_cpu_baseline(model, faces, tp, tn, theta0)
+            except Exception as e:  # the reference build is test infrastructure: its absence must not break the bench line
+                sys.stderr.write("ik cpu_baseline unavailable: %s\n" % e)
+                ikb = None
+            if ikb is not None:
+                ik["cpu_baseline"] = ikb
     print(json.dumps(line))
 
 

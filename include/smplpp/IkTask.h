@@ -103,7 +103,7 @@ public:
   // the frame loop of solveMocapMotion (node.cpp:1369-1407, targets per frame :681-700) without a host round trip per
   // frame: targetPos [T,n,K,3], valid [T,n,K]; returns g_theta after every frame [T,n,thetaDim]
   std::vector<float> solveSequence(int64_t T, const std::vector<float> & targetPos, const std::vector<uint8_t> & valid,
-                                   int warmupIters = 31, int itersPerFrame = 1, bool enableQp = true, int64_t minValid = 0)
+                                   int warmupIters = 32, int itersPerFrame = 1, bool enableQp = true, int64_t minValid = 0)
   {
     if((int64_t)targetPos.size() != T * n_ * K_ * 3 || (int64_t)valid.size() != T * n_ * K_)
       throw Exception("node", "solveSequence: targetPos must be [T,n,K,3] and valid [T,n,K]");

@@ -498,8 +498,11 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if(m->profiling)
     {
+      // (owned by the handle from the moment they exist: smplpp_profile_read / smplpp_model_destroy release them)
       HIP_TRY(hipEventCreate(&e0));
+      m->prof_events.push_back(e0);
       HIP_TRY(hipEventCreate(&e1));
+      m->prof_events.push_back(e1);
       HIP_TRY(hipEventRecord(e0, st));
     }
     if(form == 'h')
@@ -512,12 +515,7 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
       HIP_TRY(launch_skin_w<1>(m, n, theta, verts, rest, st));
     else
       HIP_TRY(launch_skin_w<2>(m, n, theta, verts, rest, st));
-    if(m->profiling)
-    {
-      HIP_TRY(hipEventRecord(e1, st));
-      m->prof_events.push_back(e0);
-      m->prof_events.push_back(e1);
-    }
+    if(m->profiling) HIP_TRY(hipEventRecord(e1, st));
   }
   return SMPLPP_OK;
 }
@@ -538,18 +536,22 @@ extern "C" int smplpp_profile_read(smplpp_model * m, int64_t * launches, double 
   HIP_TRY(hipSetDevice(m->device));
   double total = 0.0;
   const size_t pairs = m->prof_events.size() / 2;
+  size_t good = 0;
   for(size_t i = 0; i < pairs; i++)
   {
     float ms = 0.0f;
-    HIP_TRY(hipEventSynchronize(m->prof_events[2 * i + 1]));
-    HIP_TRY(hipEventElapsedTime(&ms, m->prof_events[2 * i], m->prof_events[2 * i + 1]));
-    total += ms;
-    (void)hipEventDestroy(m->prof_events[2 * i]);
-    (void)hipEventDestroy(m->prof_events[2 * i + 1]);
+    if(hipEventSynchronize(m->prof_events[2 * i + 1]) == hipSuccess &&
+       hipEventElapsedTime(&ms, m->prof_events[2 * i], m->prof_events[2 * i + 1]) == hipSuccess)
+    {
+      total += ms;
+      good++;
+    }
   }
+  for(hipEvent_t e : m->prof_events) (void)hipEventDestroy(e);
   m->prof_events.clear();
-  *launches = (int64_t)pairs;
-  *mean_ms = pairs ? total / (double)pairs : 0.0;
+  (void)hipGetLastError();
+  *launches = (int64_t)good;
+  *mean_ms = good ? total / (double)good : 0.0;
   return SMPLPP_OK;
 }
 

@@ -224,6 +224,8 @@ extern "C" int smplpp_model_destroy(smplpp_model * m)
 {
   if(!m) return SMPLPP_OK;
   (void)hipSetDevice(m->device);
+  for(hipEvent_t e : m->prof_events) (void)hipEventDestroy(e);
+  m->prof_events.clear();
   void * ptrs[] = {m->Bm, m->B3, m->B2h, m->lvl, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm};
   for(void * p : ptrs)
     if(p) (void)hipFree(p);

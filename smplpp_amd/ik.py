@@ -235,7 +235,7 @@ class IkSolver:
         return e2
 
     # ---- node.cpp:1369-1407 (+ :681-700): the frame loop of solveMocapMotion without a host round trip per frame
-    def solveSequence(self, target_pos, valid, warmup_iters=31, iters_per_frame=1, enable_qp=True, min_valid=0):
+    def solveSequence(self, target_pos, valid, warmup_iters=32, iters_per_frame=1, enable_qp=True, min_valid=0):
         """target_pos [T,n,K,3] float32, valid [T,n,K] bool -> theta [T,n,theta_dim] after every frame."""
         tp = np.ascontiguousarray(target_pos, np.float32)
         vl = np.ascontiguousarray(valid, np.uint8)

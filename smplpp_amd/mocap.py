@@ -7,7 +7,8 @@
 * `BASELINE41` — the OptiTrack Baseline-41 marker -> SMPL face table of node/node.cpp:455-500.
 * `match_markers` — suffix label match of node/node.cpp:583-594.
 * `MocapMotionSolver` — node/node.cpp:1362-1412 for R independent restarts/sequences in lock step on one GPU:
-  31 iterations on the first frame (`ikIter > 30`, :1369), then exactly ONE IK iteration per C3D frame, warm-started;
+  32 iterations on the first frame (the store block `ikIter > 30`, :1369, runs AFTER the solve of the same pass: passes
+  0..31), then exactly ONE IK iteration per C3D frame, warm-started;
   missing markers get posTaskWeight_ = 0 (:674-683); frames with fewer than K/2 valid markers skip the solve (:785);
   QP on, phi limits 0, normal task off, normal offset 15 mm (:316-322, :553-567, :699).
 * `write_motion_text` — scripts/convertRosbagToText.py:18-19 (one frame per line, theta 25x3 row-major).
@@ -180,7 +181,7 @@ def match_markers(point_labels: Sequence[str], task_names: Sequence[str]) -> Lis
 class MocapMotionSolver:
     """R independent chains (restarts or sequences) over T frames, in lock step on one GPU."""
 
-    WARMUP_ITERS = 31  # frames advance once ikIter > 30 (node/node.cpp:1369)
+    WARMUP_ITERS = 32  # frame 0 is solved in passes ikIter = 0..31: the store block (ikIter > 30, node/node.cpp:1369) follows the solve
 
     def __init__(self, smpl, face_idx, vertex_weights, restarts: int, vposer=None, marker_thickness=0.015):
         from .ik import IkSolver

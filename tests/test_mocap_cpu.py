@@ -43,6 +43,27 @@ def test_reference_sample_excerpt_matches_reader():
         assert c["rate"] == 120.0
 
 
+def test_reference_sample_full_fixture_matches_reader():
+    """tests/golden/sample_walk_full.npz (every frame of data/sample_walk.c3d, made by tools/make_sample_walk_fixture.py):
+    the counts SURVEY.md §8d quotes for config 4, the excerpt is a subset, and — when the reference tree is present — the
+    reader on the original file gives the same arrays."""
+    g = np.load(os.path.join(GOLDEN, "sample_walk_full.npz"))
+    assert g["points"].shape == (3163, 41, 3) and g["valid"].shape == (3163, 41)
+    assert int((~g["valid"]).sum()) == 4420 and int((~g["valid"]).any(axis=1).sum()) == 619
+    assert list(g["task_names"]) == sorted(mocap.BASELINE41)  # std::map order (node/node.cpp:47, 798)
+    nv = g["valid"].sum(axis=1)
+    assert int((nv < 20).sum()) == 60 and int((nv == 0).sum()) == 60  # the frames node.cpp:785 skips
+    e = np.load(os.path.join(GOLDEN, "sample_walk_excerpt.npz"))
+    assert np.array_equal(g["valid"][e["frame_ids"]], e["valid"])
+    assert np.array_equal(g["points"][e["frame_ids"]][e["valid"]], e["points"][e["valid"]])
+    path = "/root/reference/data/sample_walk.c3d"
+    if os.path.exists(path):
+        c = mocap.read_c3d(path)
+        idx = mocap.match_markers(c["labels"], list(g["task_names"]))
+        assert np.array_equal(c["valid"][:, idx], g["valid"])
+        assert np.array_equal(c["points"][:, idx][g["valid"]], g["points"][g["valid"]])
+
+
 def test_baseline41_table():
     assert len(mocap.BASELINE41) == 41 and mocap.BASELINE41["HeadTop"] == 7324 and mocap.BASELINE41["RHeel"] == 12705
     assert max(mocap.BASELINE41.values()) < 13776

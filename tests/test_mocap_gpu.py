@@ -1,5 +1,5 @@
 """BASELINE config 4 in miniature: MoSh-style sequence fit (node.cpp:1362-1412) — R restarts in lock step on one GPU,
-31 warm-up iterations then one iteration per frame, missing markers, skipped frames."""
+32 warm-up iterations then one iteration per frame, missing markers, skipped frames."""
 import os
 
 import numpy as np
@@ -92,6 +92,70 @@ def test_reference_capture_excerpt_runs(smpl, tmp_path):
             assert np.abs(th[:, t] - th[:, t - 1]).max() == 0
     mocap.write_motion_text(str(tmp_path / "motion.txt"), ms.decode_theta(th[0]))
     assert len(open(str(tmp_path / "motion.txt")).read().splitlines()) == len(frames)
+
+
+def _capture_full():
+    from smplpp_amd import mocap
+
+    g = np.load(os.path.join(GOLDEN, "sample_walk_full.npz"))
+    names = list(g["task_names"])
+    faces = np.array([mocap.BASELINE41[n] for n in names], np.int64)
+    pts = g["points"] - g["points"][0][g["valid"][0]].mean(axis=0) + np.array([0, -0.3, 0], np.float32)
+    return names, faces, pts.astype(np.float32), g["valid"]
+
+
+def test_reference_capture_full_sequence(smpl):
+    """BASELINE.json configs[3] at its stated length: all 3163 frames x 41 markers of data/sample_walk.c3d
+    (tests/golden/sample_walk_full.npz), serial warm-start chain of node/node.cpp:1369-1407 on the device, 4 restarts.
+    619 frames have missing markers; 60 frames have fewer than 20 valid markers (all of them 0 valid) and must skip the solve
+    (node.cpp:785): their stored configuration equals the previous frame's, bit for bit. The synthetic body is not a
+    human: mechanics only."""
+    from smplpp_amd import mocap
+
+    names, faces, pts, valid = _capture_full()
+    T, K = valid.shape
+    assert (T, K) == (3163, 41)
+    R = 4
+    rng = np.random.default_rng(21)
+    theta0 = np.zeros((R, 25, 3), np.float32)
+    theta0[:, 1:] = rng.normal(0, 0.03, (R, 24, 3))
+    ms = mocap.MocapMotionSolver(smpl, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R)
+    th, frames = ms.solve(pts, valid, np.zeros(10, np.float32), theta0)
+    assert th.shape == (R, T, 75) and frames == list(range(T))
+    assert np.isfinite(th).all()
+    nv = valid.sum(axis=1)
+    skipped = np.nonzero(nv < K // 2)[0]
+    assert len(skipped) == 60 and (nv[skipped] == 0).all()
+    for t in skipped:
+        assert np.abs(th[:, t] - th[:, t - 1]).max() == 0, t
+    solved = np.nonzero(nv >= K // 2)[0][1:]
+    moved = np.abs(th[:, solved] - th[:, solved - 1]).reshape(R, len(solved), -1).max(axis=2)
+    assert (moved > 0).mean() > 0.99  # every solved frame takes a step
+    assert np.abs(th[..., :3]).max() < 10.0  # the root follows the capture volume (metres), nothing diverges
+
+
+def test_reference_capture_window_device_loop_matches_host_loop(smpl):
+    """A 300-frame window of the real capture that contains missing markers and skipped (0-valid) frames: the device-side
+    frame loop (smplpp_ik_solve_sequence) against the host-driven loop, bit for bit."""
+    from smplpp_amd import mocap
+
+    names, faces, pts, valid = _capture_full()
+    K = valid.shape[1]
+    w0 = 400  # frames 466, 484, 588 have no valid marker; many frames around them lose single markers
+    win = slice(w0, w0 + 300)
+    nv = valid[win].sum(axis=1)
+    assert (nv == 0).sum() >= 3 and ((nv > 0) & (nv < K)).sum() >= 10
+    R = 2
+    theta0 = np.zeros((R, 25, 3), np.float32)
+    theta0[1, 1:] = np.random.default_rng(4).normal(0, 0.03, (24, 3))
+    out = []
+    for host_loop in (True, False):
+        ms = mocap.MocapMotionSolver(smpl, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R)
+        th, _ = ms.solve(pts[win], valid[win], np.zeros(10, np.float32), theta0, host_loop=host_loop)
+        out.append((th, ms.solver.getTasks()["face_idx"]))
+    assert np.isfinite(out[0][0]).all()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
 
 
 def test_device_frame_loop_matches_host_driven_loop(smpl, synth_model):
