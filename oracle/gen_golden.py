@@ -222,7 +222,71 @@ def ref_goldens():
     np.savez_compressed(os.path.join(OUT, "ik_synth.npz"), **save)
 
 
+def ik_traj50():
+    """BASELINE.json configs[2] length: the 50-iteration reference trajectory (libtorch autograd Jacobian through the
+    reference's compiled FK stages, node.cpp:823-869; fp64 normal equations + LLT, :883-943; re-projection by the C oracle)
+    from the start state of ik_synth.npz — TWICE, with libtorch on all threads and on ONE thread.  The two runs execute
+    the same reference code; they differ only in the fp32 summation order of its GEMMs.  Their divergence is the
+    reference's own fp32 sensitivity along the weakly observed directions of this under-determined problem (75 unknowns,
+    24 rows, damping 1e-3 + |e|^2 -> 1e-3): the yardstick for any free-running comparison."""
+    from oracle import cpu, ref
+    from smplpp_amd import model_io
+
+    model = model_io.synthetic_model()
+    R = ref.RefModel(model)
+    O = cpu.OracleModel(model)
+    g = np.load(os.path.join(OUT, "ik_synth.npz"))
+    V = model["vertices_template"].shape[0]
+    for v in range(V):
+        row = g["adjacency"][v]
+        O.set_adjacency(v, row[row >= 0])
+    K = len(g["face_idx"])
+    iters = 50
+
+    def run(threads):
+        ref.lib().ref_set_num_threads(threads)
+        th = g["traj_theta"][0].copy()
+        tasks = cpu.TaskSet(g["face_idx"], g["target_pos"], g["target_normal"], phi_limit=np.zeros(K))
+        traj = np.zeros((iters + 1, 25, 3), np.float32)
+        faces = np.zeros((iters + 1, K), np.int64)
+        weights = np.zeros((iters + 1, K, 3), np.float32)
+        e2 = np.zeros(iters)
+        traj[0], faces[0], weights[0] = th, tasks.face_idx, tasks.vertex_weights
+        for it in range(iters):
+            rr = R.ik_eval(np.zeros(10, np.float32), th, tasks.face_idx, tasks.target_pos, tasks.target_normal, [1.0] * K,
+                           [1.0] * K, [0.0] * K, [0.0] * K, tasks.vertex_weights, False)
+            x = numpy_ik_step(rr["e"], rr["J"], 75, 2 * K, 0)
+            verts = R.fk(np.zeros((1, 10), np.float32), th[None], want=("verts",))["verts"][0]
+            th = th + x[:75].astype(np.float32).reshape(25, 3)
+            pts = rr["actual_pos"] + np.einsum("kxc,kc->kx", rr["tangents"], x[75:75 + 2 * K].astype(np.float32).reshape(K, 2))
+            face, closest, _ = O.closest_points(verts, pts)
+            tasks.face_idx[:] = face
+            f0 = model["face_indices"][face] - 1
+            for k in range(K):
+                tasks.vertex_weights[k] = cpu.triangle_vertex_weights(closest[k], verts[f0[k]])
+            traj[it + 1], faces[it + 1], weights[it + 1] = th, tasks.face_idx, tasks.vertex_weights
+            e2[it] = float(rr["e"] @ rr["e"])
+        return traj, faces, weights, e2
+
+    nthr = max(2, (os.cpu_count() or 2))
+    a = run(nthr)
+    b = run(1)
+    assert np.array_equal(a[0][:13], g["traj_theta"]) or np.abs(a[0][:13] - g["traj_theta"]).max() < 3e-3
+    drift = np.abs(a[0] - b[0]).reshape(iters + 1, -1).max(axis=1)
+    print("ik_traj50 |e|^2:", ["%.3g" % v for v in a[3][::7]])
+    print("reference vs reference (threads %d vs 1), max |dtheta| per iteration:" % nthr, ["%.2g" % v for v in drift[::5]])
+    np.savez_compressed(os.path.join(OUT, "ik_traj50.npz"), face_idx=g["face_idx"], target_pos=g["target_pos"], target_normal=g["target_normal"],
+                        traj_theta=a[0], traj_faces=a[1], traj_weights=a[2], traj_e_sqnorm=a[3],
+                        alt_theta=b[0], alt_faces=b[1], alt_e_sqnorm=b[3], threads=np.array([nthr, 1]))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    tester_kats()
-    ref_goldens()
+    import sys
+
+    if "--traj50" in sys.argv:
+        ik_traj50()
+    else:
+        tester_kats()
+        ref_goldens()
+        ik_traj50()

@@ -1,8 +1,12 @@
 """GPU parity of the IK path (node/node.cpp:704-1001) through the C ABI against the reference's autograd goldens and
 the C oracle.  Tolerances: residual rows 2e-6 m (position) / 5e-5 (normal); Jacobian to fp32 rounding of the
 reference's autograd path; joint angles 1e-4 rad per step (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
+
+from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
@@ -251,6 +255,100 @@ def test_ik_many_frames_surface_queries(smpl, oracle_synth, synth_model):
     _, theta = s.getConfig()
     assert np.isfinite(theta).all() and np.isfinite(e2b).all()
     assert np.median(e2b) < 0.05 * np.median(e2)
+
+
+def test_ik_traj50_engine_per_step_and_free_run(smpl, oracle_synth):
+    """The 50-iteration reference trajectory (tests/golden/ik_traj50.npz): (1) one engine iteration from each of its 50
+    states is within 1e-4 rad of the reference's next state, same faces; (2) free-running, the engine's drift from the
+    reference stays within 3x the reference's own thread-count divergence (see
+    tests/test_oracle_golden.py::test_ik_traj50_free_run_drift_is_the_references_own_noise) and the engine tracks the
+    fp64-Jacobian oracle's free run more closely than either tracks the reference."""
+    from oracle import cpu
+    from smplpp_amd.ik import IkSolver
+
+    g = np.load(os.path.join(GOLDEN, "ik_traj50.npz"))
+    K = len(g["face_idx"])
+    traj = g["traj_theta"]
+    s = IkSolver(smpl, 50, K)
+    s.setTasks(face_idx=g["traj_faces"][:50], vertex_weights=g["traj_weights"][:50], target_pos=g["target_pos"],
+               target_normal=g["target_normal"], phi_limit=np.zeros(K))
+    s.setConfig(np.zeros((50, 10), np.float32), traj[:50])
+    e2 = s.iterate(1)
+    _, theta = s.getConfig()
+    t = s.getTasks()
+    for it in range(50):
+        assert np.abs(theta[it] - traj[it + 1]).max() < 1e-4, it
+        assert (t["face_idx"][it] == g["traj_faces"][it + 1]).all(), it
+        assert abs(e2[it] - g["traj_e_sqnorm"][it]) < 2e-5 * max(1.0, e2[it])
+    # free run: engine, oracle, reference
+    ref_noise = np.abs(g["alt_theta"] - traj).reshape(51, -1).max(axis=1)
+    s2 = IkSolver(smpl, 1, K)
+    s2.setTasks(face_idx=g["face_idx"], target_pos=g["target_pos"], target_normal=g["target_normal"], phi_limit=np.zeros(K))
+    s2.setConfig(np.zeros((1, 10), np.float32), traj[:1])
+    ts = cpu.TaskSet(g["face_idx"], g["target_pos"], g["target_normal"], phi_limit=np.zeros(K))
+    tho, beta = traj[0].copy(), np.zeros(10, np.float32)
+    d_ref, d_orc = [], []
+    for it in range(50):
+        e2 = s2.iterate(1)
+        _, the = s2.getConfig()
+        beta, tho, e2o = oracle_synth.ik_solve(beta, tho, ts, 1)
+        d_ref.append(np.abs(the[0] - traj[it + 1]).max())
+        d_orc.append(np.abs(the[0] - tho).max())
+    d_ref, d_orc = np.array(d_ref), np.array(d_orc)
+    assert d_ref[:5].max() < 1e-4
+    assert d_ref.max() < 3.0 * ref_noise.max() and np.median(d_ref) < 3.0 * np.median(ref_noise[1:])
+    assert d_orc.max() < 3.0 * ref_noise.max()
+    assert e2[0] < 1e-5 and e2o < 1e-5
+
+
+def test_ik_config2_size_256_frames_50_iterations(smpl, oracle_synth, synth_model):
+    """BASELINE.json configs[2] at its stated size: 256 frames x 6 targets (position + normal term) x 50 iterations in one
+    solver.  Sampled frames are re-synchronised with the oracle at iterations 1, 10, 25 and 50: one oracle iteration from
+    the engine's own state (pose, faces, barycentric weights) lands within 1e-4 rad of the engine's next state.  The
+    convergence verdict (|e|^2 < 1e-3 after 50 iterations) of the oracle's free run equals the engine's on those frames."""
+    from oracle import cpu
+    from smplpp_amd.ik import IkSolver, reference_task_faces
+
+    n, K, iters = 256, 6, 50
+    _, faces = reference_task_faces(K)
+    rng = np.random.default_rng(100)
+    hid = np.zeros((n, 25, 3), np.float32)
+    hid[:, 1:] = rng.normal(0, 0.2, (n, 24, 3))
+    hv = smpl.launch(np.zeros((n, 10), np.float32), hid, want=("verts",))["verts"]
+    f0 = synth_model["face_indices"][faces] - 1
+    tp = hv[:, f0].mean(axis=2)
+    tn = smpl.calcVertexNormalBatch(f0.reshape(-1)).reshape(n, K, 3, 3).mean(axis=2)
+    tn = -(tn / np.linalg.norm(tn, axis=-1, keepdims=True)).astype(np.float32)
+    theta0 = np.zeros((n, 25, 3), np.float32)
+    theta0[:, 1:] = rng.normal(0, 0.05, (n, 24, 3))
+    s = IkSolver(smpl, n, K)
+    s.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, phi_limit=np.zeros(K), normal_task_weight=np.ones(K))
+    s.setConfig(np.zeros((n, 10), np.float32), theta0)
+    sample = [0, 37, 101, 255]
+    done = 0
+    for target in (1, 10, 25, 50):
+        if target - 1 > done:
+            s.iterate(target - 1 - done)
+            done = target - 1
+        _, th_before = s.getConfig()
+        t_before = s.getTasks()
+        e2 = s.iterate(1)
+        done += 1
+        _, th_after = s.getConfig()
+        t_after = s.getTasks()
+        for f in sample:
+            ts = cpu.TaskSet(t_before["face_idx"][f], tp[f], tn[f], phi_limit=np.zeros(K), vertex_weights=t_before["vertex_weights"][f])
+            _, tho, e2o = oracle_synth.ik_solve(np.zeros(10, np.float32), th_before[f].reshape(25, 3), ts, 1)
+            assert np.abs(tho - th_after[f].reshape(25, 3)).max() < 1e-4, (target, f)
+            assert (ts.face_idx == t_after["face_idx"][f]).all(), (target, f)
+            assert abs(e2o - e2[f]) < 2e-5 * max(1.0, e2o), (target, f)
+    assert done == iters
+    conv_engine = e2 < 1e-3
+    assert conv_engine.sum() >= 250  # the normal terms make the problem non-convex: a few starts end in a local minimum
+    for f in sample + list(np.nonzero(~conv_engine)[0][:2]):
+        ts = cpu.TaskSet(faces, tp[f], tn[f], phi_limit=np.zeros(K))
+        _, _, e2o = oracle_synth.ik_solve(np.zeros(10, np.float32), theta0[f], ts, iters)
+        assert (e2o < 1e-3) == bool(conv_engine[f]), (f, e2o, e2[f])
 
 
 def _run_ik(smpl, g, n, iters, env, monkeypatch, **kw):

@@ -114,6 +114,49 @@ def test_ik_trajectory_golden(oracle_synth, golden_ik_synth):
     assert e2 < 2e-5 and g["traj_e_sqnorm"][-1] < 2e-5
 
 
+def _traj50():
+    return np.load(os.path.join(GOLDEN, "ik_traj50.npz"))
+
+
+def test_ik_traj50_per_step_from_synchronised_states(oracle_synth):
+    """BASELINE.json configs[2] length (50 iterations): from every state of the reference-autograd trajectory
+    (tests/golden/ik_traj50.npz, oracle/gen_golden.py --traj50) one oracle iteration lands within 1e-4 rad of the
+    reference's next state (observed: 6e-6), with the same re-projected faces."""
+    g = _traj50()
+    K = len(g["face_idx"])
+    traj = g["traj_theta"]
+    for it in range(50):
+        ts = cpu.TaskSet(g["traj_faces"][it], g["target_pos"], g["target_normal"], phi_limit=np.zeros(K), vertex_weights=g["traj_weights"][it])
+        _, th, e2 = oracle_synth.ik_solve(np.zeros(10, np.float32), traj[it], ts, 1)
+        assert np.abs(th - traj[it + 1]).max() < 2e-5, it
+        assert (ts.face_idx == g["traj_faces"][it + 1]).all(), it
+        assert abs(e2 - g["traj_e_sqnorm"][it]) < 2e-5 * max(1.0, e2)
+
+
+def test_ik_traj50_free_run_drift_is_the_references_own_noise(oracle_synth):
+    """Free-running for 50 iterations the fp64-Jacobian oracle drifts from the reference trajectory by ~4e-4 rad (max 1.4e-3).
+    The yardstick: the SAME reference code run with libtorch on 8 threads and on 1 thread (ik_traj50.npz `alt_theta`:
+    only the fp32 summation order of its GEMMs differs) drifts from itself by 2-3e-4 rad (max 7e-4).  So the free-running
+    difference is the reference's fp32 autograd noise amplified along the weakly observed directions (75 unknowns, 24 rows,
+    damping -> 1e-3), not the analytic Jacobian: an exact-Jacobian solver can only be held to 1e-4 rad per step from
+    synchronised states (test above).  Residuals converge alike."""
+    g = _traj50()
+    K = len(g["face_idx"])
+    traj = g["traj_theta"]
+    ref_noise = np.abs(g["alt_theta"] - traj).reshape(51, -1).max(axis=1)
+    assert 1e-4 < ref_noise.max() < 2e-3  # the reference misses the 1e-4 bar against ITSELF when free-running
+    ts = cpu.TaskSet(g["face_idx"], g["target_pos"], g["target_normal"], phi_limit=np.zeros(K))
+    th, beta = traj[0].copy(), np.zeros(10, np.float32)
+    drift = []
+    for it in range(50):
+        beta, th, e2 = oracle_synth.ik_solve(beta, th, ts, 1)
+        drift.append(np.abs(th - traj[it + 1]).max())
+    drift = np.array(drift)
+    assert drift[:5].max() < 1e-4  # while the damping |e|^2 is large the trajectories coincide
+    assert drift.max() < 3.0 * ref_noise.max() and np.median(drift) < 3.0 * np.median(ref_noise[1:])
+    assert e2 < 1e-5 and g["traj_e_sqnorm"][-1] < 1e-5 and g["alt_e_sqnorm"][-1] < 1e-5
+
+
 def test_box_qp_matches_llt_when_unconstrained_and_clamps():
     rng = np.random.default_rng(0)
     J = rng.normal(size=(30, 12))
