@@ -3,7 +3,10 @@
 #ifndef SMPLPP_SHIM_IK_TASK_H
 #define SMPLPP_SHIM_IK_TASK_H
 
+#include <cmath>
+
 #include "SMPL.h"
+#include "VPoser.h"
 
 namespace smplpp
 {
@@ -16,6 +19,81 @@ public:
   : smpl_(smpl), faceIdx_(faceIdx), targetPos_(targetPos), targetNormal_(targetNormal)
   {
   }
+
+  // ---- the four methods of the reference class (include/smplpp/IkTask.h:33-49, src/IkTask.cpp:33-86), on the vertices of
+  // batch 0 of the last SMPL::launch.  In the reference they are also the autograd seam; here they are plain values (the
+  // Jacobian comes from IkSolver::eval).  fp32 like the reference's tensors.
+  // Tangent vectors of the focused face (src/IkTask.cpp:33-48)
+  void calcTangents()
+  {
+    float v[3][3];
+    faceVertices(v);
+    float t1[3], b[3], nrm[3], t2[3];
+    for(int x = 0; x < 3; x++)
+    {
+      t1[x] = v[1][x] - v[0][x];
+      b[x] = v[2][x] - v[0][x];
+    }
+    cross(t1, b, nrm);
+    cross(nrm, t1, t2);
+    normalize(t1);
+    normalize(t2);
+    for(int x = 0; x < 3; x++)
+    {
+      tangents_[(size_t)x * 2 + 0] = t1[x];
+      tangents_[(size_t)x * 2 + 1] = t2[x];
+    }
+  }
+  // Vertex weights such that actualPos + tangents . phi is the weighted sum of the face vertices (src/IkTask.cpp:50-58,
+  // calcTriangleVertexWeights: toolbox/GeometryUtils.h:42-52)
+  void calcVertexWeights(const std::vector<float> & actualPos)
+  {
+    float v[3][3], pos[3], w[3];
+    faceVertices(v);
+    for(int x = 0; x < 3; x++) pos[x] = actualPos[(size_t)x] + tangents_[(size_t)x * 2] * phi_[0] + tangents_[(size_t)x * 2 + 1] * phi_[1];
+    for(int i = 0; i < 3; i++)
+    {
+      float a[3], b[3], c[3];
+      for(int x = 0; x < 3; x++)
+      {
+        a[x] = v[(i + 1) % 3][x] - pos[x];
+        b[x] = v[(i + 2) % 3][x] - pos[x];
+      }
+      cross(a, b, c);
+      w[i] = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    }
+    const float sum = w[0] + w[1] + w[2];
+    for(int i = 0; i < 3; i++) vertexWeights_[(size_t)i] = w[i] / sum;
+  }
+  // Position of the task point (src/IkTask.cpp:60-72)
+  std::vector<float> calcActualPos() const
+  {
+    float v[3][3];
+    faceVertices(v);
+    std::vector<float> p(3, 0.0f);
+    for(int x = 0; x < 3; x++)
+      for(int i = 0; i < 3; i++) p[(size_t)x] += v[i][x] * vertexWeights_[(size_t)i];
+    if(normalOffset_ > 0.0)
+    {
+      const std::vector<float> n = calcActualNormal();
+      for(int x = 0; x < 3; x++) p[(size_t)x] += (float)normalOffset_ * n[(size_t)x];
+    }
+    return p;
+  }
+  // Unit normal of the task point: the weighted vertex normals of the face (src/IkTask.cpp:74-86)
+  std::vector<float> calcActualNormal() const
+  {
+    const std::vector<int32_t> fv = smpl_->getFaceIndexRaw(faceIdx_);
+    float n[3] = {0.f, 0.f, 0.f};
+    for(int i = 0; i < 3; i++)
+    {
+      const Tensor vn = smpl_->calcVertexNormal((int64_t)fv[(size_t)i] - 1);
+      for(int x = 0; x < 3; x++) n[x] += vertexWeights_[(size_t)i] * vn.data[(size_t)x];
+    }
+    normalize(n);
+    return {n[0], n[1], n[2]};
+  }
+
   std::shared_ptr<smplpp::SMPL> smpl_;
   int64_t faceIdx_;
   double posTaskWeight_ = 1.0;
@@ -27,6 +105,27 @@ public:
   std::vector<float> vertexWeights_{1.f / 3, 1.f / 3, 1.f / 3};
   std::vector<float> tangents_ = std::vector<float>(6, 0.f); // [3,2]
   std::vector<float> phi_{0.f, 0.f};
+
+private:
+  void faceVertices(float (&v)[3][3]) const
+  {
+    const std::vector<int32_t> fv = smpl_->getFaceIndexRaw(faceIdx_);
+    const Tensor t = smpl_->getVertexRaw(IndexTensor{(int64_t)fv[0] - 1, (int64_t)fv[1] - 1, (int64_t)fv[2] - 1});
+    for(int i = 0; i < 3; i++)
+      for(int x = 0; x < 3; x++) v[i][x] = t.data[(size_t)i * 3 + x];
+  }
+  static void cross(const float * a, const float * b, float * c)
+  {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+  }
+  static void normalize(float * a) // torch::nn::functional::normalize: x / max(|x|, 1e-12)
+  {
+    const float n = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    const float d = n > 1e-12f ? n : 1e-12f;
+    for(int x = 0; x < 3; x++) a[x] /= d;
+  }
 };
 
 // g_ikTaskList (node/node.cpp:47): std::map order fixes the rows of e/J and the phi column blocks (:798).
@@ -36,10 +135,13 @@ using IkTaskList = std::map<std::string, IkTask>;
 class IkSolver
 {
 public:
-  IkSolver(const std::shared_ptr<SMPL> & smpl, int64_t n, int64_t K) : smpl_(smpl), n_(n), K_(K)
+  // vposer (nullable): the 44-d configuration layout of node/node.cpp:761-772 with the decoder inside the loop
+  IkSolver(const std::shared_ptr<SMPL> & smpl, int64_t n, int64_t K, const std::shared_ptr<VPoserDecoder> & vposer = nullptr)
+  : smpl_(smpl), vposer_(vposer), n_(n), K_(K)
   {
-    check(smplpp_ik_create(smpl->handle(), n, K, nullptr, &s_), "node");
+    check(smplpp_ik_create(smpl->handle(), n, K, vposer ? vposer->handle() : nullptr, &s_), "node");
   }
+  int64_t thetaDim() const { return vposer_ ? (int64_t)(LATENT_DIM + 12) : (int64_t)SMPLPP_THETA_DIM; }
   ~IkSolver() { smplpp_ik_destroy(s_); }
   IkSolver(const IkSolver &) = delete;
   IkSolver & operator=(const IkSolver &) = delete;
@@ -75,20 +177,21 @@ public:
     check(smplpp_ik_set_tasks(s_, face.data(), vw.data(), tp.data(), tn.data(), pw.data(), nw.data(), pl.data(), no.data(), SMPLPP_HOST),
           "node");
   }
-  void setConfig(const Tensor & beta /*[n,10]*/, const Tensor & theta /*[n,25,3]*/)
+  void setConfig(const Tensor & beta /*[n,10]*/, const Tensor & theta /*[n,25,3], or [n,44] with a VPoser*/)
   {
+    if(theta.numel() != n_ * thetaDim()) throw Exception("node", "setConfig: theta must hold n x thetaDim values");
     check(smplpp_ik_set_config(s_, beta.ptr(), theta.ptr(), SMPLPP_HOST), "node");
   }
   void getConfig(Tensor & beta, Tensor & theta)
   {
     beta = Tensor({n_, SHAPE_BASIS_DIM});
-    theta = Tensor({n_, JOINT_NUM + 1, 3});
+    theta = vposer_ ? Tensor({n_, thetaDim()}) : Tensor({n_, JOINT_NUM + 1, 3});
     check(smplpp_ik_get_config(s_, beta.ptr(), theta.ptr(), SMPLPP_HOST), "node");
   }
   // node.cpp:798-877 in one call: e [n,4K], J [n,4K,D] (row-major, fp64)
   void eval(bool optimizeBeta, std::vector<double> & e, std::vector<double> & J)
   {
-    const int64_t D = SMPLPP_THETA_DIM + 2 * K_ + (optimizeBeta ? SHAPE_BASIS_DIM : 0);
+    const int64_t D = thetaDim() + 2 * K_ + (optimizeBeta ? SHAPE_BASIS_DIM : 0);
     e.resize((size_t)(n_ * 4 * K_));
     J.resize((size_t)(n_ * 4 * K_ * D));
     check(smplpp_ik_eval(s_, optimizeBeta ? 1 : 0, e.data(), J.data(), SMPLPP_HOST, nullptr), "node");
@@ -107,15 +210,32 @@ public:
   {
     if((int64_t)targetPos.size() != T * n_ * K_ * 3 || (int64_t)valid.size() != T * n_ * K_)
       throw Exception("node", "solveSequence: targetPos must be [T,n,K,3] and valid [T,n,K]");
-    std::vector<float> theta((size_t)(T * n_ * SMPLPP_THETA_DIM));
+    std::vector<float> theta((size_t)(T * n_ * thetaDim()));
     check(smplpp_ik_solve_sequence(s_, T, targetPos.data(), valid.data(), warmupIters, itersPerFrame, enableQp ? 1 : 0, minValid,
                                    theta.data(), SMPLPP_HOST, nullptr),
           "node");
     return theta;
   }
 
+  // per-task state after the last evaluation / re-projection (what the reference reads back through IkTask fields and
+  // calcActualPos / calcActualNormal, node/node.cpp:803-814, 958, 997-998): faceIdx [n,K], vertexWeights [n,K,3],
+  // tangents [n,K,3,2], actualPos [n,K,3], actualNormal [n,K,3]
+  void getTasks(std::vector<int64_t> & faceIdx, std::vector<float> & vertexWeights, std::vector<float> & tangents,
+                std::vector<float> & actualPos, std::vector<float> & actualNormal)
+  {
+    const size_t nk = (size_t)(n_ * K_);
+    faceIdx.resize(nk);
+    vertexWeights.resize(nk * 3);
+    tangents.resize(nk * 6);
+    actualPos.resize(nk * 3);
+    actualNormal.resize(nk * 3);
+    check(smplpp_ik_get_tasks(s_, faceIdx.data(), vertexWeights.data(), tangents.data(), actualPos.data(), actualNormal.data(), SMPLPP_HOST),
+          "node");
+  }
+
 private:
   std::shared_ptr<SMPL> smpl_;
+  std::shared_ptr<VPoserDecoder> vposer_;
   int64_t n_, K_;
   smplpp_ik * s_ = nullptr;
 };

@@ -67,6 +67,16 @@ struct Tensor
   const float * ptr() const { return data.data(); }
 };
 
+// Minimal owning int64 array (stands in for a torch::Tensor of kInt64: vertex / face index lists).
+struct IndexTensor
+{
+  std::vector<int64_t> data;
+  IndexTensor() = default;
+  IndexTensor(std::initializer_list<int64_t> v) : data(v) {}
+  explicit IndexTensor(std::vector<int64_t> v) : data(std::move(v)) {}
+  int64_t numel() const { return (int64_t)data.size(); }
+};
+
 namespace detail
 {
 // Just enough JSON for the model files scripts/preprocess.py writes: an object of (nested) numeric arrays.
@@ -225,6 +235,19 @@ public:
     need(verts_);
     Tensor t({3});
     for(int x = 0; x < 3; x++) t.data[x] = verts_.data[(size_t)idx * 3 + x];
+    return t;
+  }
+  // index-tensor overload (include/smplpp/SMPL.h:257 of the reference; src/LinearBlendSkinning.cpp:424-427): rows of
+  // batch 0 for a list of vertex ids -> [len, 3]
+  Tensor getVertexRaw(const IndexTensor & idx) const
+  {
+    need(verts_);
+    Tensor t({idx.numel(), 3});
+    for(int64_t i = 0; i < idx.numel(); i++)
+    {
+      if(idx.data[(size_t)i] < 0 || idx.data[(size_t)i] >= V_) throw Exception("LinearBlendSknning", "vertex index out of range");
+      for(int x = 0; x < 3; x++) t.data[(size_t)i * 3 + x] = verts_.data[(size_t)idx.data[(size_t)i] * 3 + x];
+    }
     return t;
   }
   const std::vector<int32_t> & getFaceIndex() const { return faces1_; } // [F,3] 1-based (src/SMPL.cpp:418-433)

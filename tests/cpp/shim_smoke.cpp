@@ -1,15 +1,25 @@
 // Compiles against the header-only C++ shim and libsmplpp_hip.so; driven by tests/test_cpp_shim.py.
-// usage: shim_smoke <model.json> [--expect-no-gpu]
+// usage: shim_smoke <model.json> [<vposer.json>] [--expect-no-gpu]
+// Prints "KEY v0 v1 ..." lines that tests/test_cpp_shim.py compares with the Python mirror's numbers.
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 
 #include <smplpp/IkTask.h>
 #include <smplpp/SMPL.h>
+#include <smplpp/VPoser.h>
+
+static void dump(const char * key, const std::vector<float> & v)
+{
+  std::printf("%s", key);
+  for(float x : v) std::printf(" %.9g", (double)x);
+  std::printf("\n");
+}
 
 int main(int argc, char ** argv)
 {
-  const bool expect_no_gpu = argc > 2 && !std::strcmp(argv[2], "--expect-no-gpu");
+  const bool expect_no_gpu = !std::strcmp(argv[argc - 1], "--expect-no-gpu");
+  const char * vposer_json = (argc > 2 && std::strcmp(argv[2], "--expect-no-gpu")) ? argv[2] : nullptr;
   try
   {
     auto smpl = std::make_shared<smplpp::SMPL>();
@@ -60,6 +70,55 @@ int main(int argc, char ** argv)
     for(float x : seq) finite = finite && std::isfinite(x);
     std::printf("sequence: %zu values, finite %d\n", seq.size(), finite ? 1 : 0);
     if(!finite || seq.size() != (size_t)(T * 75)) return 3;
+    // ---- the reference's IkTask methods (include/smplpp/IkTask.h:33-49) on a posed frame, and the index-tensor getVertexRaw
+    smplpp::Tensor th2({1, 25, 3});
+    for(int i = 3; i < 75; i++) th2.data[(size_t)i] = 0.05f * std::sin(0.7f * (float)i);
+    smpl->launch(beta, th2);
+    smplpp::IkTask task(smpl, 7, {0.1f, 0.0f, 0.2f}, {0.f, 0.f, 1.f});
+    task.normalOffset_ = 0.015;
+    task.phi_ = {0.002f, -0.001f};
+    task.calcTangents();
+    dump("TANGENTS", task.tangents_);
+    const std::vector<int32_t> fv = smpl->getFaceIndexRaw(7);
+    smplpp::Tensor tri = smpl->getVertexRaw(smplpp::IndexTensor{fv[0] - 1, fv[1] - 1, fv[2] - 1});
+    dump("FACEVERTS", tri.data);
+    std::vector<float> centroid(3, 0.f);
+    for(int i = 0; i < 3; i++)
+      for(int x = 0; x < 3; x++) centroid[(size_t)x] += tri.data[(size_t)i * 3 + x] * (i == 0 ? 0.5f : 0.25f);
+    task.calcVertexWeights(centroid);
+    dump("WEIGHTS", task.vertexWeights_);
+    dump("ACTUALPOS", task.calcActualPos());
+    dump("ACTUALNORMAL", task.calcActualNormal());
+    if(vposer_json)
+    {
+      // ---- smplpp::VPoserDecoder (include/smplpp/VPoser.h:53-90) and the latent IK layout
+      auto vposer = std::make_shared<smplpp::VPoserDecoder>(0);
+      vposer->loadParamsFromJson(vposer_json);
+      smplpp::Tensor z({2, 32});
+      for(int i = 0; i < 64; i++) z.data[(size_t)i] = 0.1f * std::cos(0.37f * (float)i);
+      smplpp::Tensor jac;
+      smplpp::Tensor aa = vposer->forward(z, &jac);
+      dump("VPOSER", aa.data);
+      double js = 0.0;
+      for(float x : jac.data) js += std::fabs((double)x);
+      std::printf("VPOSERJACABS %.9g\n", js);
+      smplpp::Tensor rot({1, 3, 3});
+      const float c = std::cos(0.3f), sn = std::sin(0.3f);
+      rot.data = {c, -sn, 0.f, sn, c, 0.f, 0.f, 0.f, 1.f};
+      dump("ROT2AA", smplpp::convertRotMatToAxisAngle(rot).data);
+      smplpp::IkSolver ls(smpl, 1, 2, vposer);
+      ls.setTaskList(tasks);
+      smplpp::Tensor g({1, 44});
+      ls.setConfig(beta, g);
+      auto le2 = ls.iterate(3);
+      smplpp::Tensor b2, g2;
+      ls.getConfig(b2, g2);
+      std::printf("LATENTIK %.9g %zu\n", le2[0], g2.data.size());
+      std::vector<int64_t> tf;
+      std::vector<float> tw, tt, tpv, tnv;
+      ls.getTasks(tf, tw, tt, tpv, tnv);
+      dump("LATENTPOS", tpv);
+    }
     std::printf("OK\n");
     return 0;
   }
