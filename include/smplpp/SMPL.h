@@ -8,6 +8,7 @@
 #ifndef SMPLPP_SHIM_SMPL_H
 #define SMPLPP_SHIM_SMPL_H
 
+#include <array>
 #include <cctype>
 #include <cstdint>
 #include <cstdlib>
@@ -274,6 +275,33 @@ public:
     std::map<int64_t, float> r;
     for(int64_t i = 0; i < cnt && i < 64; i++) r[faces[i]] = w[i];
     return r;
+  }
+  // SMPL::calcVertexNormal for every vertex of every frame of the last launch: [N,V,3]
+  Tensor calcMeshVertexNormals() const
+  {
+    need(verts_);
+    Tensor t(verts_.shape);
+    check(smplpp_mesh_vertex_normals(m_, verts_.size(0), verts_.ptr(), t.ptr(), SMPLPP_HOST, nullptr), "SMPL");
+    return t;
+  }
+  // The sweep grid of node/node.cpp:1023-1073 for frame `index`: the grid indices (cell position = 0.025 m x index) whose
+  // winding number exceeds 0.5 — the keys the reference enters into g_sweepGridList
+  std::vector<std::array<int32_t, 3>> calcSweepGrid(int64_t index = 0) const
+  {
+    need(verts_);
+    const float * v = verts_.ptr() + (size_t)index * V_ * 3;
+    int32_t g0[3], gn[3];
+    int64_t cells = 0;
+    check(smplpp_sweep_grid(m_, v, g0, gn, 0, nullptr, nullptr, &cells, SMPLPP_HOST, nullptr), "SMPL");
+    std::vector<uint8_t> inside((size_t)cells);
+    check(smplpp_sweep_grid(m_, v, g0, gn, cells, nullptr, inside.data(), &cells, SMPLPP_HOST, nullptr), "SMPL");
+    std::vector<std::array<int32_t, 3>> out;
+    int64_t i = 0;
+    for(int32_t x = 0; x < gn[0]; x++)
+      for(int32_t y = 0; y < gn[1]; y++)
+        for(int32_t z = 0; z < gn[2]; z++, i++)
+          if(inside[(size_t)i]) out.push_back({g0[0] + x, g0[1] + y, g0[2] + z});
+    return out;
   }
   // SMPL::out (src/SMPL.cpp:757-790): Wavefront OBJ of frame `index`
   void out(int64_t index, const std::string & path) const

@@ -116,6 +116,16 @@ int smplpp_vertex_normals(smplpp_model * m, int64_t n, const float * verts, int6
  * frame's posed mesh.  face [n,K] (0-based), closest [n,K,3], sqdist [n,K] (nullable). */
 int smplpp_closest_points(smplpp_model * m, int64_t n, const float * verts, int64_t K, const float * points,
                           int64_t * face, float * closest, float * sqdist, int space, void * stream);
+/* SMPL::calcVertexNormal (src/SMPL.cpp:527-535) for EVERY vertex of every frame: normals [n,V,3]. */
+int smplpp_mesh_vertex_normals(smplpp_model * m, int64_t n, const float * verts, float * normals, int space, void * stream);
+/* The sweep grid of node/node.cpp:1023-1073 for ONE frame of posed vertices [V,3]: cells of GRID_SCALE = 0.025 m
+ * (toolbox/GridUtils.hpp:28) from getGridIdxFloor(min) to getGridIdxCeil(max) per axis (:46-60) -> grid_min [3] (cell
+ * index of the first cell), grid_num [3]; cells are ordered x outermost, z innermost like the reference's loops (:1037-1048).
+ * winding [cap] (nullable) = generalized winding number of the mesh at each cell position (igl::winding_number, :1052),
+ * inside [cap] (nullable) = the cells the reference enters into g_sweepGridList (winding number > 0.5, :1057).  *cells = the
+ * grid's cell count; at most `cap` cells are evaluated (call with cap = 0 to size the arrays). */
+int smplpp_sweep_grid(smplpp_model * m, const float * verts, int32_t * grid_min, int32_t * grid_num, int64_t cap,
+                      float * winding, uint8_t * inside, int64_t * cells, int space, void * stream);
 /* SMPL::getAdjacentFaces (src/SMPL.cpp:537-540): host copy; returns the count in *count, fills up to cap. */
 int smplpp_adjacent_faces(const smplpp_model * m, int64_t vertex, int64_t cap, int64_t * faces, float * weights,
                           int64_t * count);
@@ -158,6 +168,16 @@ int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * target_pos,
                              int iters_per_frame, int enable_qp, int64_t min_valid, float * theta_out, int space, void * stream);
 /* Vertices of the last forward inside the solver [n,V,3] (SMPL::getVertex after the loop's launch). */
 int smplpp_ik_get_vertices(smplpp_ik * s, float * verts, int space, void * stream);
+/* Outcome of the solves so far, per frame: bit 0 = the LAST solve failed with the reference's "LLT has numerical issue!"
+ * (node/node.cpp:934-937; that frame's update was skipped), bit 1 = some solve failed since the configuration was set /
+ * the sequence started.  Host-space iterate / solve_sequence calls return SMPLPP_ERR_NUMERIC themselves; enqueue-only
+ * (SMPLPP_DEVICE) callers have no return value to inspect and read it here (waits for `stream` first). flags [n]. */
+int smplpp_ik_get_status(smplpp_ik * s, int32_t * flags, int space, void * stream);
+
+/* Streams and sharing.  A model owns ONE workspace (pose coefficients, relative transforms of the last forward pass) that
+ * smplpp_fk and every smplpp_ik built on the model write: all work on one model handle must be issued in stream order on
+ * ONE caller stream (or be separated by the caller's own synchronisation).  The setters (set_tasks / set_config) are
+ * host-synchronous on the NULL stream; call them only when no enqueue-only call on the solver is still in flight. */
 
 /* ------------------------------------------------------------------ VPoser decoder (src/VPoser.cpp) */
 /* VPoserDecoderImpl (VPoser.h:53-90): Linear(32,512) LeakyReLU Dropout(eval) Linear(512,512) LeakyReLU

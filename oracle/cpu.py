@@ -65,6 +65,7 @@ def lib():
         L.oracle_vertex_normal.argtypes = [C.c_void_p, _f, C.c_int64, _f]
         L.oracle_triangle_vertex_weights.argtypes = [_f, _f, _f]
         L.oracle_closest_points.argtypes = [C.c_void_p, _f, C.c_int64, _f, _i64, _f, _f]
+        L.oracle_winding_numbers.argtypes = [C.c_void_p, _f, C.c_int64, _f, _d]
         L.oracle_ik_eval.argtypes = [C.c_void_p, _f, _f, C.POINTER(_Tasks), C.c_int, _f, _f, _d, _d, _f]
         L.oracle_normal_equations.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64, _d, _d, _f, _d, _d]
         L.oracle_llt_solve.argtypes = [C.c_int64, _d, _d, _d]
@@ -164,6 +165,14 @@ class OracleModel:
         n = np.empty(3, np.float32)
         lib().oracle_vertex_normal(self.h, _p(verts, _f), vertex, _p(n, _f))
         return n
+
+    def winding_numbers(self, verts, points):
+        """igl::winding_number (node/node.cpp:1052) at points [K,3] for one frame's vertices."""
+        verts = _f32(verts)
+        points = _f32(points).reshape(-1, 3)
+        w = np.empty(points.shape[0], np.float64)
+        lib().oracle_winding_numbers(self.h, _p(verts, _f), points.shape[0], _p(points, _f), _p(w, _d))
+        return w
 
     def closest_points(self, verts, points):
         verts = _f32(verts)

@@ -46,6 +46,8 @@ int oracle_max_threads(void);
 void oracle_face_normal(const oracle_model * m, const float * verts /*[V,3]*/, int64_t face, float * n3);
 void oracle_vertex_normal(const oracle_model * m, const float * verts, int64_t vertex, float * n3);
 void oracle_triangle_vertex_weights(const float * pos3, const float * tri9, float * w3);
+/* igl::winding_number (node/node.cpp:1052) restated as the plain solid-angle sum, fp64: points [count,3] -> w [count] */
+void oracle_winding_numbers(const oracle_model * m, const float * verts, int64_t count, const float * points, double * w);
 /* igl::point_mesh_squared_distance restated as exact brute force (node/node.cpp:982) */
 void oracle_closest_points(const oracle_model * m, const float * verts, int64_t K, const float * points /*[K,3]*/,
                            int64_t * face /*[K]*/, float * closest /*[K,3]*/, float * sqdist /*[K]*/);

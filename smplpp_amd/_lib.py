@@ -66,6 +66,8 @@ def load():
         "smplpp_face_normals": [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int, vp],
         "smplpp_vertex_normals": [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int, vp],
         "smplpp_closest_points": [vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, C.c_int, vp],
+        "smplpp_mesh_vertex_normals": [vp, C.c_int64, vp, vp, C.c_int, vp],
+        "smplpp_sweep_grid": [vp, vp, vp, vp, C.c_int64, vp, vp, i64p, C.c_int, vp],
         "smplpp_adjacent_faces": [vp, C.c_int64, C.c_int64, i64p, f32p, i64p],
         "smplpp_ik_create": [vp, C.c_int64, C.c_int64, vp, C.POINTER(vp)],
         "smplpp_ik_destroy": [vp],
@@ -77,6 +79,7 @@ def load():
         "smplpp_ik_iterate": [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, C.c_int, vp],
         "smplpp_ik_solve_sequence": [vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, C.c_int, vp],
         "smplpp_ik_get_vertices": [vp, vp, C.c_int, vp],
+        "smplpp_ik_get_status": [vp, vp, C.c_int, vp],
         "smplpp_vposer_create": [C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(vp)],
         "smplpp_vposer_destroy": [vp],
         "smplpp_vposer_forward": [vp, C.c_int64, vp, vp, vp, C.c_int, vp],

@@ -2739,6 +2739,30 @@ extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * 
   return SMPLPP_OK;
 }
 
+// Per-frame outcome of the solves so far: flags[f] bit 0 = the last solve of frame f failed ("LLT has numerical issue!",
+// node/node.cpp:934-937: the update of that frame was skipped), bit 1 = some solve since the last set_config /
+// solve_sequence start failed.  SMPLPP_HOST calls of iterate / solve_sequence report the same condition as an error; a
+// SMPLPP_DEVICE (enqueue-only) caller reads it here once its stream has reached the point of interest.
+extern "C" int smplpp_ik_get_status(smplpp_ik * s, int32_t * flags, int space, void * stream)
+{
+  if(!s || !flags) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_get_status: bad argument");
+  int rc = check_space(space, "smplpp_ik_get_status");
+  if(rc) return rc;
+  HIP_TRY(hipSetDevice(s->m->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  std::vector<int> a((size_t)s->n), b((size_t)s->n);
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipMemcpy(a.data(), s->status, sizeof(int) * s->n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(b.data(), s->sticky, sizeof(int) * s->n, hipMemcpyDeviceToHost));
+  std::vector<int32_t> h((size_t)s->n);
+  for(int64_t f = 0; f < s->n; f++) h[(size_t)f] = (a[(size_t)f] == 1 ? 1 : 0) | (b[(size_t)f] ? 2 : 0);
+  if(space == SMPLPP_HOST)
+    memcpy(flags, h.data(), sizeof(int32_t) * (size_t)s->n);
+  else
+    HIP_TRY(hipMemcpy(flags, h.data(), sizeof(int32_t) * (size_t)s->n, hipMemcpyHostToDevice));
+  return SMPLPP_OK;
+}
+
 extern "C" int smplpp_ik_get_vertices(smplpp_ik * s, float * verts, int space, void * stream)
 {
   if(!s || !verts) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_get_vertices: bad argument");

@@ -207,6 +207,13 @@ class IkSolver:
         check(_lib.load().smplpp_ik_get_tasks(self._h, _ptr(face), _ptr(vw), _ptr(tang), _ptr(apos), _ptr(anrm), HOST))
         return dict(face_idx=face, vertex_weights=vw, tangents=tang, actual_pos=apos, actual_normal=anrm)
 
+    def getStatus(self):
+        """Per-frame solve outcome (bit 0: the last solve hit "LLT has numerical issue!", node.cpp:934-937; bit 1: some
+        solve did since setConfig / the sequence start) — what an enqueue-only caller checks after synchronising."""
+        f = np.zeros(self.n, np.int32)
+        check(_lib.load().smplpp_ik_get_status(self._h, _ptr(f), HOST, None))
+        return f
+
     # ---- configuration g_beta / g_theta (node.cpp:44-45)
     def setConfig(self, beta=None, theta=None):
         b = _np32(beta, (self.n, 10)) if beta is not None else None

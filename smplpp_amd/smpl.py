@@ -237,6 +237,50 @@ class SMPL:
     def calcVertexNormalBatch(self, vertexIds):
         return self._normals(vertexIds, True)
 
+    def calcMeshVertexNormals(self):
+        """SMPL::calcVertexNormal (src/SMPL.cpp:527-535) for every vertex of every frame of the last launch: [N,V,3]."""
+        verts = self._need("verts")
+        L = _lib.load()
+        if _is_torch(verts):
+            out = torch.empty_like(verts)
+            check(L.smplpp_mesh_vertex_normals(self.handle, verts.shape[0], _ptr(verts), _ptr(out), DEVICE, _stream()))
+        else:
+            out = np.empty_like(verts)
+            check(L.smplpp_mesh_vertex_normals(self.handle, verts.shape[0], _ptr(verts), _ptr(out), HOST, None))
+        return out
+
+    def calcSweepGrid(self, frame=0):
+        """The sweep grid of node/node.cpp:1023-1073 for one frame of the last launch: dict(grid_min [3], grid_num [3],
+        winding [cells], inside [cells] bool, grid_idx [cells,3] int32 in the reference's cell order, positions = 0.025 *
+        grid_idx). `inside` marks the cells the reference enters into g_sweepGridList (winding number > 0.5)."""
+        verts = self._need("verts")
+        v = verts[frame]
+        if _is_torch(v):
+            v = v.contiguous()
+            space, st = DEVICE, _stream()
+        else:
+            v = np.ascontiguousarray(v)
+            space, st = HOST, None
+        L = _lib.load()
+        gmin = np.zeros(3, np.int32)
+        gnum = np.zeros(3, np.int32)
+        cells = C.c_int64(0)
+        check(L.smplpp_sweep_grid(self.handle, _ptr(v), _ptr(gmin), _ptr(gnum), 0, None, None, C.byref(cells), space, st))
+        n = int(cells.value)
+        if space == DEVICE:
+            w = torch.empty(n, dtype=torch.float32, device=v.device)
+            ins = torch.empty(n, dtype=torch.uint8, device=v.device)
+        else:
+            w = np.empty(n, np.float32)
+            ins = np.empty(n, np.uint8)
+        check(L.smplpp_sweep_grid(self.handle, _ptr(v), _ptr(gmin), _ptr(gnum), n, _ptr(w), _ptr(ins), C.byref(cells), space, st))
+        if space == DEVICE:
+            torch.cuda.synchronize()
+            w, ins = w.cpu().numpy(), ins.cpu().numpy()
+        ix, iy, iz = np.meshgrid(*[np.arange(gmin[a], gmin[a] + gnum[a], dtype=np.int32) for a in range(3)], indexing="ij")
+        gidx = np.stack([ix.reshape(-1), iy.reshape(-1), iz.reshape(-1)], axis=1)
+        return dict(grid_min=gmin, grid_num=gnum, winding=w, inside=ins.astype(bool), grid_idx=gidx)
+
     def closestPoints(self, points):
         """igl::point_mesh_squared_distance as used at node/node.cpp:982 — points [N,K,3] vs each frame's mesh."""
         verts = self._need("verts")

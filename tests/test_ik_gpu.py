@@ -351,6 +351,25 @@ def test_ik_config2_size_256_frames_50_iterations(smpl, oracle_synth, synth_mode
         assert (e2o < 1e-3) == bool(conv_engine[f]), (f, e2o, e2[f])
 
 
+def test_ik_status_flags_visible_to_enqueue_only_callers(smpl, golden_ik_synth):
+    """A failed factorisation ("LLT has numerical issue!", node/node.cpp:934-937) is an error return for host-space calls; an
+    enqueue-only caller reads smplpp_ik_get_status. NaN targets make the normal equations non-finite: frame 1 must be
+    flagged (last + sticky), frame 0 not."""
+    from smplpp_amd.ik import IkSolver
+
+    g = golden_ik_synth
+    K = len(g["face_idx"])
+    s = IkSolver(smpl, 2, K)
+    tp = np.tile(g["target_pos"], (2, 1, 1)).astype(np.float32)
+    tp[1, 0, 0] = np.nan
+    s.setTasks(face_idx=g["face_idx"], target_pos=tp, target_normal=g["target_normal"], phi_limit=np.zeros(K))
+    s.setConfig(np.zeros((2, 10), np.float32), np.tile(g["traj_theta"][0], (2, 1, 1)))
+    assert not s.getStatus().any()
+    s.iterate(1, sync=False)
+    f = s.getStatus()
+    assert f[0] == 0 and f[1] == 3, f
+
+
 def _run_ik(smpl, g, n, iters, env, monkeypatch, **kw):
     """theta / beta / faces after `iters` iterations from seeded perturbed starts under the given environment switches."""
     from smplpp_amd.ik import IkSolver
