@@ -34,8 +34,9 @@ constexpr int TD44 = SMPLPP_LATENT_POSE_DIM;  // 44
 constexpr int NQ = TD75 + NB;                 // differentiation columns handled per frame: theta(75) | beta(10)
 constexpr int IK_MAXK = 48;                   // tasks per frame supported (the reference uses at most 41: MocapBody markers)
 constexpr int MAXADJ = 12;                    // adjacent faces per vertex supported by the normal Jacobian
+constexpr size_t SOLVE_LDS_MAX = 160 * 1024 - 512; // dynamic LDS the solve kernels may ask for (160 KiB per CU, minus their static LDS)
 constexpr int MAXRING = 3 * (MAXADJ + 1) + 1; // distinct vertices a task can touch
-constexpr int MAXD = 170;                     // unknowns per frame supported by the in-LDS solver
+constexpr int MAXD = TD75 + 2 * IK_MAXK + NB;  // 181: unknowns per frame supported by the in-LDS solver (every task count up to IK_MAXK, beta included)
 
 struct TaskArrays
 {
@@ -1536,7 +1537,10 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
 // theta is always free, so the free set never shrinks below the residual rows). It does not carry the register-tiled
 // primal factorisation, which is what sizes the general kernel's register file footprint (247 of the SIMD's 512
 // registers per lane: the face scan that runs beside the solve then keeps one wavefront per SIMD instead of three).
-template<bool DUAL_ONLY>
+// NTR: tiles of 16 the register-tiled primal factorisation covers (free unknowns + 1 <= 16 NTR): 6 for every mode but the
+// 41-marker body solve (phi and beta live: 167 free unknowns), which gets its own instantiation with 11 — a second tile
+// count inside one instantiation slowed the common path by 16 us (its register file footprint).
+template<bool DUAL_ONLY, int NTR = 6>
 __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const double * __restrict__ e_all, const double * __restrict__ J_all,
                                                        float * __restrict__ theta, float * __restrict__ beta, float * __restrict__ pts,
                                                        int K, int theta_dim, int beta_dim, int phi_live, int enable_qp, int use_prior,
@@ -1557,8 +1561,8 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   double * lo = bpri + D;
   double * hi = lo + D;
   double * rowv = hi + D;
-  double * lraw = rowv + rows; // [2][2][96] published column pairs of the register-tiled factorisation
-  double * ldiag = lraw + 384; // [4] (spare)
+  double * lraw = rowv + rows; // [2][2][16 NTR] published column pairs of the register-tiled factorisation
+  double * ldiag = lraw + 64 * NTR; // [4] (spare)
   double * dinv = ldiag + 4;   // [D] reciprocal pivots for the back substitution
   int * idx = reinterpret_cast<int *>(dinv + D);
   int * state = idx + D; // 0 free, -1 at lo, +1 at hi, 2 pinned (empty box)
@@ -1723,11 +1727,11 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     else if constexpr(DUAL_ONLY)
     {
     }
-    else if(nf + 1 <= 96)
+    else if(nf + 1 <= 16 * NTR)
     {
-      // small systems (every mode except the 41-marker body solve): registers, one barrier per column
+      // registers, one barrier per column
       __syncthreads();
-      build_and_factor_reg<6>(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, chunk_rows, lraw, ldiag, dinv, &s_bad, dbg_stop);
+      build_and_factor_reg<NTR>(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, chunk_rows, lraw, ldiag, dinv, &s_bad, dbg_stop);
       if(dbg_stop == 4) return;
     }
     else
@@ -2269,7 +2273,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   if(m->V > 65535) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: at most 65535 vertices are supported (ring tables hold 16-bit ids)");
   if(K > PROJ_MAXK) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: at most 48 tasks per frame are supported");
   if(TD75 + 2 * K + NB > MAXD)
-    return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: too many tasks for the in-LDS solver (75 + 2K + 10 must be <= 170)");
+    return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: too many tasks for the in-LDS solver (75 + 2K + 10 must be <= 181)");
   int maxadj = 0;
   for(int64_t v = 0; v < m->V; v++) maxadj = std::max(maxadj, (int)(m->h_adjOff[v + 1] - m->h_adjOff[v]));
   if(maxadj > MAXADJ) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: a vertex has more than 12 adjacent faces");
@@ -2543,9 +2547,10 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
   int rc = SMPLPP_OK;
   smplpp_model * m = s->m;
   const int K = (int)s->K;
-  static PerDeviceOnce once_solve[2];
-  HIP_TRY(lds_opt_in(once_solve[0], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false>), 152 * 1024));
-  HIP_TRY(lds_opt_in(once_solve[1], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<true>), 152 * 1024));
+  static PerDeviceOnce once_solve[3];
+  HIP_TRY(lds_opt_in(once_solve[0], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false>), (int)SOLVE_LDS_MAX));
+  HIP_TRY(lds_opt_in(once_solve[1], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<true>), (int)SOLVE_LDS_MAX));
+  HIP_TRY(lds_opt_in(once_solve[2], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false, 11>), (int)SOLVE_LDS_MAX));
   const bool dbg = s->dbg_sync;
   const int dbg_stop = s->dbg_stop;
   const bool overlap_ok = s->overlap_ok;
@@ -2573,8 +2578,9 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
     // the packed system is sized for the unknowns that CAN be free: a pinned phi (zero limit, node.cpp:567,699) never is,
     // which leaves 75 of the 157 unknowns of a 41-marker motion solve and room for its 164 Jacobian rows in two chunks
     const int m_dim = D - ((!phi_live || s->phi_locked) ? 2 * K : 0);
-    const size_t fixed = sizeof(double) * ((size_t)(m_dim + 1) * (m_dim + 2) / 2 + 7 * (size_t)D + 2 * (size_t)rows + 388) + sizeof(int) * 2 * (size_t)D;
-    const size_t budget = 150 * 1024;
+    const int ntr = (m_dim + 1 <= 96 || m_dim + 1 > 176) ? 6 : 11; // tiles of the register-tiled factorisation (176 < m_dim + 1: all-LDS path)
+    const size_t fixed = sizeof(double) * ((size_t)(m_dim + 1) * (m_dim + 2) / 2 + 7 * (size_t)D + 2 * (size_t)rows + 64 * (size_t)ntr + 4) + sizeof(int) * 2 * (size_t)D;
+    const size_t budget = SOLVE_LDS_MAX;
     int chunk_rows = (int)((budget - fixed) / (sizeof(double) * (size_t)D));
     if(chunk_rows > rows) chunk_rows = rows;
     if(chunk_rows < 4) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_iterate: system too large for the in-LDS solver");
@@ -2585,11 +2591,17 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
 #define SOLVE_(DO) ik_solve_kernel<DO><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
     s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
     s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim)
+#define SOLVE11_() ik_solve_kernel<false, 11><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
+    s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
+    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim)
     if(dual_only)
       SOLVE_(true);
+    else if(ntr == 11)
+      SOLVE11_();
     else
       SOLVE_(false);
 #undef SOLVE_
+#undef SOLVE11_
     HIP_TRY(hipGetLastError());
     DBG_SYNC("solve");
     {

@@ -11,6 +11,8 @@
   0..31), then exactly ONE IK iteration per C3D frame, warm-started;
   missing markers get posTaskWeight_ = 0 (:674-683); frames with fewer than K/2 valid markers skip the solve (:785);
   QP on, phi limits 0, normal task off, normal offset 15 mm (:316-322, :553-567, :699).
+* `MocapBodySolver` — solveMocapBody (node/node.cpp:652-656, 693-696, 1343-1352): the 51-iteration body stage that
+  produces beta and the per-marker faces / weights (MocapBody.yaml).
 * `write_motion_text` — scripts/convertRosbagToText.py:18-19 (one frame per line, theta 25x3 row-major).
 * `write_mocap_body_yaml` / `read_mocap_body_yaml` — /tmp/MocapBody.yaml of node/node.cpp:1426-1441 and :509-534.
 """
@@ -238,6 +240,58 @@ class MocapMotionSolver:
         body = self.vposer.forward(flat[:, 6:38]).reshape(-1, 63)
         th = np.concatenate([flat[:, :6], body, flat[:, 38:44]], axis=1)
         return th.reshape(g.shape[:-1] + (25, 3))
+
+
+class MocapBodySolver:
+    """solveMocapBody (node/node.cpp:652-656, 674-679, 693-696, 1343-1352, 1418-1431) for R independent restarts in lock
+    step on one GPU: 51 iterations on ONE capture frame whose markers are all present; iterations 0-24 move theta only
+    (phiLimit_ = 0), from iteration 25 on theta + phi (|phi| <= 0.04 m: the markers slide on the surface) + beta
+    (|dbeta| <= 0.5 per iteration) by box QP; marker-thickness normal offset 15 mm, normal task off (:553-562). The result
+    is what the motion stage starts from: beta and, per marker, the face and barycentric weights it ended on
+    (/tmp/MocapBody.yaml, :1418-1431)."""
+
+    ITERS = 51       # ikIter 0..50: the loop breaks at the END of pass 50 (node.cpp:1349)
+    BETA_FROM = 25   # optimizeBeta = ikIter >= 25 (:655); phiLimit_ = ikIter < 25 ? 0 : 0.04 (:695)
+    PHI_LIMIT = 0.04
+
+    def __init__(self, smpl, names: Sequence[str], restarts: int = 1, vposer=None, marker_thickness=0.015):
+        from .ik import IkSolver
+
+        self.names = sorted(names)  # std::map<std::string, IkTask> order (node.cpp:47, 798)
+        self.faces = np.array([BASELINE41[n] for n in self.names], np.int64)
+        self.K = len(self.names)
+        self.R = restarts
+        self.solver = IkSolver(smpl, restarts, self.K, vposer=vposer)
+        K = self.K
+        self.solver.setTasks(face_idx=self.faces, vertex_weights=np.full((K, 3), 1 / 3, np.float32),
+                             normal_task_weight=np.zeros(K), normal_offset=np.full(K, marker_thickness),
+                             phi_limit=np.full(K, self.PHI_LIMIT))
+
+    def solve(self, markers: np.ndarray, theta0: np.ndarray, beta0: Optional[np.ndarray] = None, iters: Optional[int] = None):
+        """markers [K,3] (or [R,K,3]) in the task order `self.names`, every one present (a missing marker is an error in
+        this stage, node.cpp:674-679); theta0 [R,25,3] (or [R,44] with a VPoser). Returns dict(beta [R,10], theta,
+        face_idx [R,K], vertex_weights [R,K,3], e_sqnorm [R])."""
+        R, K = self.R, self.K
+        m = np.asarray(markers, np.float32)
+        if m.ndim == 2:
+            m = np.broadcast_to(m, (R,) + m.shape)
+        if m.shape != (R, K, 3) or not np.isfinite(m).all():
+            raise ValueError("All mocap markers must be found to solve mocap body")  # node.cpp:677
+        # every call starts from the marker table's faces at their centroids, like a fresh run of the node
+        self.solver.setTasks(face_idx=self.faces, vertex_weights=np.full((K, 3), 1 / 3, np.float32), target_pos=np.ascontiguousarray(m),
+                             pos_task_weight=np.ones((R, K)))
+        b0 = np.zeros((R, 10), np.float32) if beta0 is None else np.broadcast_to(np.asarray(beta0, np.float32), (R, 10)).copy()
+        self.solver.setConfig(b0, theta0)
+        e2 = self.solver.iterate(self.ITERS if iters is None else iters, enable_qp=True, optimize_beta_from=self.BETA_FROM)
+        beta, theta = self.solver.getConfig()
+        t = self.solver.getTasks()
+        return dict(beta=beta, theta=theta, face_idx=t["face_idx"], vertex_weights=t["vertex_weights"], e_sqnorm=e2)
+
+    def write_yaml(self, path: str, result: dict, restart: Optional[int] = None) -> int:
+        """MocapBody.yaml (node.cpp:1418-1431) of one restart (default: the one with the smallest final residual)."""
+        r = int(np.argmin(result["e_sqnorm"])) if restart is None else int(restart)
+        write_mocap_body_yaml(path, result["beta"][r], self.names, result["face_idx"][r], result["vertex_weights"][r])
+        return r
 
 
 # ------------------------------------------------------------------------------------------------ result files

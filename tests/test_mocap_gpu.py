@@ -231,3 +231,98 @@ def test_capture_fit_two_stream_schedule_is_bit_identical(smpl, synth_model, mon
         out.append((th, ms.solver.getTasks()["face_idx"], ms.solver.getTasks()["vertex_weights"]))
     for x, y in zip(out[0], out[1]):
         assert np.array_equal(x, y)
+
+
+def test_body_stage_end_to_end(smpl, oracle_synth, synth_model, tmp_path):
+    """MoSh stage 1 (solveMocapBody, node/node.cpp:652-656, 693-696, 909-930, 1343-1352, 1418-1431): 41 markers placed on a
+    hidden body (hidden beta and pose, 15 mm off the surface, off-centre on their faces), 51 iterations from beta = 0 and a
+    perturbed pose: theta only for 25 iterations, then theta + phi (|phi| <= 0.04) + beta (|dbeta| <= 0.5) by box QP with
+    167 free unknowns (the register-tiled 11-tile factorisation). Checked: the schedule (beta frozen before iteration 25,
+    steps bounded after), convergence towards the hidden shape, step-by-step parity with the oracle from synchronised
+    states across the 24 -> 25 switch, and the MocapBody.yaml round trip into the motion stage."""
+    from oracle import cpu
+    from smplpp_amd import mocap
+    from smplpp_amd.ik import IkSolver
+
+    names = sorted(mocap.BASELINE41)
+    K = len(names)
+    rng = np.random.default_rng(31)
+    beta_h = rng.normal(0, 0.8, 10).astype(np.float32)
+    theta_h = np.zeros((25, 3), np.float32)
+    theta_h[1:] = rng.normal(0, 0.15, (24, 3))
+    theta_h[0] = [0.1, -0.2, 0.9]
+    faces = np.array([mocap.BASELINE41[n] for n in names], np.int64)
+    bary = rng.dirichlet(np.ones(3) * 4, K).astype(np.float32)
+    hid = IkSolver(smpl, 1, K)
+    hid.setTasks(face_idx=faces, vertex_weights=bary, target_pos=np.zeros((K, 3), np.float32), normal_offset=np.full(K, 0.015),
+                 normal_task_weight=np.zeros(K), phi_limit=np.zeros(K))
+    hid.setConfig(beta_h[None], theta_h[None])
+    hid.eval()
+    markers = hid.getTasks()["actual_pos"][0].copy()  # surface point + 15 mm along the interpolated normal (src/IkTask.cpp:60-72)
+    R = 2
+    theta0 = np.tile(theta_h, (R, 1, 1)) + rng.normal(0, 0.03, (R, 25, 3)).astype(np.float32)
+    bs = mocap.MocapBodySolver(smpl, names, restarts=R)
+    assert bs.names == names and (bs.faces == faces).all()
+    # ---- schedule, through the driver's own solver, one iteration at a time with the driver's switches
+    bs.solver.setTasks(target_pos=np.broadcast_to(markers, (R, K, 3)).copy(), pos_task_weight=np.ones((R, K)))
+    bs.solver.setConfig(np.zeros((R, 10), np.float32), theta0)
+    f0 = synth_model["face_indices"].astype(np.int64) - 1
+    e_hist, prev_beta = [], np.zeros((R, 10), np.float32)
+    for it in range(mocap.MocapBodySolver.ITERS):
+        live = it >= mocap.MocapBodySolver.BETA_FROM
+        check = it in (0, 24, 25, 26, 40, 50)
+        if check:
+            st = bs.solver.getTasks()
+            gb, gt = bs.solver.getConfig()
+        e2 = bs.solver.iterate(1, enable_qp=True, optimize_beta_from=(0 if live else 1000))
+        nb, nt = bs.solver.getConfig()
+        e_hist.append(e2.copy())
+        if not live:
+            assert np.abs(nb).max() == 0, it  # beta frozen (node.cpp:655)
+        else:
+            assert np.abs(nb - prev_beta).max() <= 0.5 + 1e-6, it  # :925
+        prev_beta = nb.copy()
+        if check:
+            ts = cpu.TaskSet(st["face_idx"][0], markers, phi_limit=np.full(K, 0.04), normal_offset=np.full(K, 0.015),
+                             normal_task_weight=np.zeros(K), vertex_weights=st["vertex_weights"][0])
+            ob, oth, oe2 = oracle_synth.ik_solve(gb[0], gt[0], ts, 1, enable_qp=True, optimize_beta_from=(0 if live else 1000))
+            assert np.abs(nt[0] - oth).max() < 5e-5, it
+            assert np.abs(nb[0] - ob).max() < 5e-5, it
+            assert abs(oe2 - e2[0]) < 2e-5 * max(1.0, oe2), it
+            st2 = bs.solver.getTasks()
+            verts = bs.solver.getVertices()[0]
+            p_gpu = np.einsum("ki,kix->kx", st2["vertex_weights"][0], verts[f0[st2["face_idx"][0]]])
+            p_ora = np.einsum("ki,kix->kx", ts.vertex_weights, verts[f0[ts.face_idx]])
+            assert np.abs(p_gpu - p_ora).max() < 5e-5, it  # same surface point, whichever incident face is named (ties)
+    e_hist = np.array(e_hist)
+    assert (e_hist[-1] < e_hist[24]).all() and (e_hist[24] < e_hist[0]).all()  # both stages reduce the residual
+    # (the synthetic model's shape basis moves the surface by millimetres while the markers may slide by 4 cm: beta is
+    # weakly observed here, so only its activity is checked; the step-by-step parity above is the correctness check)
+    assert (np.abs(prev_beta).max(axis=1) > 1e-3).all()
+    # ---- the driver call itself reproduces that trajectory, and its output feeds the motion stage
+    res = bs.solve(markers, theta0)
+    assert np.array_equal(res["beta"], prev_beta) and res["face_idx"].shape == (R, K) and np.isfinite(res["theta"]).all()
+    y = str(tmp_path / "MocapBody.yaml")
+    r = bs.write_yaml(y, res)
+    beta_y, names_y, faces_y, w_y = mocap.read_mocap_body_yaml(y)
+    assert names_y == names and (faces_y == res["face_idx"][r]).all() and np.abs(beta_y - res["beta"][r]).max() < 1e-6
+    ms = mocap.MocapMotionSolver(smpl, faces_y, w_y, restarts=1)
+    th, frames = ms.solve(markers[None], np.ones((1, K), bool), beta_y, res["theta"][r][None].reshape(1, 25, 3))
+    assert np.isfinite(th).all() and len(frames) == 1
+
+
+def test_ik_task_count_limit_is_48_with_beta(smpl):
+    """The in-LDS solver takes every task count up to IK_MAXK = 48 with phi and beta live (D = 75 + 96 + 10 = 181)."""
+    from smplpp_amd.ik import IkSolver
+
+    K = 48
+    rng = np.random.default_rng(1)
+    s = IkSolver(smpl, 1, K)
+    s.setTasks(face_idx=rng.integers(0, 13776, K), target_pos=rng.normal(0, 0.4, (K, 3)).astype(np.float32), phi_limit=np.full(K, 0.04),
+               normal_task_weight=np.zeros(K))
+    s.setConfig(np.zeros((1, 10), np.float32), np.zeros((1, 25, 3), np.float32))
+    e2a = s.iterate(1, enable_qp=True, optimize_beta_from=0)
+    e2b = s.iterate(3, enable_qp=True, optimize_beta_from=0)
+    assert np.isfinite(e2a).all() and np.isfinite(e2b).all() and e2b[0] < e2a[0]
+    with pytest.raises(Exception):
+        IkSolver(smpl, 1, 49)
