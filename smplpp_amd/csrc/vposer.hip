@@ -10,11 +10,16 @@
 #include "staging.h"
 
 #include <cfloat>
+#include <cmath>
+#include <vector>
 
 struct smplpp_vposer
 {
   int device = 0;
   float *w0t = nullptr, *b0 = nullptr, *w1t = nullptr, *b1 = nullptr, *w2t = nullptr, *b2 = nullptr;
+  // layers 1 and 2 once more as fp16x2 pieces in MFMA fragment order (the A operand of the tangent GEMMs, layout below)
+  uint8_t *w1h = nullptr, *w2h = nullptr;
+  float sW1 = 1.f, sW2 = 1.f, sD1 = 1.f, sD2 = 1.f; // power-of-two scales: weights of layers 1 / 2, tangent blocks of layers 0 / 1
 };
 
 namespace smplpp_hip
@@ -197,16 +202,15 @@ __device__ inline void sixd_to_aa(const float * o6, float * aa_out, float * jac3
   }
 }
 
-// grid = n frames, block = 256.  LDS: a1/D1 then a2/D2, [512][VS] floats each (33 used: 32 tangent columns + the
-// activation in column 32; the stride VS = 36 keeps every row 16-byte aligned so a row is read with nine ds_read_b128 —
-// every lane reads the same row (broadcast), and 33 scalar LDS reads per k made the LDS issue slots the bottleneck);
-// the layer-2 output [126][33] reuses the a1/D1 region.
+// Value-only forward (no Jacobian: decoding a stored latent, node/node.cpp:1376-1391): grid = n frames, block = 256, exact
+// fp32 on the VALU.  LDS: activations of layers 0 / 1 in column 32 of [512][VS] rows (the layout the first Jacobian form
+// shared), the layer-2 output [126][33] reuses the first region.
 constexpr int VS = 36;
 __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ z, int64_t z_stride, const float * __restrict__ w0t,
                                                      const float * __restrict__ b0, const float * __restrict__ w1t,
                                                      const float * __restrict__ b1, const float * __restrict__ w2t,
                                                      const float * __restrict__ b2, float * __restrict__ out, int64_t out_stride,
-                                                     float * __restrict__ jac, int want_jac)
+                                                     float * __restrict__ /*unused*/, int /*unused*/)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float * L1 = lds;                  // [512][VS]
@@ -225,16 +229,9 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
     for(int c = 0; c < LAT; c++) h += w0t[c * HID + row] * sz[c];
     const float slope = (h > 0.0f) ? 1.0f : 0.01f;
     L1[row * VS + 32] = h * slope;
-    for(int c = 0; c < LAT; c++) L1[row * VS + c] = slope * w0t[c * HID + row];
   }
   __syncthreads();
-  // layer 1 (+ LeakyReLU).  The activation column is a matrix-vector product on the VALU (two rows per thread); the 32
-  // tangent columns are a [512 x 512] . [512 x 32] GEMM on v_mfma_f32_32x32x2_f32 (exact fp32): wavefront w owns the four
-  // 32-row tiles 4w..4w+3, lane l feeds A[row = l % 32][k = l / 32] = W1[row][k] (K-major weights: coalesced) and
-  // B[k = l / 32][col = l % 32] = D1[k][col] from LDS, weights prefetched eight k ahead.
-  // With a Jacobian the activation column rides in the tangent loop below instead (same weights, VALU work in the MFMA
-  // shadows); both forms sum the even and the odd k separately and add the halves (they agree to the last bits: 4e-8 rad).
-  if(!want_jac)
+  // layer 1 (+ LeakyReLU): a matrix-vector product on the VALU, two rows per thread, even and odd k summed separately
   {
     const int r0 = tid, r1 = tid + 256;
     float h0 = 0.f, h1 = 0.f, h0o = 0.f, h1o = 0.f;
@@ -279,71 +276,9 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
     sSlope[r0] = s0;
     sSlope[r1] = s1;
   }
-  if(want_jac)
-  {
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
-    const int wave = tid >> 6, l = tid & 63, l31 = l & 31, lh = l >> 5;
-    f32x16 acc[4];
-    float hq[4] = {0.f, 0.f, 0.f, 0.f}; // activation of row 32 (4 wave + t) + l31 over this lane's k parity (lh)
-#pragma unroll
-    for(int t = 0; t < 4; t++)
-#pragma unroll
-      for(int r = 0; r < 16; r++) acc[t][r] = 0.0f;
-    constexpr int KU = 8; // k-steps of 2 per batch
-    float wq[KU][4], wn[KU][4];
-#pragma unroll
-    for(int u = 0; u < KU; u++)
-#pragma unroll
-      for(int t = 0; t < 4; t++) wq[u][t] = w1t[(2 * u + lh) * HID + 32 * (4 * wave + t) + l31];
-    for(int k2 = 0; k2 < HID / 2; k2 += KU)
-    {
-      const int kn = (k2 + KU < HID / 2) ? k2 + KU : k2;
-#pragma unroll
-      for(int u = 0; u < KU; u++)
-#pragma unroll
-        for(int t = 0; t < 4; t++) wn[u][t] = w1t[(2 * (kn + u) + lh) * HID + 32 * (4 * wave + t) + l31];
-#pragma unroll
-      for(int u = 0; u < KU; u++)
-      {
-        const float bv = L1[(2 * (k2 + u) + lh) * VS + l31], av = L1[(2 * (k2 + u) + lh) * VS + 32];
-#pragma unroll
-        for(int t = 0; t < 4; t++)
-        {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[u][t], bv, acc[t], 0, 0, 0);
-          hq[t] += wq[u][t] * av;
-        }
-      }
-#pragma unroll
-      for(int u = 0; u < KU; u++)
-#pragma unroll
-        for(int t = 0; t < 4; t++) wq[u][t] = wn[u][t];
-    }
-#pragma unroll
-    for(int t = 0; t < 4; t++)
-    {
-      const int row = 32 * (4 * wave + t) + l31;
-      const float ho = __shfl_xor(hq[t], 32, 64); // the other k parity of the same row
-      const float h = ((lh ? ho + hq[t] : hq[t] + ho)) + b1[row]; // (even + odd) + bias, like the VALU form
-      const float sl = (h > 0.0f) ? 1.0f : 0.01f;
-      if(lh == 0)
-      {
-        L2[row * VS + 32] = h * sl;
-        sSlope[row] = sl;
-      }
-    }
-    __syncthreads(); // slopes are in LDS
-#pragma unroll
-    for(int t = 0; t < 4; t++)
-#pragma unroll
-      for(int r = 0; r < 16; r++)
-      {
-        const int row = 32 * (4 * wave + t) + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        L2[row * VS + l31] = sSlope[row] * acc[t][r];
-      }
-  }
   __syncthreads();
-  // layer 2: 126 rows (activation column on the VALU, tangents on the matrix pipe: wavefront w owns rows 32w..32w+31)
-  if(!want_jac && tid < OUT6)
+  // layer 2: 126 rows
+  if(tid < OUT6)
   {
     float h = 0.f, ho = 0.f;
     constexpr int KU = 16;
@@ -366,75 +301,342 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
     }
     so[tid * 33 + 32] = (h + ho) + b2[tid];
   }
-  if(want_jac)
+  __syncthreads();
+  // rotation tail: 6D -> axis-angle and its 3 x 6 Jacobian, one thread per joint; the chain rule into the 32 latent columns
+  // (63 x 32 entries, six terms each) by all threads, coalesced over the columns
+  if(tid < 21)
   {
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
-    const int wave = tid >> 6, l = tid & 63, l31 = l & 31, lh = l >> 5;
-    const int arow = 32 * wave + l31;
-    const bool alive = arow < OUT6;
-    const int acol = alive ? arow : 0;
-    f32x16 acc;
-    float hq = 0.f; // activation of row arow over this lane's k parity
+    float o6[6], aa[3];
+    for(int q = 0; q < 6; q++) o6[q] = so[(tid * 6 + q) * 33 + 32];
+    sixd_to_aa(o6, aa, nullptr);
+    for(int i = 0; i < 3; i++) out[f * out_stride + tid * 3 + i] = aa[i];
+  }
+}
+
+// ---- forward + Jacobian on the f16 matrix pipe.
+// d(out)/dz is carried through the MLP as 32 tangent columns per row.  Layer 1: [512 x 512] . [512 x 32], layer 2:
+// [126 x 512] . [512 x 32] per frame: v_mfma_f32_32x32x16_f16 with every fp32 operand as two fp16 pieces of a power-of-two
+// multiple (common.h, "fp16x2": 22 significant bits, three products hi.hi + hi.lo + lo.hi) — 96 MFMAs of 32 cycles per
+// 32-row tile where the exact-fp32 form (v_mfma_f32_32x32x2_f32, 1/16 of the rate) took 256 of 64.
+//   A operand: the weights, split once at creation, in fragment order: w1h [16 row tiles][32 k-steps][piece 2][64 lanes][8 fp16]
+//              (lane 32 h + r holds W[32 tile + r][16 ks + 8 h + j], j = 0..7), straight from L2 to registers;
+//   B operand: the tangent block of the previous layer, written to LDS in fragment order by its producer:
+//              Df [32 k-steps][piece 2][64 lanes (32 h + column)][8 fp16].
+// The VALUE path (activations) rides on the same weight fragments: the lane that feeds W[row][8 k's] to the MFMA also
+// takes their dot product with the previous layer's activations (fp16x2 pieces too, per-frame power-of-two scale) by
+// v_dot2_f32_f16, three products per pair like the MFMAs, fp32 accumulate — no second (fp32) stream of the weights, which
+// at 1 MB per layer and frame was what the kernel waited for.  Values carry 22-bit operands: 1e-6 relative to the fp32
+// VALU form of the value-only kernel.
+// LDS: D1f 64 KiB | D2f 64 KiB | a2, slope1 [512 each] fp32 | activation fragments Af [32 k-steps][piece 2][h 2][8 fp16] | z, scratch;
+// the layer-2 output so [126][33] reuses D1f, the rotation tail's 3 x 6 blocks reuse D2f.
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+typedef float v4fv __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+constexpr int VJ_DF = 32 * 2 * 1024; // bytes of one tangent block in fragment order
+constexpr int VJ_AF = 32 * 2 * 2 * 16; // bytes of one activation vector in fragment order
+constexpr int VJ_LDS = 2 * VJ_DF + 2 * HID * 4 + VJ_AF + (LAT + 16) * 4;
+
+__device__ __forceinline__ f32x16v vmfma(const v4fv & a, const v4fv & b, const f32x16v & c)
+{
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), c, 0, 0, 0);
+}
+// dot product of 8 fp16 pairs (one MFMA fragment against the matching activation fragment), fp32 accumulate
+__device__ __forceinline__ float vdot8(const v4fv & w, const v4fv & a, float c)
+{
+  // (explicit element pairs: hipcc folded `bit_cast<half2>(w[q])` inside an unrolled loop over q to element 0 for every q)
+  const f16x8v wv = __builtin_bit_cast(f16x8v, w), av = __builtin_bit_cast(f16x8v, a);
+  c = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 0, 1), __builtin_shufflevector(av, av, 0, 1), c, false);
+  c = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 2, 3), __builtin_shufflevector(av, av, 2, 3), c, false);
+  c = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 4, 5), __builtin_shufflevector(av, av, 4, 5), c, false);
+  c = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 6, 7), __builtin_shufflevector(av, av, 6, 7), c, false);
+  return c;
+}
+// per-frame power-of-two scale that puts max|v| of a 512-vector (two entries per thread) just under 2^14; red: [5] floats of LDS
+__device__ __forceinline__ float vscale512(float v0, float v1, float * red)
+{
+  float m = fmaxf(fabsf(v0), fabsf(v1));
+  for(int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  return exp2f(floorf(log2f(16384.0f / fmaxf(m, 1e-30f))));
+}
+// entry k of an activation vector into fragment order: k-step k / 16, half (k % 16) / 8, element k % 8
+__device__ __forceinline__ void vput_act(unsigned char * Af, int k, float scaled)
+{
+  _Float16 hi, lo;
+  split_f16x2(scaled, hi, lo);
+  _Float16 * p = reinterpret_cast<_Float16 *>(Af + (k >> 4) * 64 + ((k >> 3) & 1) * 16) + (k & 7);
+  p[0] = hi;
+  p[16] = lo; // piece 1: + 32 bytes
+}
+
+#ifdef VPJ_STAMP
+__device__ unsigned long long g_vpj_stamps[16];
+#define VPJ_T(i) if(blockIdx.x == 0 && threadIdx.x == 0) g_vpj_stamps[i] = __builtin_amdgcn_s_memtime()
+extern "C" int smplpp_debug_vpj_stamps(unsigned long long * out)
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vpj_stamps), sizeof(unsigned long long) * 16);
+}
+#else
+#define VPJ_T(i)
+#endif
+__global__ __launch_bounds__(256) void vposer_jac_kernel(const float * __restrict__ z, int64_t z_stride, const float * __restrict__ w0t,
+                                                         const float * __restrict__ b0, const float * __restrict__ b1,
+                                                         const float * __restrict__ b2, const uint8_t * __restrict__ w1h,
+                                                         const uint8_t * __restrict__ w2h, float sD1, float sD2, float iW1, float iW2,
+                                                         float * __restrict__ out, int64_t out_stride, float * __restrict__ jac)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char vl[];
+  unsigned char * D1f = vl;
+  unsigned char * D2f = vl + VJ_DF;
+  float * a2 = reinterpret_cast<float *>(vl + 2 * VJ_DF);   // [512] layer-1 activations (fp32)
+  float * sl1 = a2 + HID;                                    // [512] LeakyReLU slopes of layer 1
+  unsigned char * Af = reinterpret_cast<unsigned char *>(sl1 + HID); // activation fragments of the layer being consumed
+  float * sz = reinterpret_cast<float *>(Af + VJ_AF);       // [32]
+  float * red = sz + LAT;                                    // [16] scratch of the scale reductions
+  float * so = reinterpret_cast<float *>(D1f);               // [126][33] layer-2 output (D1f is dead by then)
+  const int64_t f = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, l31 = l & 31, lh = l >> 5;
+  VPJ_T(0);
+  // ---- layer 0 (+ LeakyReLU 0.01), rows tid and tid + 256: all 64 weights of the two rows in flight at once
+  float w0a[LAT], w0b[LAT];
+#pragma unroll
+  for(int c = 0; c < LAT; c++)
+  {
+    w0a[c] = w0t[c * HID + tid];
+    w0b[c] = w0t[c * HID + tid + 256];
+  }
+  if(tid < LAT) sz[tid] = z[f * z_stride + tid];
+  __syncthreads();
+  float h0 = b0[tid], h1 = b0[tid + 256];
+#pragma unroll
+  for(int c = 0; c < LAT; c++)
+  {
+    h0 += w0a[c] * sz[c];
+    h1 += w0b[c] * sz[c];
+  }
+  const float s00 = (h0 > 0.0f) ? 1.0f : 0.01f, s01 = (h1 > 0.0f) ? 1.0f : 0.01f;
+  h0 *= s00;
+  h1 *= s01;
+  {
+    // tangent block D1[row][c] = slope . W0[row][c] into fragment order: element (k = row, column c) sits in k-step row / 16,
+    // lane 32 ((row % 16) / 8) + c, element row % 8
+#pragma unroll
+    for(int rr = 0; rr < 2; rr++)
+    {
+      const int row = tid + 256 * rr;
+      const float sl = (rr ? s01 : s00) * sD1;
+      _Float16 * base = reinterpret_cast<_Float16 *>(D1f + (row >> 4) * 2048 + ((row >> 3) & 1) * 512) + (row & 7);
+#pragma unroll
+      for(int c = 0; c < LAT; c++)
+      {
+        _Float16 hi, lo;
+        split_f16x2(sl * (rr ? w0b[c] : w0a[c]), hi, lo);
+        base[c * 8] = hi;
+        base[512 + c * 8] = lo;
+      }
+    }
+  }
+  const float sA1 = vscale512(h0, h1, red);
+  vput_act(Af, tid, h0 * sA1);
+  vput_act(Af, tid + 256, h1 * sA1);
+  __syncthreads();
+  VPJ_T(1);
+  // ---- layer 1: wavefront w owns the row tiles 4w .. 4w + 3; per k-step 2 B fragments + 2 activation fragments from LDS (shared by
+  // the four tiles) and 8 A fragments from L2, prefetched three k-steps ahead; 12 MFMAs + 48 v_dot2
+  {
+    f32x16v acc[4];
+    float hq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for(int t = 0; t < 4; t++)
+#pragma unroll
+      for(int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+    const uint8_t * ap = w1h + (size_t)(4 * wave) * (32 * 2048) + l * 16;
+    // A fragments three k-steps ahead in a ring of four register stages (the loop is unrolled by four: static stage indices);
+    // one k-step of lead left the loop waiting ~900 cycles per step for L2
+    v4fv st[4][4][2];
+    auto load_stage = [&](int sidx, int ks) {
+#pragma unroll
+      for(int t = 0; t < 4; t++)
+#pragma unroll
+        for(int p = 0; p < 2; p++) st[sidx][t][p] = *reinterpret_cast<const v4fv *>(ap + (size_t)t * (32 * 2048) + ks * 2048 + p * 1024);
+    };
+    load_stage(0, 0);
+    load_stage(1, 1);
+    load_stage(2, 2);
+    for(int k4 = 0; k4 < 32; k4 += 4)
+    {
+#pragma unroll
+      for(int u = 0; u < 4; u++)
+      {
+        const int ks = k4 + u;
+        load_stage((u + 3) & 3, ks + 3 < 32 ? ks + 3 : 31);
+        const v4fv bh = *reinterpret_cast<const v4fv *>(D1f + ks * 2048 + l * 16);
+        const v4fv bl = *reinterpret_cast<const v4fv *>(D1f + ks * 2048 + 1024 + l * 16);
+        const v4fv ah = *reinterpret_cast<const v4fv *>(Af + ks * 64 + lh * 16);
+        const v4fv al = *reinterpret_cast<const v4fv *>(Af + ks * 64 + 32 + lh * 16);
+#pragma unroll
+        for(int t = 0; t < 4; t++)
+        {
+          acc[t] = vmfma(st[u][t][0], bh, acc[t]);
+          acc[t] = vmfma(st[u][t][0], bl, acc[t]);
+          acc[t] = vmfma(st[u][t][1], bh, acc[t]);
+          hq[t] = vdot8(st[u][t][1], ah, hq[t]);
+          hq[t] = vdot8(st[u][t][0], al, hq[t]);
+          hq[t] = vdot8(st[u][t][0], ah, hq[t]);
+        }
+      }
+    }
+    VPJ_T(2);
+    // activations of this wavefront's 128 rows: the two k halves of a row meet through one shuffle
+    const float iv = iW1 / sA1;
+    float hv[4], sv[4];
+#pragma unroll
+    for(int t = 0; t < 4; t++)
+    {
+      const int row = 32 * (4 * wave + t) + l31;
+      const float h = (hq[t] + __shfl_xor(hq[t], 32, 64)) * iv + b1[row];
+      sv[t] = (h > 0.0f) ? 1.0f : 0.01f;
+      hv[t] = h * sv[t];
+      if(lh == 0)
+      {
+        a2[row] = hv[t];
+        sl1[row] = sv[t];
+      }
+    }
+    __syncthreads(); // slopes and activations of layer 1 are in LDS; every wavefront is done with D1f and Af
+#ifdef VPJ_DUMP
+    jac[f * 63 * LAT + tid] = a2[tid];
+    jac[f * 63 * LAT + tid + 256] = a2[tid + 256];
+    if(wave == 0) jac[f * 63 * LAT + 512 + l] = hq[0] * iv;
+    if(wave == 0) jac[f * 63 * LAT + 576 + l] = (float)reinterpret_cast<const _Float16 *>(Af)[l] / sA1; // Af of k-step 0 and 1: hi(h0) hi(h1) lo(h0) lo(h1)
+    return;
+#endif
+    const float sA2 = vscale512(a2[tid], a2[tid + 256], red);
+    vput_act(Af, tid, a2[tid] * sA2);
+    vput_act(Af, tid + 256, a2[tid + 256] * sA2);
+    red[8] = sA2; // (every thread writes the same value)
+    // D2[row][col] = slope1[row] . (W1 . D1)[row][col]: this lane holds column l31 and, per tile, the rows (r & 3) + 8 (r >> 2) + 4 lh.
+    // As the B operand of layer 2 (k = row): the four rows of a register group g = r >> 2 are elements j = 4 lh .. 4 lh + 3 of
+    // lane 32 (g & 1) + column in k-step 2 tile + (g >> 1): one 8-byte store per piece.
+    const float un = iW1 / sD1 * sD2;
+#pragma unroll
+    for(int t = 0; t < 4; t++)
+#pragma unroll
+      for(int g = 0; g < 4; g++)
+      {
+        const int tile = 4 * wave + t, row0 = 32 * tile + 8 * g + 4 * lh;
+        f16x4v hi, lo;
+#pragma unroll
+        for(int i = 0; i < 4; i++)
+        {
+          _Float16 a, b;
+          split_f16x2(sl1[row0 + i] * acc[t][4 * g + i] * un, a, b);
+          hi[i] = a;
+          lo[i] = b;
+        }
+        unsigned char * dst = D2f + (2 * tile + (g >> 1)) * 2048 + (32 * (g & 1) + l31) * 16 + 8 * lh;
+        *reinterpret_cast<f16x4v *>(dst) = hi;
+        *reinterpret_cast<f16x4v *>(dst + 1024) = lo;
+      }
+  }
+  __syncthreads();
+  VPJ_T(3);
+  // ---- layer 2: wavefront w owns rows 32 w .. 32 w + 31 (126 live); tangents on the MFMA, activations by v_dot2 on the same fragments
+  {
+    const float sA2 = red[8];
+    f32x16v acc;
+    float hq = 0.f;
 #pragma unroll
     for(int r = 0; r < 16; r++) acc[r] = 0.0f;
-    constexpr int KU = 8;
-    float wq[KU], wn[KU];
+    const uint8_t * ap = w2h + (size_t)wave * (32 * 2048) + l * 16;
+    v4fv st[4][2];
 #pragma unroll
-    for(int u = 0; u < KU; u++) wq[u] = alive ? w2t[(2 * u + lh) * OUT6 + acol] : 0.0f;
-    for(int k2 = 0; k2 < HID / 2; k2 += KU)
+    for(int q = 0; q < 3; q++)
     {
-      const int kn = (k2 + KU < HID / 2) ? k2 + KU : k2;
-#pragma unroll
-      for(int u = 0; u < KU; u++)
-      {
-        const float wv = w2t[(2 * (kn + u) + lh) * OUT6 + acol];
-        wn[u] = alive ? wv : 0.0f;
-      }
-#pragma unroll
-      for(int u = 0; u < KU; u++)
-      {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[u], L2[(2 * (k2 + u) + lh) * VS + l31], acc, 0, 0, 0);
-        hq += wq[u] * L2[(2 * (k2 + u) + lh) * VS + 32];
-      }
-#pragma unroll
-      for(int u = 0; u < KU; u++) wq[u] = wn[u];
+      st[q][0] = *reinterpret_cast<const v4fv *>(ap + q * 2048);
+      st[q][1] = *reinterpret_cast<const v4fv *>(ap + q * 2048 + 1024);
     }
+    for(int k4 = 0; k4 < 32; k4 += 4)
     {
-      const float hx = __shfl_xor(hq, 32, 64);
-      const float h = (lh ? hx + hq : hq + hx) + b2[acol];
-      if(alive && lh == 0) so[arow * 33 + 32] = h;
+#pragma unroll
+      for(int u = 0; u < 4; u++)
+      {
+        const int ks = k4 + u, kn = ks + 3 < 32 ? ks + 3 : 31;
+        st[(u + 3) & 3][0] = *reinterpret_cast<const v4fv *>(ap + kn * 2048);
+        st[(u + 3) & 3][1] = *reinterpret_cast<const v4fv *>(ap + kn * 2048 + 1024);
+        const v4fv bh = *reinterpret_cast<const v4fv *>(D2f + ks * 2048 + l * 16);
+        const v4fv bl = *reinterpret_cast<const v4fv *>(D2f + ks * 2048 + 1024 + l * 16);
+        const v4fv ah = *reinterpret_cast<const v4fv *>(Af + ks * 64 + lh * 16);
+        const v4fv al = *reinterpret_cast<const v4fv *>(Af + ks * 64 + 32 + lh * 16);
+        acc = vmfma(st[u][0], bh, acc);
+        acc = vmfma(st[u][0], bl, acc);
+        acc = vmfma(st[u][1], bh, acc);
+        hq = vdot8(st[u][1], ah, hq);
+        hq = vdot8(st[u][0], al, hq);
+        hq = vdot8(st[u][0], ah, hq);
+      }
     }
+    const int arow = 32 * wave + l31;
+    const float hsum = hq + __shfl_xor(hq, 32, 64); // (so aliases D1f, whose last readers passed two barriers ago)
+    if(arow < OUT6 && lh == 0) so[arow * 33 + 32] = hsum * (iW2 / sA2) + b2[arow];
+    const float u2 = iW2 / sD2;
 #pragma unroll
     for(int r = 0; r < 16; r++)
     {
       const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if(row < OUT6) so[row * 33 + l31] = acc[r];
+      if(row < OUT6) so[row * 33 + l31] = acc[r] * u2;
     }
   }
   __syncthreads();
-  // rotation tail: 6D -> axis-angle and its 3 x 6 Jacobian, one thread per joint; the chain rule into the 32 latent columns
-  // (63 x 32 entries, six terms each) by all threads, coalesced over the columns
-  float * sj = L2; // [21][18]  (the a2/D2 region is dead once layer 2 is done)
+  VPJ_T(4);
+  // ---- rotation tail: 6D -> axis-angle and its 3 x 6 Jacobian, one thread per joint; the chain rule into the 32 latent columns
+  float * sj = reinterpret_cast<float *>(D2f); // [21][18]
   if(tid < 21)
   {
     float o6[6], aa[3], j36[18];
     for(int q = 0; q < 6; q++) o6[q] = so[(tid * 6 + q) * 33 + 32];
-    sixd_to_aa(o6, aa, want_jac ? j36 : nullptr);
+    sixd_to_aa(o6, aa, j36);
     for(int i = 0; i < 3; i++) out[f * out_stride + tid * 3 + i] = aa[i];
-    if(want_jac)
-      for(int q = 0; q < 18; q++) sj[tid * 18 + q] = j36[q];
+    for(int q = 0; q < 18; q++) sj[tid * 18 + q] = j36[q];
   }
-  if(want_jac)
+  __syncthreads();
+  VPJ_T(5);
+  for(int item = tid; item < 63 * LAT; item += 256)
   {
-    __syncthreads();
-    for(int item = tid; item < 63 * LAT; item += 256)
-    {
-      const int row = item / LAT, c = item % LAT, j = row / 3, i = row % 3;
-      float s = 0.f;
-      for(int q = 0; q < 6; q++) s += sj[j * 18 + i * 6 + q] * so[(j * 6 + q) * 33 + c];
-      jac[(f * 63 + row) * LAT + c] = s;
-    }
+    const int row = item / LAT, c = item % LAT, j = row / 3, i = row % 3;
+    float s = 0.f;
+    for(int q = 0; q < 6; q++) s += sj[j * 18 + i * 6 + q] * so[(j * 6 + q) * 33 + c];
+    jac[(f * 63 + row) * LAT + c] = s;
   }
+  VPJ_T(6);
+}
+
+// weights [out][in] -> fp16x2 pieces in MFMA fragment order: [ceil(out/32)][in/16][piece 2][64 lanes][8 fp16]
+static hipError_t upload_frag(uint8_t ** dst, const float * w, int out, int in, float scale)
+{
+  const int tiles = (out + 31) / 32, ksn = in / 16;
+  std::vector<_Float16> t((size_t)tiles * ksn * 2 * 64 * 8);
+  for(int tile = 0; tile < tiles; tile++)
+    for(int ks = 0; ks < ksn; ks++)
+      for(int lane = 0; lane < 64; lane++)
+        for(int j = 0; j < 8; j++)
+        {
+          const int row = 32 * tile + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+          const float v = row < out ? w[(size_t)row * in + k] * scale : 0.0f;
+          _Float16 hi, lo;
+          split_f16x2(v, hi, lo);
+          const size_t o = ((((size_t)tile * ksn + ks) * 2) * 64 + lane) * 8 + j;
+          t[o] = hi;
+          t[o + 64 * 8] = lo;
+        }
+  hipError_t e = hipMalloc((void **)dst, sizeof(_Float16) * t.size());
+  if(e != hipSuccess) return e;
+  return hipMemcpy(*dst, t.data(), sizeof(_Float16) * t.size(), hipMemcpyHostToDevice);
 }
 
 __global__ void rotmat_to_aa_kernel(const float * __restrict__ rot, float * __restrict__ aa_out, int64_t n)
@@ -451,11 +653,20 @@ __global__ void rotmat_to_aa_kernel(const float * __restrict__ rot, float * __re
 int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
                           float * jac, hipStream_t st)
 {
+  if(jac)
+  {
+    static PerDeviceOnce oncej;
+    HIP_TRY(lds_opt_in(oncej, v->device, reinterpret_cast<const void *>(&vposer_jac_kernel), VJ_LDS));
+    vposer_jac_kernel<<<dim3((unsigned)n), dim3(256), VJ_LDS, st>>>(z, z_stride, v->w0t, v->b0, v->b1, v->b2, v->w1h, v->w2h, v->sD1, v->sD2,
+                                                                   1.0f / v->sW1, 1.0f / v->sW2, out, out_stride, jac);
+    HIP_TRY(hipGetLastError());
+    return SMPLPP_OK;
+  }
   const size_t shmem = sizeof(float) * (size_t)(2 * HID * VS + LAT + HID);
   static PerDeviceOnce once;
   HIP_TRY(lds_opt_in(once, v->device, reinterpret_cast<const void *>(&vposer_kernel), (int)shmem));
   vposer_kernel<<<dim3((unsigned)n), dim3(256), shmem, st>>>(z, z_stride, v->w0t, v->b0, v->w1t, v->b1, v->w2t, v->b2, out, out_stride,
-                                                            jac, jac ? 1 : 0);
+                                                            nullptr, 0);
   HIP_TRY(hipGetLastError());
   return SMPLPP_OK;
 }
@@ -469,6 +680,8 @@ extern "C" int smplpp_vposer_destroy(smplpp_vposer * v)
   (void)hipSetDevice(v->device);
   for(float * p : {v->w0t, v->b0, v->w1t, v->b1, v->w2t, v->b2})
     if(p) (void)hipFree(p);
+  if(v->w1h) (void)hipFree(v->w1h);
+  if(v->w2h) (void)hipFree(v->w2h);
   delete v;
   return SMPLPP_OK;
 }
@@ -501,6 +714,28 @@ extern "C" int smplpp_vposer_create(int device, const float * w0, const float * 
   if(e == hipSuccess) e = upload_t(&v->b0, b0, 1, HID);
   if(e == hipSuccess) e = upload_t(&v->b1, b1, 1, HID);
   if(e == hipSuccess) e = upload_t(&v->b2, b2, 1, OUT6);
+  {
+    // fp16x2 operands of the tangent GEMMs: power-of-two scales that keep every piece inside fp16's range.  Weights: the
+    // largest entry just under 2^14.  Tangent blocks: |D1| <= max|W0|; |D2| <= 512 max|W1| max|W0| (every slope <= 1).
+    auto amax = [](const float * w, size_t cnt) {
+      float m = 0.0f;
+      for(size_t i = 0; i < cnt; i++) m = std::fmax(m, std::fabs(w[i]));
+      return m;
+    };
+    auto pow2_under = [](float bound, float m) { return std::exp2(std::floor(std::log2(bound / (m > 1e-30f ? m : 1e-30f)))); };
+    const float m0 = amax(w0, (size_t)HID * LAT), m1 = amax(w1, (size_t)HID * HID), m2 = amax(w2, (size_t)OUT6 * HID);
+    if(!std::isfinite(m0) || !std::isfinite(m1) || !std::isfinite(m2))
+    {
+      smplpp_vposer_destroy(v);
+      return fail(SMPLPP_ERR_INVALID, "smplpp_vposer_create: non-finite weights");
+    }
+    v->sW1 = pow2_under(16384.0f, m1);
+    v->sW2 = pow2_under(16384.0f, m2);
+    v->sD1 = pow2_under(16384.0f, m0);
+    v->sD2 = pow2_under(16384.0f, 512.0f * m1 * m0);
+    if(e == hipSuccess) e = upload_frag(&v->w1h, w1, HID, HID, v->sW1);
+    if(e == hipSuccess) e = upload_frag(&v->w2h, w2, OUT6, HID, v->sW2);
+  }
   if(e != hipSuccess)
   {
     int r = hip_fail(e, "vposer upload", __FILE__, __LINE__);

@@ -1,0 +1,18 @@
+"""Development aid: phase stamps of vposer_jac_kernel (variant built with -DVPJ_STAMP). usage: SMPLPP_HIP_LIB=$PWD/ab/vpj.so python tools/vpj_stamps.py [frames]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from smplpp_amd import _lib
+from smplpp_amd.ik import VPoserDecoder
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+vp = VPoserDecoder(VPoserDecoder.synthetic_params(seed=3), device=0)
+z = np.random.default_rng(0).normal(0, 0.3, (n, 32)).astype(np.float32)
+for _ in range(5): vp.forward(z, want_jac=True)
+L = _lib.load()
+buf = (ctypes.c_ulonglong * 16)()
+L.smplpp_debug_vpj_stamps.restype = ctypes.c_int
+assert L.smplpp_debug_vpj_stamps(buf) == 0
+t = np.array(buf, dtype=np.uint64).astype(np.int64)[:7]
+names = ["layer 0 + fragments", "layer 1 loop", "activations + D2f", "layer 2", "rotation tail", "chain rule"]
+for i in range(6): print("%-20s %7d cycles" % (names[i], t[i + 1] - t[i]))
+print("total %d cycles" % (t[6] - t[0]))
