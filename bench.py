@@ -114,7 +114,7 @@ def cpu_baseline(model, frames, budget_s=12.0):
     }
 
 
-def ik_cpu_baseline(model, faces, tp, tn, theta0, budget_s=12.0):
+def ik_cpu_baseline(model, faces, tp, tn, theta0, budget_s=8.0):
     """configs[2] on the host: one IK iteration per frame as the reference computes it — residual and Jacobian by libtorch
     autograd, one backward() per Jacobian row, through the reference's own compiled FK stages (oracle/_ref,
     node/node.cpp:823-869), then the fp64 normal equations and LLT (node/node.cpp:883-943, restated in oracle/cpu.py).
@@ -137,7 +137,7 @@ def ik_cpu_baseline(model, faces, tp, tn, theta0, budget_s=12.0):
         cpu.llt_solve(A, b)
         done += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or done >= 16:
+        if el >= budget_s or done >= 400:
             break
     return {"value": done / el, "unit": "IK iterations/s", "cores": int(cores), "kind": "reference",
             "sample": "%d frame-iterations (%.1f s) of configs[2]: 24 autograd backward() calls per frame through the reference's "
