@@ -166,6 +166,26 @@ def test_fk_small_sparse_models(V):
             assert np.abs(g[k] - r[k]).max() < VERT_TOL, (V, n, k)
 
 
+def test_fk_workgroups_spanning_frame_tiles(smpl, oracle_synth):
+    """Batches beyond 2048 frames: a workgroup of the default fused kernel then runs through several frame tiles (its A
+    registers, the G' image and the root translations are reloaded, the previous item's tail is flushed first, the LDS ring
+    keeps streaming). 2500 frames, vertices AND rest shapes: every frame equals the same frame computed in a batch of 500
+    (where no workgroup changes its frame tile), and frames at tile boundaries match the oracle."""
+    from smplpp_amd import model_io
+
+    n = 2500
+    beta, theta = model_io.synthetic_inputs(n, seed=77)
+    o = smpl.launch(beta, theta, want=("verts", "rest"))
+    big_v, big_r = o["verts"].copy(), o["rest"].copy()
+    for a in range(0, n, 500):
+        p = smpl.launch(beta[a:a + 500], theta[a:a + 500], want=("verts", "rest"))
+        assert np.abs(p["verts"] - big_v[a:a + 500]).max() < 1e-6, a
+        assert np.abs(p["rest"] - big_r[a:a + 500]).max() < 1e-6, a
+    sel = np.array([0, 63, 64, 127, 128, 1279, 1280, 2047, 2048, 2495, 2496, 2499])
+    r = oracle_synth.fk(beta[sel], theta[sel], want=("verts", "rest"))
+    assert np.abs(big_v[sel] - r["verts"]).max() < VERT_TOL and np.abs(big_r[sel] - r["rest"]).max() < VERT_TOL
+
+
 def test_fk_outputs_beyond_2gib(smpl, oracle_synth):
     """The default fused kernels address their outputs with 32-bit buffer offsets; a batch whose vertex array reaches
     2 GiB (26 100 frames) is split into launches of at most 2 GiB (fp32-MFMA form: falls back to 64-bit addressing) and must still be right (device buffers: no 2 GiB host copy)."""
