@@ -21,6 +21,7 @@ constexpr int NP = SMPLPP_POSE_BASIS_DIM;
 constexpr int KP = 220;
 constexpr int K_BETA = NP;       // 207
 constexpr int K_ONE = NP + NB;   // 217
+constexpr int CT_LEV = 12;       // tree levels the pose kernel's register-resident chain table covers
 // Column layout of the B operand: vertex group g = v / 32 owns columns [96 g, 96 g + 96): 32 x, then 32 y, 32 z.
 constexpr int VG = 32;
 __host__ __device__ inline int64_t bcol(int64_t v, int x)
@@ -186,6 +187,7 @@ struct smplpp_model
   int32_t * parent = nullptr;  // [24]
   int32_t * lvl = nullptr;     // [25 + 24] kinematic tree by depth: level offsets, then the joints sorted by level
   int nlev = 0;
+  bool chain_fast = false;     // lvl also holds the (level, slot) -> (joint, parent) table of the pose kernel's chain
   int32_t * faces = nullptr;   // [F][3] 0-based
   int32_t * adjOff = nullptr;  // [V+1]
   int32_t * adjFace = nullptr; // [adjOff[V]] ascending face id per vertex

@@ -30,7 +30,9 @@ __device__ inline void rodrigues_dev(float t0, float t1, float t2, float * R)
   float angle = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
   float k0 = t0 / angle, k1 = t1 / angle, k2 = t2 / angle; // :815
   float K[9] = {0.0f, -k2, k1, k2, 0.0f, -k0, -k1, k0, 0.0f};
-  float s = sinf(angle), c1 = 1.0f - cosf(angle);
+  float s, co;
+  sincosf(angle, &s, &co); // (one range reduction for both)
+  const float c1 = 1.0f - co;
 #pragma unroll
   for(int r = 0; r < 3; r++)
 #pragma unroll
@@ -63,6 +65,16 @@ __device__ __forceinline__ void block_sync_lds()
 //            time (lane = (joint of the level, entry of its 3x4 transform); SMPL: 9 levels instead of 23 sequential joints)
 //   phase 3  relative transforms G', 4x4 outputs
 // levels: [nlev + 1] offsets into lvl_joint, then the joints sorted by depth (built at model creation).
+#ifdef POSE_STAMP
+__device__ unsigned long long g_pose_stamps[16];
+#define PST(i) if(blockIdx.x == 512 && threadIdx.x == 0) g_pose_stamps[i] = __builtin_amdgcn_s_memtime()
+extern "C" int smplpp_debug_pose_stamps(unsigned long long * out)
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pose_stamps), sizeof(unsigned long long) * 16);
+}
+#else
+#define PST(i)
+#endif
 __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ beta, const float * __restrict__ theta,
                                                    const float * __restrict__ J0, const float * __restrict__ JS,
                                                    const int32_t * __restrict__ parent, const int32_t * __restrict__ lvl_off,
@@ -70,18 +82,20 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
                                                    float * __restrict__ Gp, float * __restrict__ joints_out,
                                                    float * __restrict__ rot_out, float * __restrict__ xf44_out, int64_t n,
                                                    uint16_t * __restrict__ A3, _Float16 * __restrict__ A2h,
-                                                   _Float16 * __restrict__ G2h, float gscale)
+                                                   _Float16 * __restrict__ G2h, float gscale, const int32_t * __restrict__ ctab)
 {
   const int64_t f = blockIdx.x;
   const int tid = threadIdx.x;
   __shared__ float sR[NJ][9];
   __shared__ float sJ[NJ][3];
-  __shared__ float sG[NJ][12]; // global transforms [A | g], 3x4 row-major
+  __shared__ __attribute__((aligned(16))) float sG[NJ][12]; // global transforms [A | g], 3x4 row-major
   __shared__ float sBeta[NB];
   __shared__ float sCoef[224]; // the A operand row of this frame: [c(207) | beta(10) | 1 | 0...]
   __shared__ int sPar[NJ];
+  __shared__ float sZero[4];
   __shared__ int sLvl[NJ + 1 + NJ];
   if(f >= n) return;
+  PST(0);
   // ---- phase 0 (the folded-regressor rows are fetched now, so their latency overlaps Rodrigues and the first barrier)
   float j0v = 0.0f, jsv[NB];
 #pragma unroll
@@ -92,10 +106,34 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
 #pragma unroll
     for(int k = 0; k < NB; k++) jsv[k] = JS[tid * NB + k];
   }
+  // chain wavefront: (joint, parent) of this lane's slot at every level (ctab: model.hip), in registers
+  int cti[CT_LEV], ctp[CT_LEV], cts[CT_LEV];
+#pragma unroll
+  for(int L = 0; L < CT_LEV; L++)
+  {
+    cti[L] = ctp[L] = -1;
+    cts[L] = 0;
+  }
+  if(ctab && tid >= 192 && tid < 192 + 60)
+  {
+    const int slot = (tid - 192) / 12;
+#pragma unroll
+    for(int L = 0; L < CT_LEV; L++)
+      if(L < nlev)
+      {
+        cti[L] = ctab[(L * 5 + slot) * 3 + 0];
+        ctp[L] = ctab[(L * 5 + slot) * 3 + 1];
+        cts[L] = ctab[(L * 5 + slot) * 3 + 2];
+      }
+  }
   if(tid >= 64 && tid < 64 + NB) sBeta[tid - 64] = beta ? beta[f * NB + (tid - 64)] : 0.0f;
-  if(tid >= 128 && tid < 128 + NJ) sPar[tid - 128] = parent[tid - 128];
-  if(tid >= 192 && tid < 192 + nlev + 1) sLvl[tid - 192] = lvl_off[tid - 192];
-  if(tid >= 224 && tid < 224 + NJ) sLvl[NJ + 1 + tid - 224] = lvl_joint[tid - 224];
+  if(tid < 4) sZero[tid] = 0.0f;
+  if(!ctab) // (the tree tables in LDS serve the generic chain only)
+  {
+    if(tid >= 128 && tid < 128 + NJ) sPar[tid - 128] = parent[tid - 128];
+    if(tid >= 192 && tid < 192 + nlev + 1) sLvl[tid - 192] = lvl_off[tid - 192];
+    if(tid >= 224 && tid < 224 + NJ) sLvl[NJ + 1 + tid - 224] = lvl_joint[tid - 224];
+  }
   if(tid < NJ)
   {
     float R[9];
@@ -107,7 +145,9 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
 #pragma unroll
       for(int q = 0; q < 9; q++) rot_out[(f * NJ + tid) * 9 + q] = R[q];
   }
+  PST(1);
   block_sync_lds();
+  PST(2);
   // ---- phase 1: coefficient k = tid (root joint has no pose corrective: src/BlendShape.cpp:884-887) and joint coordinate tid
   if(tid < 224)
   {
@@ -134,6 +174,7 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
     if(joints_out) joints_out[f * NJ * 3 + tid] = s;
   }
   block_sync_lds();
+  PST(3);
   // ---- phase 2
   if(A3 && tid < 84)
   {
@@ -178,10 +219,58 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
     *reinterpret_cast<f16x8 *>(dst) = hi;
     *reinterpret_cast<f16x8 *>(dst + 64 * 8) = lo;
   }
-  if(tid >= 192)
+  if(tid >= 192 && ctab)
   {
     // chain: G_0 = L_0, G_i = G_p(i) . L_i with L_i = [R_i | j_i - j_p(i)] (src/WorldTransformation.cpp:508-610), level by
-    // level; within a level the joints are independent (their parents are one level up)
+    // level; within a level the joints are independent (their parents are one level up).  The lane's operand of every level
+    // (a column of R_i, or the offset j_i - j_p) does not depend on the chain: fetched up front.
+    const int lane = tid - 192, e = lane % 12, r = e / 4, c = e % 4;
+    // (branch-free: every lane issues the same six LDS reads per level back to back — divergent per-case reads cost a
+    // serialized LDS round trip per case and level, which was most of the chain's time)
+    float x0[CT_LEV], x1[CT_LEV], x2[CT_LEV];
+    const float * const zero3 = &sZero[0];
+#pragma unroll
+    for(int L = 0; L < CT_LEV; L++)
+    {
+      const int i = cti[L] >= 0 ? cti[L] : 0, p = ctp[L];
+      const float * a = (c < 3) ? &sR[i][c] : &sJ[i][0]; // column c of R_i (stride 3) or j_i (stride 1)
+      const int st = (c < 3) ? 3 : 1;
+      const float * b = (c == 3 && p >= 0) ? &sJ[p][0] : zero3;
+      const float a0 = a[0], a1 = a[st], a2 = a[2 * st], b0 = b[0], b1 = b[1], b2 = b[2];
+      x0[L] = a0 - b0;
+      x1[L] = a1 - b1;
+      x2[L] = a2 - b2;
+      if(p < 0) x0[L] = (r == 0) ? x0[L] : (r == 1 ? x1[L] : x2[L]); // root: L_0 = [R_0 | j_0], entry (r, c) itself
+    }
+    // The parent's row comes out of the REGISTERS of the lanes that computed it one level earlier (ds_bpermute through
+    // __shfl: no LDS write -> wait -> read turn-around per level); the LDS copy is written on the side for phase 3.
+    float vprev = 0.0f;
+#pragma unroll
+    for(int L = 0; L < CT_LEV; L++)
+    {
+      if(L < nlev) // (wave-uniform)
+      {
+        const int i = cti[L], p = ctp[L], src = 12 * cts[L] + r * 4;
+        const float g0 = __shfl(vprev, src + 0, 64), g1 = __shfl(vprev, src + 1, 64), g2 = __shfl(vprev, src + 2, 64),
+                    g3 = __shfl(vprev, src + 3, 64);
+        float v = x0[L];
+        if(p >= 0)
+        {
+          v = g0 * x0[L] + g1 * x1[L] + g2 * x2[L];
+          if(c == 3) v += g3;
+        }
+        if(lane < 60 && i >= 0)
+        {
+          vprev = v;
+          sG[i][e] = v;
+        }
+      }
+    }
+    wave_sync();
+  }
+  else if(tid >= 192)
+  {
+    // generic trees (deeper than CT_LEV levels or wider than 5 joints per level): the same chain with its look-ups in LDS
     const int lane = tid - 192, slot = lane / 12, e = lane % 12, r = e / 4, c = e % 4;
     for(int L = 0; L < nlev; L++)
     {
@@ -207,7 +296,9 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
       wave_sync();
     }
   }
+  PST(4);
   block_sync_lds();
+  PST(5);
   // ---- phase 3: relative transforms: translation -= A_i . j_i (src/WorldTransformation.cpp:657-677)
   for(int e = tid; e < NJ * 12; e += 256)
   {
@@ -249,6 +340,7 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
       *reinterpret_cast<f16x8 *>(blk + 1024 + 256 + r * 8) = lo;
     }
   }
+  PST(6);
 }
 
 // rows [n, ldA) of AT are padding for the last 32-frame tile: keep them zero (re-zeroed whenever n changes)
@@ -470,13 +562,13 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
                                                          ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr,
                                                          (verts || rest) ? ws.A2h.as<_Float16>() : nullptr,
-                                                         (verts || rest) ? ws.G2h.as<_Float16>() : nullptr, m->sG);
+                                                         (verts || rest) ? ws.G2h.as<_Float16>() : nullptr, m->sG, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr);
   }
   else if(form == 'b')
   {
     HIP_TRY(ws.A3.reserve((size_t)(n64 / 64) * BB_KS * BB_A_BYTES));
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
-                                                         ws.Gp.as<float>(), joints, poserot, xforms44, n, ws.A3.as<uint16_t>(), nullptr, nullptr, 1.0f);
+                                                         ws.Gp.as<float>(), joints, poserot, xforms44, n, ws.A3.as<uint16_t>(), nullptr, nullptr, 1.0f, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr);
   }
   else
   {
@@ -490,7 +582,7 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
       zero_pad_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(ws.AT.as<float>(), ldA, n);
     }
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, ws.AT.as<float>(),
-                                                         ldA, ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr, nullptr, nullptr, 1.0f);
+                                                         ldA, ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr, nullptr, nullptr, 1.0f, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr);
   }
   HIP_TRY(hipGetLastError());
   if(verts || rest)

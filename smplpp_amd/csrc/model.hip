@@ -415,6 +415,25 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
     }
     lv[nlev] = pos;
     m->nlev = nlev;
+    // per (level, slot) the joint and its parent for the pose kernel's chain wavefront (5 joints of a level at a time, 12
+    // lanes each): read once into registers instead of three dependent LDS look-ups per level.  chain_fast: the tree has at
+    // most CT_LEV levels of at most 5 joints (SMPL: 9 levels, widest 5); other trees take the generic loop.
+    m->chain_fast = nlev <= CT_LEV;
+    lv.resize(NJ + 1 + NJ + CT_LEV * 5 * 3, -1);
+    std::vector<int> slot_of(NJ, 0); // slot of a joint inside its level
+    for(int L = 0; L < nlev && m->chain_fast; L++)
+    {
+      const int cnt = lv[L + 1] - lv[L];
+      if(cnt > 5) m->chain_fast = false;
+      for(int q = 0; q < cnt && q < 5; q++)
+      {
+        const int i = lv[NJ + 1 + lv[L] + q];
+        slot_of[i] = q;
+        lv[NJ + 1 + NJ + (L * 5 + q) * 3 + 0] = i;
+        lv[NJ + 1 + NJ + (L * 5 + q) * 3 + 1] = parent[i];
+        lv[NJ + 1 + NJ + (L * 5 + q) * 3 + 2] = parent[i] >= 0 ? slot_of[parent[i]] : 0; // (the parent sits one level up: already placed)
+      }
+    }
     TRY_OR_FREE(upload(&m->lvl, lv.data(), lv.size()));
   }
 
