@@ -49,10 +49,10 @@ MFMA_32X32X16_FLOPS = 2 * 32 * 32 * 16
 
 def issued_mfma_flops(form, n):
     """FLOPs of the matrix instructions the fused kernel actually ISSUES per launch.
-    h (skin_h.hip): per 64 x 64 item and wavefront 126 GEMM MFMAs (14 k-steps x 3 coordinates x 3 piece products) + 72
-    skinning MFMAs (12 entries x 2 k-steps x 3 products); b (skin_b.hip): 252 (14 x 3 x 6)."""
+    h (skin_h.hip): per 64 x 64 item and wavefront 126 GEMM MFMAs (14 k-steps x 3 coordinates x 3 piece products) + 60
+    skinning MFMAs (12 entries x 5: K = 24 joints is 1.5 k-steps, the half k-step carries two of its products in one MFMA); b (skin_b.hip): 252 (14 x 3 x 6)."""
     items = ((n + 63) // 64) * ((V + 63) // 64)
-    per_wave = {"h": 126 + 72, "b": 252}[form]
+    per_wave = {"h": 126 + 60, "b": 252}[form]
     return items * 4 * per_wave * MFMA_32X32X16_FLOPS
 
 

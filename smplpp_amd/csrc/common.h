@@ -69,7 +69,8 @@ __host__ __device__ inline void split_bf16x3(float x, uint16_t & p0, uint16_t & 
 //   A2h [ceil(n/64)][HB_KS][fh 2][piece 2][64 lanes][8 fp16]                 frame = 64 ft + 32 fh + r; value sA.a
 //   B2h [ceil(V/64)][HB_SLOTS][12 KiB]: slots 0..13 = k-steps: [vh 2][coordinate 3][piece 2][64][8]  (value sB.b)
 //                                       slot 14 = skinning weights of the group: [ks 2][vh 2][piece 2][64][8] fp16 of
-//                                       sW.W[v][joint k] (k >= 24: 0), then cw[64] fp32 = 1 / (sG sW sum_j W[v,j]), then padding
+//                                       sW.W[v][joint k] (k >= 24: 0; k-step 1, eight live k: piece 1 = [hi | lo] over the
+//                                       lane halves), then cw[64] fp32 = 1 / (sG sW sum_j W[v,j]), then padding
 //   G2h [ceil(n/64)][fh 2][entry 12][3 KiB]: relative transforms as the A operand of the blend MFMAs (rows = frames,
 //                                       k = joint): ks 0: [piece 2][64][8]; ks 1 (joints 16..23): [piece 2][32 lanes][8]
 constexpr int HB_KS = 14;

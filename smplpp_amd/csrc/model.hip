@@ -139,7 +139,15 @@ __global__ void relayout_basis_f16x2_kernel(const float * __restrict__ Bm, int64
     }
     uint8_t * dst = base + HB_KS * HB_IMG + ((ks * 2 + vh) * 2) * 1024 + lane * 16;
     *reinterpret_cast<f16x8h *>(dst) = hi;
-    *reinterpret_cast<f16x8h *>(dst + 1024) = lo;
+    if(ks == 0)
+      *reinterpret_cast<f16x8h *>(dst + 1024) = lo;
+    else if(h == 0)
+    {
+      // k-step 1 has eight live k (joints 16..23): its second fragment is [hi | lo] over the two lane halves, so that one
+      // MFMA against the G' hi piece (read by both halves) is Ghi.Whi + Ghi.Wlo (skin_h.hip)
+      *reinterpret_cast<f16x8h *>(dst + 1024) = hi;
+      *reinterpret_cast<f16x8h *>(dst + 1024 + 512) = lo;
+    }
   }
   else
   {

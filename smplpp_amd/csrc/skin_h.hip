@@ -9,8 +9,8 @@
 // (tests/test_fp16x2_budget.py).
 //
 // Skinning on the matrix pipe.  M[f, v, e] = sum_j W[v, j] G'[f, j, e] (e = one of the 12 entries of the 3 x 4 transform)
-// is a [frames x 24] . [24 x vertices] product per entry: the same fp16x2 scheme, 6 MFMAs per entry (K = 24 padded to 32:
-// two k-steps x three products), accumulator layout identical to the blend-shape GEMM's (row = frame, column = vertex), so
+// is a [frames x 24] . [24 x vertices] product per entry: the same fp16x2 scheme, 5 MFMAs per entry (K = 24: k-step 0
+// takes three products, the half-live k-step 1 carries hi.hi + hi.lo in one MFMA and lo.hi in another), accumulator layout identical to the blend-shape GEMM's (row = frame, column = vertex), so
 // out = M . [rest; 1] is 5 VALU instructions per (frame, vertex, coordinate) on registers.  This replaces the ~65 VALU
 // instructions + 12 LDS gathers per (frame, vertex) that bound the bf16x3 form (its MFMA wavefronts issued 1079 VALU + 376
 // LDS instructions per item), handles any number of weights per vertex, and needs no per-lane joint tables.
@@ -368,16 +368,19 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
       g_hslot_times[dbg_item * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    // ---- skinning: 12 entries of 6 MFMAs; the VALU work of entry E - 1 rides behind the MFMAs of entry E
+    // ---- skinning: 12 entries of 5 MFMAs; the VALU work of entry E - 1 rides behind the MFMAs of entry E.  K = 24 joints:
+    // k-step 0 (joints 0..15) takes the three piece products; of k-step 1 only eight k are live (joints 16..23) and both lane
+    // halves read the same G' piece, so Ghi1.Whi1 + Ghi1.Wlo1 is ONE MFMA against the weight fragment [Whi1 | Wlo1]
     hstatic_for<12>([&](auto ee) {
       constexpr int E = decltype(ee)::value, MPE = E & 1;
-      hstatic_for<6>([&](auto bb) {
+      hstatic_for<5>([&](auto bb) {
         constexpr int B = decltype(bb)::value;
-        // B: 0 Ghi0.Whi0, 1 Ghi1.Whi1, 2 Ghi0.Wlo0, 3 Ghi1.Wlo1, 4 Glo0.Whi0, 5 Glo1.Whi1  (fragment index = 2 ks + piece)
-        constexpr int GI = (B == 0 || B == 2) ? 0 : ((B == 1 || B == 3) ? 2 : (B == 4 ? 1 : 3));
-        constexpr int WI = (B == 0 || B == 4) ? 0 : ((B == 1 || B == 5) ? 2 : (B == 2 ? 1 : 3));
+        // B: 0 Ghi0.Whi0, 1 Ghi0.Wlo0, 2 Ghi1.[Whi1 | Wlo1], 3 Glo0.Whi0, 4 Glo1.[Whi1 | 0]
+        // (G' fragment index = 2 ks + piece; weight fragments: 0 Whi0, 1 Wlo0, 2 [Whi1 | 0], 3 [Whi1 | Wlo1])
+        constexpr int GI = B < 2 ? 0 : (B == 2 ? 2 : (B == 3 ? 1 : 3));
+        constexpr int WI = B == 0 ? 0 : (B == 1 ? 1 : (B == 2 ? 3 : (B == 3 ? 0 : 2)));
 #if SKINH_ABL & 256
-        if(blockIdx.x == 0 && tid == 0 && dbg_item < 8) g_hslot_times[dbg_item * 256 + 126 + E * 6 + B] = __builtin_readcyclecounter();
+        if(blockIdx.x == 0 && tid == 0 && dbg_item < 8) g_hslot_times[dbg_item * 256 + 126 + E * 5 + B] = __builtin_readcyclecounter();
 #endif
         if constexpr(SKINH_ABL & 8)
         {
@@ -391,19 +394,23 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
         if constexpr(E == 0 && B == 0) h_barrier<h_barrier_vmcnt(HB_KS, HT, WANT_REST)>(); // slot 14: publishes slot 0 of the next item
         if constexpr(E == 0 && B >= 1 && B <= 3) dma(std::integral_constant<int, B - 1>{}, Bnext, HB_KS + 7 - HB_SLOTS, imgS[HB_KS % H_R]);
         if constexpr(E == 1) // operand fragments of the next item's first k-step (image (14 + 1) % 7)
-          bfr[B / 2][B % 2] = *reinterpret_cast<const v4f *>(imgV[(HB_KS + 1) % H_R] + B * 1024);
-        if constexpr(E < 11 && B >= 2 && !(SKINH_ABL & (8 | 16))) // G' fragments of the next entry, each right behind its last MFMA of this one
         {
-          constexpr int I = B == 2 ? 0 : (B == 3 ? 2 : (B == 4 ? 1 : 3));
+          bfr[B / 2][B % 2] = *reinterpret_cast<const v4f *>(imgV[(HB_KS + 1) % H_R] + B * 1024);
+          if constexpr(B == 4) bfr[2][1] = *reinterpret_cast<const v4f *>(imgV[(HB_KS + 1) % H_R] + 5 * 1024);
+        }
+        if constexpr(E < 11 && B >= 1 && !(SKINH_ABL & (8 | 16))) // G' fragments of the next entry, each right behind its last MFMA of this one
+        {
+          constexpr int I = B == 1 ? 0 : (B == 2 ? 2 : (B == 3 ? 1 : 3));
           gfr[I] = *reinterpret_cast<const v4f *>((I < 2 ? gLane0 + I * 1024 : gLane1 + (I - 2) * 512) + (E + 1) * 3072);
         }
-        if constexpr(E == 11 && B == 5) // root translation of the tail's first row
+        if constexpr(E == 11 && B == 4) // root translation of the tail's first row
           trb[0] = *reinterpret_cast<const v4f *>(trLane);
-        if constexpr(E >= 1 && B >= 2 && !(SKINH_ABL & 8)) // entry F = E - 1 = (XF, CF): four rows per slot
+        if constexpr(E >= 1 && B >= 2 && !(SKINH_ABL & 8)) // entry F = E - 1 = (XF, CF): rows 0..5, 6..10, 11..15
         {
           constexpr int F = E - 1, CF = F % 4, MP = F & 1;
+          constexpr int R0 = B == 2 ? 0 : (B == 3 ? 6 : 11), R1 = B == 2 ? 6 : (B == 3 ? 11 : 16);
 #pragma unroll
-          for(int r = 4 * (B - 2); r < 4 * (B - 2) + 4; r++)
+          for(int r = R0; r < R1; r++)
           {
             if constexpr(CF == 0) tt[r] = macc[MP][r] * acc[0][r];
             if constexpr(CF == 1) tt[r] = __builtin_fmaf(macc[MP][r], acc[1][r], tt[r]);

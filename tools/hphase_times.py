@@ -24,7 +24,7 @@ print("prologue (start -> first item): %d cycles; start -> entry barrier %d, -> 
 for it in range(items):
     g0, b0 = T[it * 8 + 0], T[it * 8 + 2]
     nxt = T[(it + 1) * 8] if it + 1 < items else t1
-    print("item %d: gemm %d cycles (%.0f per MFMA), blend+rest %d cycles (%.0f per MFMA)" % (it, b0 - g0, (b0 - g0) / 126.0, nxt - b0, (nxt - b0) / 72.0))
+    print("item %d: gemm %d cycles (%.0f per MFMA), blend+rest %d cycles (%.0f per MFMA)" % (it, b0 - g0, (b0 - g0) / 126.0, nxt - b0, (nxt - b0) / 60.0))
 
 wb = (ctypes.c_ulonglong * (256 * 4))()
 L.smplpp_debug_hwg_times.restype = ctypes.c_int
