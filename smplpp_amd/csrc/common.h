@@ -22,6 +22,12 @@ constexpr int KP = 220;
 constexpr int K_BETA = NP;       // 207
 constexpr int K_ONE = NP + NB;   // 217
 constexpr int CT_LEV = 12;       // tree levels the pose kernel's register-resident chain table covers
+// tree tables of a model for the IK evaluation (smplpp_model::anc, int32): ancestor bit masks [24] | level offsets
+// [TREE_DMAX + 1] | joints sorted by level [24]
+constexpr int TREE_DMAX = 12;
+constexpr int TREE_ANC = 0, TREE_LVL = SMPLPP_JOINT_NUM, TREE_LVLJ = TREE_LVL + TREE_DMAX + 1, TREE_SIZE = TREE_LVLJ + SMPLPP_JOINT_NUM;
+constexpr int MAXADJ = 12;                    // adjacent faces per vertex the IK normal Jacobian differentiates through
+constexpr int MAXRING = 3 * (MAXADJ + 1) + 1; // distinct vertices an IK task can touch: its face's and those of the faces around them
 // Column layout of the B operand: vertex group g = v / 32 owns columns [96 g, 96 g + 96): 32 x, then 32 y, 32 z.
 constexpr int VG = 32;
 __host__ __device__ inline int64_t bcol(int64_t v, int x)
@@ -192,6 +198,10 @@ struct smplpp_model
   int32_t * faces = nullptr;   // [F][3] 0-based
   int32_t * adjOff = nullptr;  // [V+1]
   int32_t * adjFace = nullptr; // [adjOff[V]] ascending face id per vertex
+  uint16_t * faceRing = nullptr; // [F][MAXRING + 1] IK ring of a task on face f: count, the face's three vertices, then the distinct
+                                 // vertices of the faces adjacent to them in (vertex, adjacent face, corner) order (V <= 65535)
+  uint8_t * faceMap = nullptr;   // [F][3 MAXADJ 3] (vertex of the face, adjacent face, corner) -> slot in that ring
+  int32_t * anc = nullptr;       // [TREE_SIZE] tree tables of the IK evaluation (TREE_* above)
   float * Wdense = nullptr;    // [V][24] original weights (stage entry points / IK)
   float * Pvm = nullptr;       // [V][3][207] posedirs, vertex-major (IK Jacobian: pose-corrective term of a few vertices)
   float * Svm = nullptr;       // [V][3][10]  shapedirs, vertex-major (IK Jacobian: beta columns)

@@ -33,9 +33,7 @@ constexpr int TD75 = SMPLPP_THETA_DIM;        // 75
 constexpr int TD44 = SMPLPP_LATENT_POSE_DIM;  // 44
 constexpr int NQ = TD75 + NB;                 // differentiation columns handled per frame: theta(75) | beta(10)
 constexpr int IK_MAXK = 48;                   // tasks per frame supported (the reference uses at most 41: MocapBody markers)
-constexpr int MAXADJ = 12;                    // adjacent faces per vertex supported by the normal Jacobian
 constexpr size_t SOLVE_LDS_MAX = 160 * 1024 - 512; // dynamic LDS the solve kernels may ask for (160 KiB per CU, minus their static LDS)
-constexpr int MAXRING = 3 * (MAXADJ + 1) + 1; // distinct vertices a task can touch
 constexpr int MAXD = TD75 + 2 * IK_MAXK + NB;  // 181: unknowns per frame supported by the in-LDS solver (every task count up to IK_MAXK, beta included)
 
 struct TaskArrays
@@ -66,6 +64,10 @@ struct ModelView
   const float * Pvm;
   const float * Svm;
   const float * JS;
+  const uint16_t * faceRing; // [F][MAXRING + 1] per face: ring size, then the ring (common.h)
+  const uint8_t * faceMap;   // [F][3 MAXADJ 3] (vertex of the face, adjacent face, corner) -> ring slot
+  const int32_t * anc;       // [TREE_SIZE] tree tables (common.h): ancestor masks, joints by level
+  int nlev;
   int64_t V;
   int maxw;
 };
@@ -209,7 +211,7 @@ constexpr int L_DR = L_T + NJ * 3;             // [72][9]
 // d[A_i | b_i]/d theta_c is non-zero only when joint(c) is an ancestor of i (or i itself), and a joint has exactly one
 // ancestor per depth: the table keeps, per joint, three columns per DEPTH (column slot 3 depth(joint(c)) + axis(c)) instead of
 // all 72 — 41 KB instead of 83 KB of LDS, which is what lets three tasks with a normal term share the ring buffers below.
-constexpr int DMAX = 12;                       // deepest kinematic tree served (SMPL: 9 levels); smplpp_ik_create checks
+constexpr int DMAX = TREE_DMAX;                     // deepest kinematic tree served (SMPL: 9 levels); smplpp_ik_create checks
 constexpr int CS = 3 * DMAX;                   // column slots per joint
 constexpr int L_DAB = L_DR + 72 * 9;           // [24][CS][3][4]  per (joint, column slot): rows [dA_r | db_r] (one 16-byte LDS access per row)
 constexpr int L_DBB = L_DAB + NJ * 12 * CS;    // [24*3][10]
@@ -238,13 +240,15 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
                                                       const float * __restrict__ verts_all, const float * __restrict__ rest_all,
                                                       const float * __restrict__ Gp, const float * __restrict__ joints,
                                                       const float * __restrict__ poserot, int K, int optimize_beta,
-                                                      int phi_live, int min_valid, int32_t * __restrict__ ring_buf, int32_t * __restrict__ ring_key,
-                                                      uint8_t * __restrict__ map_buf, float * __restrict__ pos804,
+                                                      int phi_live, int min_valid, float * __restrict__ pos804,
                                                       double * __restrict__ e_out, double * __restrict__ J_out,
-                                                      int * __restrict__ skip, int dbg_stop, int tsplit)
+                                                      int * __restrict__ skip, int dbg_stop, int tsplit, const int32_t * __restrict__ roles)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  int * sAnc = reinterpret_cast<int *>(lds + L_END);
+  __shared__ int s_tree[TREE_SIZE];
+  __shared__ int s_par[NJ];
+  const int * sAnc = s_tree + TREE_ANC;
+  const int nlev = mv.nlev;
   // grid = n * tsplit: when frames are fewer than CUs (mocap chains: 8 per GPU x 41 markers) a frame's tasks are split over
   // tsplit workgroups, each rebuilding the frame's derivative tables (4 us) for its contiguous share of the tasks
   const int64_t f = blockIdx.x / tsplit;
@@ -252,6 +256,11 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
 
   const int tid = threadIdx.x;
   EVAL_STAMP(0);
+  // this thread's entry of the chain-derivative table at every tree level (built by smplpp_ik_create from the tree): joint |
+  // parent << 5 | column slot << 10 | row << 16 | (the column's joint is the joint itself) << 18; -1: none
+  int role[DMAX];
+#pragma unroll
+  for(int L = 0; L < DMAX; L++) role[L] = roles[L * EVAL_NT + tid];
   const int nq = TD75 + (optimize_beta ? NB : 0);
   const int D = TD75 + 2 * K + (optimize_beta ? NB : 0);
   const float * verts = verts_all + f * mv.V * 3;
@@ -276,8 +285,9 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   for(int i = tid; i < NJ * 9; i += EVAL_NT) lds[L_R + i] = poserot[f * NJ * 9 + i];
   for(int i = tid; i < NJ * 3; i += EVAL_NT) lds[L_J + i] = joints[f * NJ * 3 + i];
   for(int i = tid; i < NJ * 12; i += EVAL_NT) lds[L_G + i] = Gp[f * NJ * 12 + i];
-  if(tid == 0)
-    for(int i = 0; i < NJ; i++) sAnc[i] = (1 << i) | (i ? sAnc[mv.parent[i]] : 0); // depth(i) = popcount(anc) - 1
+  // tree tables of the model (common.h TREE_*): ancestor masks (with the joint itself; depth(i) = popcount - 1), joints by level
+  for(int i = tid; i < TREE_SIZE; i += EVAL_NT) s_tree[i] = mv.anc[i];
+  if(tid < NJ) s_par[tid] = mv.parent[tid];
   __syncthreads();
   for(int i = tid; i < NJ * 3; i += EVAL_NT)
   {
@@ -294,67 +304,83 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
 
   EVAL_STAMP(1);
   if(dbg_stop == 20) return; // (timing experiments only: SMPLPP_IK_DBG_STOP)
-  // ---- chain derivatives: thread (c, r) = rotation column c (joint c/3, component c%3) x matrix
-  // row r.  Row r of dA_i and dg_i depends only on row r of the parent's: 216 independent 24-step recurrences (one thread
-  // per column walked all three rows through ~40 dependent LDS accesses per joint).
-  if(tid < 216)
+  // ---- chain derivatives, one tree level per step.  Entry (joint i, ancestor depth da, axis a,
+  // row r) = row r of d[A_i | b_i]/d theta_c for c = (ancestor of i at depth da, axis a); it depends only on the SAME
+  // entry of i's parent (or, when the ancestor is i itself, on dR_c and the parent's A): all joints of a level and all
+  // their columns advance together — 9 steps of one LDS round trip instead of 24-step walks by 216 threads.
+  // The beta columns (joints move, rotations do not) ride in the same steps on another thread range:
+  // d g_i/d beta_k = A_p . dt_i + d g_p; the running d g sits in the (still unused) dp buffer.
   {
-    const int c = tid % 72, r = tid / 72, jc = c / 3;
-    const int cs = 3 * (__popc(sAnc[jc]) - 1) + c % 3; // this column's slot (3 depth + axis) in the table of every descendant of joint jc
-    for(int i = jc; i < NJ; i++)           // (descendants follow their ancestors in the joint order)
-    {
-      float dA[3] = {0.f, 0.f, 0.f}, dg = 0.f;
-      const int p = mv.parent[i];
-      if(!((sAnc[i] >> jc) & 1)) continue; // not a descendant: no entry (the slot of this depth belongs to i's own ancestor)
-      if(i == jc)
-      {
-        const float * dR = lds + L_DR + c * 9;
-        if(i == 0)
-          for(int cc = 0; cc < 3; cc++) dA[cc] = dR[r * 3 + cc];
-        else
-        {
-          const float * Ap = lds + L_G + p * 12;
-          for(int cc = 0; cc < 3; cc++) dA[cc] = Ap[r * 4 + 0] * dR[cc] + Ap[r * 4 + 1] * dR[3 + cc] + Ap[r * 4 + 2] * dR[6 + cc];
-        }
-      }
-      else
-      {
-        // parent's dA row and dg (dg_p = db_p + dA_p . j_p)
-        const float4 pr = *reinterpret_cast<const float4 *>(lds + L_DAB + ((p * CS + cs) * 3 + r) * 4);
-        const float dAp[3] = {pr.x, pr.y, pr.z};
-        const float dgp = pr.w + (dAp[0] * lds[L_J + p * 3] + dAp[1] * lds[L_J + p * 3 + 1] + dAp[2] * lds[L_J + p * 3 + 2]);
-        const float * Ri = lds + L_R + i * 9;
-        const float * ti = lds + L_T + i * 3;
-        for(int cc = 0; cc < 3; cc++) dA[cc] = dAp[0] * Ri[cc] + dAp[1] * Ri[3 + cc] + dAp[2] * Ri[6 + cc];
-        dg = (dAp[0] * ti[0] + dAp[1] * ti[1] + dAp[2] * ti[2]) + dgp;
-      }
-      *reinterpret_cast<float4 *>(lds + L_DAB + ((i * CS + cs) * 3 + r) * 4) =
-          make_float4(dA[0], dA[1], dA[2], dg - (dA[0] * lds[L_J + i * 3] + dA[1] * lds[L_J + i * 3 + 1] + dA[2] * lds[L_J + i * 3 + 2]));
-    }
-  }
-  else if(tid < 216 + NB && optimize_beta) // beta columns: joints move, rotations do not
-  {
-    const int k = tid - 216;
-    float dgl[NJ][3];
-    for(int i = 0; i < NJ; i++)
-    {
-      const int p = mv.parent[i];
-      float dj[3], dt[3];
+    const int * s_lvl = s_tree + TREE_LVL, * s_lvlj = s_tree + TREE_LVLJ;
+    float * dgl = lds + L_DP; // [24][3][NB]
+    static_assert(EVAL_NT >= 512 + NJ * NB, "the beta columns take threads 512..");
+    // beta columns: thread (joint i, k) works at the joint's level; its regressor rows are loaded ahead of the steps
+    const bool isb = optimize_beta && tid >= 512 && tid < 512 + NJ * NB;
+    const int bi = isb ? (tid - 512) / NB : 0, bk = isb ? (tid - 512) % NB : 0, bp = s_par[bi];
+    const int blev = isb ? __popc(sAnc[bi]) - 1 : -1;
+    float dj[3] = {0.f, 0.f, 0.f}, dt[3] = {0.f, 0.f, 0.f};
+    if(isb)
       for(int x = 0; x < 3; x++)
       {
-        dj[x] = mv.JS[(i * 3 + x) * NB + k];
-        dt[x] = (i == 0) ? dj[x] : dj[x] - mv.JS[(p * 3 + x) * NB + k];
+        dj[x] = mv.JS[(bi * 3 + x) * NB + bk];
+        dt[x] = (bi == 0) ? dj[x] : dj[x] - mv.JS[(bp * 3 + x) * NB + bk];
       }
-      if(i == 0)
-        for(int x = 0; x < 3; x++) dgl[0][x] = dt[x];
-      else
+#pragma unroll
+    for(int L = 0; L < DMAX; L++)
+    {
+      if(L >= nlev) break;
+      if(role[L] >= 0)
       {
-        const float * Ap = lds + L_G + p * 12;
-        for(int r = 0; r < 3; r++) dgl[i][r] = (Ap[r * 4] * dt[0] + Ap[r * 4 + 1] * dt[1] + Ap[r * 4 + 2] * dt[2]) + dgl[p][r];
+        // one path for both kinds of entry: row = x . M with x = the parent's dA row and M = R_i (the column's joint is an
+        // ancestor), or x = row r of the parent's A (the unit row for the root) and M = dR_c (it is joint i itself)
+        const int i = role[L] & 31, p = (role[L] >> 5) & 31, cs = (role[L] >> 10) & 63, r = (role[L] >> 16) & 3;
+        const bool self = (role[L] >> 18) & 1;
+        const int pc = (i == 0) ? 0 : p; // (the root has no parent: any valid address, the value is not used)
+        const float4 xr = *reinterpret_cast<const float4 *>(self ? lds + L_G + pc * 12 + r * 4 : lds + L_DAB + ((pc * CS + cs) * 3 + r) * 4);
+        const float * M = self ? lds + L_DR + (3 * i + cs % 3) * 9 : lds + L_R + i * 9;
+        const float m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3], m4 = M[4], m5 = M[5], m6 = M[6], m7 = M[7], m8 = M[8];
+        const float t0 = lds[L_T + i * 3], t1 = lds[L_T + i * 3 + 1], t2 = lds[L_T + i * 3 + 2];
+        const float jp0 = lds[L_J + pc * 3], jp1 = lds[L_J + pc * 3 + 1], jp2 = lds[L_J + pc * 3 + 2];
+        const float ji0 = lds[L_J + i * 3], ji1 = lds[L_J + i * 3 + 1], ji2 = lds[L_J + i * 3 + 2];
+        const bool unit = self && i == 0;
+        const float x0 = unit ? (r == 0 ? 1.0f : 0.0f) : xr.x, x1 = unit ? (r == 1 ? 1.0f : 0.0f) : xr.y, x2 = unit ? (r == 2 ? 1.0f : 0.0f) : xr.z;
+        float dA[3];
+        if(unit) // (the reference's dA_0 = dR itself: no products with the unit row's zeros)
+        {
+          dA[0] = r == 0 ? m0 : (r == 1 ? m3 : m6);
+          dA[1] = r == 0 ? m1 : (r == 1 ? m4 : m7);
+          dA[2] = r == 0 ? m2 : (r == 1 ? m5 : m8);
+        }
+        else
+        {
+          dA[0] = x0 * m0 + x1 * m3 + x2 * m6;
+          dA[1] = x0 * m1 + x1 * m4 + x2 * m7;
+          dA[2] = x0 * m2 + x1 * m5 + x2 * m8;
+        }
+        // dg = dA_p . t_i + (db_p + dA_p . j_p) for an ancestor's column, 0 for the joint's own
+        const float dgp = xr.w + (x0 * jp0 + x1 * jp1 + x2 * jp2);
+        const float dg = self ? 0.0f : (x0 * t0 + x1 * t1 + x2 * t2) + dgp;
+        *reinterpret_cast<float4 *>(lds + L_DAB + ((i * CS + cs) * 3 + r) * 4) =
+            make_float4(dA[0], dA[1], dA[2], dg - (dA[0] * ji0 + dA[1] * ji1 + dA[2] * ji2));
       }
-      const float * Ai = lds + L_G + i * 12;
-      for(int r = 0; r < 3; r++)
-        lds[L_DBB + (i * 3 + r) * NB + k] = dgl[i][r] - (Ai[r * 4] * dj[0] + Ai[r * 4 + 1] * dj[1] + Ai[r * 4 + 2] * dj[2]);
+      if(blev == L)
+      {
+        float dgi[3];
+        if(bi == 0)
+          for(int x = 0; x < 3; x++) dgi[x] = dt[x];
+        else
+        {
+          const float * Ap = lds + L_G + bp * 12;
+          for(int r = 0; r < 3; r++) dgi[r] = (Ap[r * 4] * dt[0] + Ap[r * 4 + 1] * dt[1] + Ap[r * 4 + 2] * dt[2]) + dgl[(bp * 3 + r) * NB + bk];
+        }
+        const float * Ai = lds + L_G + bi * 12;
+        for(int r = 0; r < 3; r++)
+        {
+          dgl[(bi * 3 + r) * NB + bk] = dgi[r];
+          lds[L_DBB + (bi * 3 + r) * NB + bk] = dgi[r] - (Ai[r * 4] * dj[0] + Ai[r * 4 + 1] * dj[1] + Ai[r * 4 + 2] * dj[2]);
+        }
+      }
+      __syncthreads();
     }
   }
 
@@ -373,75 +399,18 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   static_assert(IK_MAXK * MAXRING * 3 <= RCAP * 3 * NQ, "s_rpos must fit the L_DP region");
   float(*s_rpos)[MAXRING][3] = reinterpret_cast<float(*)[MAXRING][3]>(lds + L_DP);
   const int ntask = k_end - k_begin;
-  if(tid < ntask) // A0
+  // A0: ring lists from the per-face tables built with the model (topology only)
+  for(int item = tid; item < ntask * (MAXRING + 1); item += EVAL_NT)
   {
-    const int k = k_begin + tid;
-    const int face = ta.face[tb + k];
+    const int t = item / (MAXRING + 1), q = item % (MAXRING + 1);
+    const int k = k_begin + t;
     const bool use_normal = (ta.noff[tb + k] > 0.0f) || (ta.nrmw[tb + k] > 0.0f);
-    uint16_t * ring = s_ringb[tid];
-    s_usen[tid] = use_normal ? 1 : 0;
-    uint8_t * map = map_buf + (f * K + k) * (3 * MAXADJ * 3);
-    int32_t * ring_out = ring_buf + (f * K + k) * (MAXRING + 1);
-    const int key = face * 2 + (use_normal ? 1 : 0);
-    const bool cached = ring_key[tb + k] == key;
-    int nr = 0;
-    if(cached)
-    {
-      nr = ring_out[0];
-      for(int q = 1; q <= nr; q++) ring[q] = ring_out[q];
-    }
-    else
-    {
-      int fv[3];
-      for(int i = 0; i < 3; i++) fv[i] = mv.faces[face * 3 + i];
-      for(int i = 0; i < 3; i++) ring[1 + nr++] = fv[i]; // slots 0..2 = the face's own vertices
-      if(use_normal) // + the distinct vertices of the faces around them
-      {
-        // all candidate vertices first (two rounds of independent loads: adjacent faces, then their corners; the duplicate
-        // search below then runs on LDS only), into this task's slice of the position buffer used as integer scratch
-        int * cand = reinterpret_cast<int *>(&s_rpos[tid][0][0]); // [3][MAXADJ][3] = 108 <= 120
-        int b0[3], cnt[3];
-        for(int i = 0; i < 3; i++)
-        {
-          b0[i] = mv.adjOff[fv[i]];
-          cnt[i] = mv.adjOff[fv[i] + 1] - b0[i];
-          if(cnt[i] > MAXADJ) cnt[i] = MAXADJ;
-        }
-        int fa[3][MAXADJ];
-#pragma unroll
-        for(int i = 0; i < 3; i++)
-#pragma unroll
-          for(int a2 = 0; a2 < MAXADJ; a2++) fa[i][a2] = mv.adjFace[b0[i] + (a2 < cnt[i] ? a2 : 0)];
-#pragma unroll
-        for(int i = 0; i < 3; i++)
-#pragma unroll
-          for(int a2 = 0; a2 < MAXADJ; a2++)
-#pragma unroll
-            for(int cc = 0; cc < 3; cc++) cand[(i * MAXADJ + a2) * 3 + cc] = mv.faces[fa[i][a2] * 3 + cc];
-        for(int i = 0; i < 3; i++)
-          for(int a2 = 0; a2 < cnt[i]; a2++)
-            for(int cc = 0; cc < 3; cc++)
-            {
-              const int v = cand[(i * MAXADJ + a2) * 3 + cc];
-              int slot = -1;
-              for(int q = 0; q < nr; q++)
-                if(ring[1 + q] == v) slot = q;
-              if(slot < 0 && nr < MAXRING)
-              {
-                slot = nr;
-                ring[1 + nr++] = v;
-              }
-              map[(i * MAXADJ + a2) * 3 + cc] = (uint8_t)(slot < 0 ? 0 : slot);
-            }
-      }
-      for(int q = 1; q <= nr; q++) ring_out[q] = ring[q];
-      ring_out[0] = nr;
-      ring_key[tb + k] = key;
-    }
-    ring[0] = nr;
+    const uint16_t e = mv.faceRing[(int64_t)ta.face[tb + k] * (MAXRING + 1) + q];
+    // slots 0..2 = the face's own vertices; with a normal term / offset also the distinct vertices of the faces around them
+    s_ringb[t][q] = (q == 0 && !use_normal) ? (uint16_t)3 : e;
+    if(q == 0) s_usen[t] = use_normal ? 1 : 0;
   }
   __syncthreads();
-  __threadfence_block(); // a rebuilt map is read by other threads below
   EVAL_STAMP(3);
   if(dbg_stop == 23) return;
   for(int item = tid; item < ntask * MAXRING; item += EVAL_NT) // A1
@@ -470,7 +439,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
         vertex_normal_dev(verts, mv.faces, mv.adjOff, mv.adjFace, u, vn);
       else
       {
-        const uint8_t * map = map_buf + (f * K + k) * (3 * MAXADJ * 3);
+        const uint8_t * map = mv.faceMap + (int64_t)ta.face[tb + k] * (3 * MAXADJ * 3);
         float sum = 0.0f;
         for(int q = 0; q < cnt; q++) sum += 1.0f;
         const float w = 1.0f / sum;
@@ -630,7 +599,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
     else if(tid >= 64 && tid < 64 + NGN * 128) // ring-slot maps of the group's normal tasks
     {
       const int gi = (tid - 64) >> 7, j = (tid - 64) & 127;
-      if(gi < ngn && j < 3 * MAXADJ * 3) s_map[gi][j] = map_buf[(f * K + k_lo + gi) * (3 * MAXADJ * 3) + j];
+      if(gi < ngn && j < 3 * MAXADJ * 3) s_map[gi][j] = mv.faceMap[(int64_t)ta.face[tb + k_lo + gi] * (3 * MAXADJ * 3) + j];
     }
     else if(tid >= 64 + NGN * 128 && tid < 64 + NGN * 128 + NGN * 4)
     {
@@ -643,51 +612,78 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
     }
     __syncthreads();
     if(k_lo == k_begin) EVAL_STAMP(9);
-    for(int item = tid; item < total * nq; item += EVAL_NT) // B2: dp[rv][:, q]  
+    // B2: dp[rv][:, q]  (SURVEY.md §9 items 1-5).  One thread per (ring vertex, column group): the root translation triple,
+    // one joint's three rotation columns (they share the vertex's weights, its rest position and the 27 pose-corrective
+    // coefficients of that joint: loaded once instead of once per column), or one beta column.
+    const int ngrp = 1 + NJ + (nq - TD75);
+    for(int item = tid; item < total * ngrp; item += EVAL_NT)
     {
-      const int r_ = (nq == TD75) ? item / TD75 : item / NQ; // (nq is one of the two: constant divisions)
-      const int q = item - r_ * nq;
+      const int r_ = item / ngrp, g = item - r_ * ngrp;
       const int v = s_rvert[r_];
       const float * rv = lds + L_RV + r_ * RVS;
-      float acc[3] = {0.f, 0.f, 0.f};
-      if(q < 3)
-        acc[q] = rv[12]; // root translation: identity (divided by wsum below)
-      else if(q < TD75)
+      float * dpv = lds + L_DP + (r_ * 3) * NQ; // row r, column q: dpv[r * NQ + q]
+      const float wsum = rv[12];
+      if(g == 0) // root translation: identity
       {
-        const int c = q - 3, jc = c / 3;
-        const int cslot = 3 * (__popc(sAnc[jc]) - 1) + c % 3, jbit = 1 << jc;
+        for(int q = 0; q < 3; q++)
+          for(int r = 0; r < 3; r++) dpv[r * NQ + q] = ((r == q) ? wsum : 0.0f) / wsum;
+      }
+      else if(g <= NJ)
+      {
+        const int jc = g - 1;
+        const int cs0 = 3 * (__popc(sAnc[jc]) - 1), jbit = 1 << jc;
         const bool wlds = mv.maxw <= 4;
+        float acc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}; // [axis][row]
         for(int m = 0; m < mv.maxw; m++)
         {
           const float wm = wlds ? rv[16 + m] : mv.wVal[(int64_t)v * mv.maxw + m];
           if(wm == 0.0f) continue;
           const int i = wlds ? __float_as_int(rv[20 + m]) : (int)mv.wIdx[(int64_t)v * mv.maxw + m];
-          if(!((wlds ? __float_as_int(rv[24 + m]) : sAnc[i]) & jbit)) continue; // joint(c) does not move joint i: the term is exactly zero
-          const float4 * d = reinterpret_cast<const float4 *>(lds + L_DAB + (i * CS + cslot) * 12);
-          for(int r = 0; r < 3; r++)
-          {
-            const float4 dr4 = d[r];
-            acc[r] += wm * (((dr4.x * rv[0] + dr4.y * rv[1]) + dr4.z * rv[2]) + dr4.w);
-          }
+          if(!((wlds ? __float_as_int(rv[24 + m]) : sAnc[i]) & jbit)) continue; // joint jc does not move joint i: the term is exactly zero
+          const float4 * d = reinterpret_cast<const float4 *>(lds + L_DAB + (i * CS + cs0) * 12);
+#pragma unroll
+          for(int a = 0; a < 3; a++)
+#pragma unroll
+            for(int r = 0; r < 3; r++)
+            {
+              const float4 dr4 = d[a * 3 + r];
+              acc[a][r] += wm * (((dr4.x * rv[0] + dr4.y * rv[1]) + dr4.z * rv[2]) + dr4.w);
+            }
         }
         if(jc >= 1) // pose correctives; the root joint has none (src/BlendShape.cpp:884-887)
         {
-          const float * dR = lds + L_DR + c * 9;
-          float dr[3];
+          float dr[3][3]; // [axis][coordinate x]
+#pragma unroll
           for(int x = 0; x < 3; x++)
           {
             const float * Pv = mv.Pvm + ((int64_t)v * 3 + x) * NP + 9 * (jc - 1);
-            float s = 0.f;
-            for(int e = 0; e < 9; e++) s += Pv[e] * dR[e];
-            dr[x] = s;
+            float Pc[9];
+#pragma unroll
+            for(int e = 0; e < 9; e++) Pc[e] = Pv[e];
+#pragma unroll
+            for(int a = 0; a < 3; a++)
+            {
+              const float * dR = lds + L_DR + (3 * jc + a) * 9;
+              float sacc = 0.f;
+#pragma unroll
+              for(int e = 0; e < 9; e++) sacc += Pc[e] * dR[e];
+              dr[a][x] = sacc;
+            }
           }
-          for(int r = 0; r < 3; r++) acc[r] += (rv[3 + r * 3] * dr[0] + rv[3 + r * 3 + 1] * dr[1]) + rv[3 + r * 3 + 2] * dr[2];
+#pragma unroll
+          for(int a = 0; a < 3; a++)
+#pragma unroll
+            for(int r = 0; r < 3; r++) acc[a][r] += (rv[3 + r * 3] * dr[a][0] + rv[3 + r * 3 + 1] * dr[a][1]) + rv[3 + r * 3 + 2] * dr[a][2];
         }
+#pragma unroll
+        for(int a = 0; a < 3; a++)
+#pragma unroll
+          for(int r = 0; r < 3; r++) dpv[r * NQ + 3 + 3 * jc + a] = acc[a][r] / wsum;
       }
       else
       {
-        const int kb = q - TD75;
-        float ds[3];
+        const int kb = g - 1 - NJ;
+        float ds[3], acc[3];
         for(int x = 0; x < 3; x++) ds[x] = mv.Svm[((int64_t)v * 3 + x) * NB + kb];
         for(int r = 0; r < 3; r++) acc[r] = (rv[3 + r * 3] * ds[0] + rv[3 + r * 3 + 1] * ds[1]) + rv[3 + r * 3 + 2] * ds[2];
         for(int m = 0; m < mv.maxw; m++)
@@ -697,8 +693,8 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
           const int i = mv.wIdx[(int64_t)v * mv.maxw + m];
           for(int r = 0; r < 3; r++) acc[r] += wm * lds[L_DBB + (i * 3 + r) * NB + kb];
         }
+        for(int r = 0; r < 3; r++) dpv[r * NQ + TD75 + kb] = acc[r] / wsum;
       }
-      for(int r = 0; r < 3; r++) lds[L_DP + (r_ * 3 + r) * NQ + q] = acc[r] / rv[12];
     }
     // the column-independent half of B3n, once per adjacent face instead of once per (face, column): edges, unit normal and
     // |cross| of every face around the three vertices of each normal task (positions staged by B1)
@@ -2198,10 +2194,8 @@ struct smplpp_ik
   float *theta = nullptr, *beta = nullptr, *theta25 = nullptr, *vout = nullptr, *vjac = nullptr;
   float *verts = nullptr, *rest = nullptr, *joints = nullptr, *poserot = nullptr, *pts = nullptr;
   double *e = nullptr, *J = nullptr, *Jl = nullptr, *e2 = nullptr, *xout = nullptr;
-  int32_t * ring = nullptr;
-  int32_t * ringkey = nullptr; // [n,K] 2 * face + uses-normal the cached ring / map of a task was built for (-1: none)
-  uint8_t * map = nullptr;
   int *skip = nullptr, *status = nullptr, *sticky = nullptr, *list_cnt = nullptr, *list_f = nullptr;
+  int32_t * roles = nullptr; // [DMAX][EVAL_NT] chain-derivative entry of every thread of ik_eval_kernel at every tree level
   float * list_d = nullptr;
   std::vector<void *> owned;
   bool have_eval = false;
@@ -2246,6 +2240,10 @@ static ModelView view_of(const smplpp_model * m)
   mv.Pvm = m->Pvm;
   mv.Svm = m->Svm;
   mv.JS = m->JS;
+  mv.faceRing = m->faceRing;
+  mv.faceMap = m->faceMap;
+  mv.anc = m->anc;
+  mv.nlev = m->nlev;
   mv.V = m->V;
   mv.maxw = m->maxw;
   return mv;
@@ -2271,6 +2269,30 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   if(m->F <= 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: the model has no faces");
   if(m->nlev > DMAX) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: kinematic trees deeper than 12 levels are not supported");
   if(m->V > 65535) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: at most 65535 vertices are supported (ring tables hold 16-bit ids)");
+  if(!m->faceRing || !m->faceMap || !m->anc) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: the model carries no ring tables");
+  // the evaluation advances the chain derivatives one tree level per step with one thread per (joint of the level, ancestor
+  // depth, axis, row): the per-thread entries of every level (ik_eval_kernel: role), and every level must fit the workgroup
+  // (SMPL: at most 5 x 9 x 9 = 405 of 1024)
+  std::vector<int32_t> roles((size_t)DMAX * EVAL_NT, -1);
+  {
+    std::vector<int> depth(NJ, 0);
+    std::vector<std::vector<int>> at(NJ + 1);
+    for(int i = 0; i < NJ; i++)
+    {
+      depth[i] = i ? depth[m->h_parent[i]] + 1 : 0;
+      at[depth[i]].push_back(i);
+    }
+    for(int L = 0; L < DMAX; L++)
+    {
+      const int per = 9 * (L + 1);
+      if((int)at[L].size() * per > EVAL_NT) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: kinematic tree too wide for the evaluation kernel");
+      for(int t = 0; t < (int)at[L].size() * per; t++)
+      {
+        const int ji = t / per, rem = t % per, da = rem / 9, a9 = rem % 9, i = at[L][ji];
+        roles[(size_t)L * EVAL_NT + t] = i | ((m->h_parent[i] & 31) << 5) | ((3 * da + a9 / 3) << 10) | ((a9 % 3) << 16) | ((da == L ? 1 : 0) << 18);
+      }
+    }
+  }
   if(K > PROJ_MAXK) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: at most 48 tasks per frame are supported");
   if(TD75 + 2 * K + NB > MAXD)
     return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: too many tasks for the in-LDS solver (75 + 2K + 10 must be <= 181)");
@@ -2330,9 +2352,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   A_(J, nk * 4 * Dmax);
   A_(e2, (size_t)n);
   A_(xout, (size_t)n * Dmax);
-  A_(ring, nk * (MAXRING + 1));
-  A_(ringkey, nk);
-  A_(map, nk * 3 * MAXADJ * 3);
+  A_(roles, roles.size());
   A_(list_cnt, nk);
   A_(list_d, nk * PROJ_LIST);
   A_(list_f, nk * PROJ_LIST);
@@ -2349,7 +2369,6 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   // IkTask defaults (include/smplpp/IkTask.h:54-84)
   auto grid = [](size_t c) { return dim3((unsigned)((c + 255) / 256)); };
   HIP_TRY(hipMemset(s->ta.face, 0, sizeof(int32_t) * nk));
-  HIP_TRY(hipMemset(s->ringkey, 0xFF, sizeof(int32_t) * nk));
   fill_f32_kernel<<<grid(nk * 3), 256>>>(s->ta.vw, 1.0f / 3.0f, nk * 3);
   fill_f32_kernel<<<grid(nk * 6), 256>>>(s->ta.tang, 0.0f, nk * 6);
   fill_f32_kernel<<<grid(nk * 3), 256>>>(s->ta.tpos, 0.0f, nk * 3);
@@ -2361,6 +2380,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   HIP_TRY(hipMemset(s->theta, 0, sizeof(float) * n * s->theta_dim));
   HIP_TRY(hipMemset(s->beta, 0, sizeof(float) * n * NB));
   HIP_TRY(hipMemset(s->skip, 0, sizeof(int) * n));
+  HIP_TRY(hipMemcpy(s->roles, roles.data(), sizeof(int32_t) * roles.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(s->list_cnt, 0, sizeof(int) * nk));
   HIP_TRY(hipMemset(s->status, 0, sizeof(int) * n));
   HIP_TRY(hipMemset(s->sticky, 0, sizeof(int) * n));
@@ -2510,8 +2530,8 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   if(tsplit < 1) tsplit = 1;
   hipExtLaunchKernelGGL(ik_eval_kernel, dim3((unsigned)(n * tsplit)), dim3(EVAL_NT), shmem, st, nullptr, eval_done, 0, view_of(m), s->ta, th25,
                         (const float *)s->verts, (const float *)s->rest, (const float *)m->ws.Gp.as<float>(), (const float *)s->joints,
-                        (const float *)s->poserot, K, optimize_beta, phi_live, (int)min_valid, s->ring, s->ringkey, s->map, s->pts, s->e,
-                        s->J, s->skip, s->dbg_stop, tsplit);
+                        (const float *)s->poserot, K, optimize_beta, phi_live, (int)min_valid, s->pts, s->e,
+                        s->J, s->skip, s->dbg_stop, tsplit, s->roles);
   HIP_TRY(hipGetLastError());
   if(s->vp)
   {

