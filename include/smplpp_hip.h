@@ -179,6 +179,18 @@ int smplpp_ik_get_status(smplpp_ik * s, int32_t * flags, int space, void * strea
  * ONE caller stream (or be separated by the caller's own synchronisation).  The setters (set_tasks / set_config) are
  * host-synchronous on the NULL stream; call them only when no enqueue-only call on the solver is still in flight. */
 
+/* ------------------------------------------------------------------ multi-GPU: the final gather
+ * Frames (FK, independent IK) and restarts (capture fitting) shard across GPUs with no exchange in the data path; the only
+ * collective is the gather of result rows at the end.  `comm` is an ncclComm_t (RCCL) the HOST created — one rank per GPU,
+ * ncclCommInitRank / ncclCommInitAll — passed as an opaque pointer; RCCL is resolved at run time (the symbols already in the
+ * process, else librccl.so), so single-GPU users carry no dependency on it.  Every rank passes its block `send`
+ * [rows_per_rank[rank], row_floats] and receives all blocks in rank order in `recv` [sum rows_per_rank, row_floats] (device
+ * pointers; `send` may alias its own slot of `recv`).  Equal blocks travel as one ncclAllGather, ragged ones as grouped
+ * broadcasts; enqueued on `stream`.  What it replaces: nothing in the single-GPU reference — this is the SURVEY's proposed
+ * `smplpp_gather(comm, ...)`. */
+int smplpp_gather(void * comm, const float * send, float * recv, const int64_t * rows_per_rank, int world, int rank,
+                  int64_t row_floats, void * stream);
+
 /* ------------------------------------------------------------------ VPoser decoder (src/VPoser.cpp) */
 /* VPoserDecoderImpl (VPoser.h:53-90): Linear(32,512) LeakyReLU Dropout(eval) Linear(512,512) LeakyReLU
  * Linear(512,126) -> 6D -> rotation (Gram-Schmidt, :129-141) -> axis-angle (:25-120).  Weights are

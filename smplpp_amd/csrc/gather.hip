@@ -1,0 +1,92 @@
+// smplpp_gather: the one collective of the path for a C++ multi-GPU host — result rows of every rank,
+// in rank order, over RCCL.  RCCL is bound at run time: the symbols already loaded in the process (a host that created the
+// communicator has them), else librccl.so.
+#include "common.h"
+
+#include <dlfcn.h>
+
+namespace
+{
+using nccl_fn_allgather = int (*)(const void *, void *, size_t, int, void *, hipStream_t);
+using nccl_fn_bcast = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
+using nccl_fn_group = int (*)();
+using nccl_fn_errstr = const char * (*)(int);
+constexpr int NCCL_FLOAT32 = 7; // ncclFloat32 (rccl.h: ncclDataType_t)
+
+struct Rccl
+{
+  nccl_fn_allgather allgather = nullptr;
+  nccl_fn_bcast bcast = nullptr;
+  nccl_fn_group gstart = nullptr, gend = nullptr;
+  nccl_fn_errstr errstr = nullptr;
+  bool tried = false;
+};
+
+Rccl & rccl()
+{
+  static Rccl r;
+  if(r.tried) return r;
+  r.tried = true;
+  void * h = RTLD_DEFAULT;
+  if(!dlsym(h, "ncclAllGather"))
+  {
+    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if(!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if(!h) return r;
+  }
+  r.allgather = reinterpret_cast<nccl_fn_allgather>(dlsym(h, "ncclAllGather"));
+  r.bcast = reinterpret_cast<nccl_fn_bcast>(dlsym(h, "ncclBroadcast"));
+  r.gstart = reinterpret_cast<nccl_fn_group>(dlsym(h, "ncclGroupStart"));
+  r.gend = reinterpret_cast<nccl_fn_group>(dlsym(h, "ncclGroupEnd"));
+  r.errstr = reinterpret_cast<nccl_fn_errstr>(dlsym(h, "ncclGetErrorString"));
+  return r;
+}
+} // namespace
+
+using namespace smplpp_hip;
+
+extern "C" int smplpp_gather(void * comm, const float * send, float * recv, const int64_t * rows_per_rank, int world, int rank,
+                             int64_t row_floats, void * stream)
+{
+  if(!comm || !recv || !rows_per_rank || world <= 0 || rank < 0 || rank >= world || row_floats <= 0)
+    return fail(SMPLPP_ERR_INVALID, "smplpp_gather: bad argument");
+  Rccl & r = rccl();
+  if(!r.allgather || !r.bcast || !r.gstart || !r.gend)
+    return fail(SMPLPP_ERR_HIP, "smplpp_gather: RCCL is not available (librccl.so could not be loaded)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  bool equal = true;
+  int64_t total = 0;
+  for(int i = 0; i < world; i++)
+  {
+    if(rows_per_rank[i] < 0) return fail(SMPLPP_ERR_INVALID, "smplpp_gather: negative row count");
+    equal = equal && rows_per_rank[i] == rows_per_rank[0];
+    total += rows_per_rank[i];
+  }
+  if(total == 0) return SMPLPP_OK;
+  if(rows_per_rank[rank] > 0 && !send) return fail(SMPLPP_ERR_INVALID, "smplpp_gather: null send block");
+  auto check = [&](int rc, const char * what) -> int {
+    if(rc == 0) return (int)SMPLPP_OK;
+    return fail(SMPLPP_ERR_HIP, std::string("smplpp_gather: ") + what + " failed: " + (r.errstr ? r.errstr(rc) : "RCCL error"));
+  };
+  if(equal) // (in place when `send` is the rank's own slot of `recv`, as RCCL defines it)
+    return check(r.allgather(send, recv, (size_t)(rows_per_rank[0] * row_floats), NCCL_FLOAT32, comm, st), "ncclAllGather");
+  // ragged shards (dist.shard_sizes: the first N % world ranks hold one row more): one broadcast per rank, fused in a group
+  int rc = check(r.gstart(), "ncclGroupStart");
+  if(rc) return rc;
+  int64_t off = 0;
+  for(int i = 0; i < world; i++)
+  {
+    float * slot = recv + off * row_floats;
+    if(rows_per_rank[i] > 0)
+    {
+      const int e = r.bcast(i == rank ? (const void *)send : (const void *)slot, slot, (size_t)(rows_per_rank[i] * row_floats), NCCL_FLOAT32, i, comm, st);
+      if(e)
+      {
+        (void)r.gend();
+        return check(e, "ncclBroadcast");
+      }
+    }
+    off += rows_per_rank[i];
+  }
+  return check(r.gend(), "ncclGroupEnd");
+}
