@@ -546,12 +546,11 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
               float * xforms44, float * rest, float * poserot, hipStream_t st)
 {
   Workspace & ws = m->ws;
-  // Form of the fused kernel (m->form, from SMPLPP_SKIN at model creation; smplpp_model_set_form for A/B runs): h (default,
+  // Form of the fused kernel (m->form, from SMPLPP_SKIN at model creation): h (default,
   // skin_h.hip): fp16x2 operand pieces on the f16 matrix pipe, skinning on the matrix pipe too; b (skin_b.hip): bf16x3
   // pieces, VALU skinning in MFMA shadows; p (skin_p.hip): exact fp32 MFMA; v (skin_kernel above): the first form.
   // b needs <= 8 weights per vertex; p (32-bit output offsets) falls back to v for outputs of 2 GiB and more.
-  char form = m->form;
-  if(m->maxw > 8 && (form == 'b' || form == 'p')) form = 'v';
+  char form = m->form; // (model creation already turned b / p into v for models with more than 8 weights per vertex)
   if(form == 'p' && n * m->V * 12 >= 0x7fffff00LL) form = 'v';
   const int64_t n64 = ((n + 63) / 64) * 64;
   HIP_TRY(ws.Gp.reserve(sizeof(float) * (size_t)n64 * NJ * 12)); // b / p stage whole frame tiles of G' (padding never stored)

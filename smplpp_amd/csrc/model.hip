@@ -399,6 +399,14 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
     TRY_OR_FREE(hipGetLastError());
     TRY_OR_FREE(hipDeviceSynchronize());
   }
+  // b and p keep at most 8 weights per vertex in registers: a model with more takes the first form from here on (decided
+  // once, so that the layouts kept below are the ones the launches will read)
+  if(m->maxw > 8 && (m->form == 'b' || m->form == 'p')) m->form = 'v';
+  if(m->form != 'b' && m->B3)
+  {
+    (void)hipFree(m->B3);
+    m->B3 = nullptr;
+  }
   if(m->form == 'h' || m->form == 'b')
   {
     (void)hipFree(m->Bm); // only the fp32-MFMA forms read the K-major fp32 basis

@@ -92,11 +92,15 @@ def test_fk_batch1024_properties_and_sample(smpl, oracle_synth):
     assert np.isfinite(o).all()
 
 
-def test_fk_dense_weights_and_ragged_vertex_count():
-    """61-vertex model with all 24 skinning weights non-zero (dense path) — golden from the reference build."""
+@pytest.mark.parametrize("form", ["h", "b", "p", "v"])
+def test_fk_dense_weights_and_ragged_vertex_count(form, monkeypatch):
+    """61-vertex model with all 24 skinning weights non-zero (dense path) — golden from the reference build.  Under every
+    SMPLPP_SKIN: h takes dense weights as they are; b and p (at most 8 weights per vertex) must hand such a model to the
+    first form when it is CREATED, with the operand layout that form reads kept resident."""
     from smplpp_amd import model_io
     from smplpp_amd.smpl import SMPL
 
+    monkeypatch.setenv("SMPLPP_SKIN", form)
     g = np.load(os.path.join(GOLDEN, "fk_tiny.npz"))
     s = SMPL()
     s.setDevice("cuda:0")
