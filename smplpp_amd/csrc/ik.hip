@@ -224,6 +224,13 @@ constexpr int L_VN = L_DP + RCAP * 3 * NQ;     // per such task: [3][3] vertex n
 constexpr int L_END = L_VN + 12 * NGN;
 constexpr int L_ANC_BYTES = NJ * 4;            // int anc[24] (ancestor bit masks; depth = popcount - 1) after the float region
 
+// workgroup barrier that orders LDS traffic only: global stores issued before it may still be in flight (__syncthreads
+// waits for them too — one HBM round trip per barrier behind every phase that writes results out)
+__device__ inline void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 #ifndef SMPLPP_EVAL_NT
 #define SMPLPP_EVAL_NT 1024
 #endif
@@ -411,6 +418,47 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
     if(q == 0) s_usen[t] = use_normal ? 1 : 0;
   }
   __syncthreads();
+  __shared__ int s_rcum[IK_MAXK + 1]; // ring sizes of the workgroup's tasks, cumulated (offsets of the groups' ring buffers)
+  __shared__ int s_gk[IK_MAXK + 1], s_ng; // phase B's task groups: first task of each (relative to k_begin), their number
+  static_assert(IK_MAXK < 64, "one wavefront scans the ring sizes");
+  if(tid < 64)
+  {
+    const int cnt_l = (tid < ntask) ? (int)s_ringb[tid][0] : 0, usen_l = (tid < ntask) ? (int)s_usen[tid] : 0;
+    int incl = cnt_l;
+    for(int o = 1; o < 64; o <<= 1)
+    {
+      const int up = __shfl_up(incl, o, 64);
+      if(tid >= o) incl += up;
+    }
+    if(tid < ntask) s_rcum[tid + 1] = incl;
+    if(tid == 0) s_rcum[0] = 0;
+    // task groups of phase B, greedy by ring size: tasks with a normal term or offset (ring: the face's vertices and those of
+    // their adjacent faces) go NGN to a group when their rings fit the LDS buffers together, position-only tasks (ring 3) as
+    // many as fit; the two kinds are not mixed.  The wavefront walks the tasks in step, sizes out of registers (v_readlane).
+    int ng = 0, k = 0;
+    while(k < ntask)
+    {
+      k = __builtin_amdgcn_readfirstlane(k);
+      if(tid == 0) s_gk[ng] = k;
+      ng++;
+      const int gn = __builtin_amdgcn_readlane(usen_l, k);
+      int tot = 0, k2 = k;
+      while(k2 < ntask)
+      {
+        k2 = __builtin_amdgcn_readfirstlane(k2);
+        const int nrk = __builtin_amdgcn_readlane(cnt_l, k2), un2 = __builtin_amdgcn_readlane(usen_l, k2);
+        if(k2 > k && (tot + nrk > RCAP || un2 != gn || (gn && k2 - k >= (dbg_stop == 40 ? 1 : NGN)))) break; // (40: dev switch, one per group)
+        tot += nrk;
+        k2++;
+      }
+      k = k2;
+    }
+    if(tid == 0)
+    {
+      s_gk[ng] = ntask;
+      s_ng = ng;
+    }
+  }
   EVAL_STAMP(3);
   if(dbg_stop == 23) return;
   for(int item = tid; item < ntask * MAXRING; item += EVAL_NT) // A1
@@ -427,10 +475,30 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   __syncthreads();
   EVAL_STAMP(4);
   if(dbg_stop == 24) return;
-  if(tid < 3 * ntask) // A2: SMPL::calcVertexNormal (src/SMPL.cpp:527-535) with the adjacent faces' corners taken by ring slot
+  // A2: SMPL::calcVertexNormal (src/SMPL.cpp:527-535) with the adjacent faces' corners taken by ring slot — the unit normals
+  // of the adjacent faces one thread per (task, triangle vertex, adjacent face), then the uniform sum per vertex in the
+  // reference's order
+  static_assert((IK_MAXK * MAXRING * 3 + IK_MAXK * 3 * MAXADJ * 3) <= RCAP * 3 * NQ, "s_rpos + s_fn must fit the L_DP region");
+  float(*s_fn)[3 * MAXADJ][3] = reinterpret_cast<float(*)[3 * MAXADJ][3]>(lds + L_DP + IK_MAXK * MAXRING * 3);
+  for(int item = tid; item < ntask * 3 * MAXADJ; item += EVAL_NT)
   {
-    const int t = tid / 3, i = tid % 3, k = k_begin + t;
-    if(ta.noff[tb + k] > 0.0f || ta.nrmw[tb + k] > 0.0f)
+    const int t = item / (3 * MAXADJ), ia = item % (3 * MAXADJ), i = ia / MAXADJ, a2 = ia % MAXADJ, k = k_begin + t;
+    if(s_usen[t])
+    {
+      const int u = s_ringb[t][1 + i];
+      const int cnt = mv.adjOff[u + 1] - mv.adjOff[u];
+      if(a2 < cnt && cnt <= MAXADJ)
+      {
+        const uint8_t * mp = mv.faceMap + (int64_t)ta.face[tb + k] * (3 * MAXADJ * 3) + ia * 3;
+        face_normal_pts(s_rpos[t][mp[0]], s_rpos[t][mp[1]], s_rpos[t][mp[2]], s_fn[t][ia]);
+      }
+    }
+  }
+  __syncthreads();
+  if(tid < 3 * ntask)
+  {
+    const int t = tid / 3, i = tid % 3;
+    if(s_usen[t])
     {
       const int u = s_ringb[t][1 + i];
       const int b0 = mv.adjOff[u], cnt = mv.adjOff[u + 1] - b0;
@@ -439,16 +507,13 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
         vertex_normal_dev(verts, mv.faces, mv.adjOff, mv.adjFace, u, vn);
       else
       {
-        const uint8_t * map = mv.faceMap + (int64_t)ta.face[tb + k] * (3 * MAXADJ * 3);
         float sum = 0.0f;
         for(int q = 0; q < cnt; q++) sum += 1.0f;
         const float w = 1.0f / sum;
         float acc[3] = {0.f, 0.f, 0.f};
         for(int a2 = 0; a2 < cnt; a2++)
         {
-          const uint8_t * mp = map + (i * MAXADJ + a2) * 3;
-          float fn[3];
-          face_normal_pts(s_rpos[t][mp[0]], s_rpos[t][mp[1]], s_rpos[t][mp[2]], fn);
+          const float * fn = s_fn[t][i * MAXADJ + a2];
           acc[0] += w * fn[0];
           acc[1] += w * fn[1];
           acc[2] += w * fn[2];
@@ -519,7 +584,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   }
   EVAL_STAMP(6);
   if(dbg_stop == 28) return;
-  __syncthreads();
+  lds_barrier(); // (global stores of this phase stay in flight: nothing reads them before the next full barrier)
 
   if(dbg_stop == 22) return;
   // ---- phase B: Jacobian rows (node.cpp:823-873).  Tasks are taken in GROUPS whose ring vertices fit the LDS buffers
@@ -527,45 +592,33 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   // touches up to MAXRING and forms a group of its own): each barrier-separated step then serves the whole group, and the
   // global-memory latencies of the tasks overlap instead of queueing.
   __shared__ int s_roff[IK_MAXK + 1]; // ring offset of task k inside its group's buffers
-  __shared__ int s_rtask[RCAP];         // ring slot -> task
   __shared__ int s_rvert[RCAP];         // ring slot -> vertex
   __shared__ uint8_t s_map[NGN][3 * MAXADJ * 3]; // (vertex of the face, adjacent face, corner) -> slot in the task's ring, per normal task
   __shared__ int s_cnt[NGN][3];         // adjacent-face count of the face's three vertices
   __shared__ float s_nrm[NGN][NQ * 3 * 6]; // per (column, triangle vertex): vertex normal (3) and its derivative (3)
   __shared__ __attribute__((aligned(16))) float s_geo[NGN][3 * MAXADJ][12]; // per adjacent face of a triangle vertex: unit normal, |cross|, edges e1, e2
   static_assert(EVAL_NT >= 64 + NGN * 128 + NGN * 4, "B1 hands the map / count loads to thread ranges beyond the ring threads");
-  for(int k_lo = k_begin; k_lo < k_end;)
+  for(int g = 0; g < s_ng; g++)
   {
-    // group [k_lo, k_hi): greedy by ring size (every thread computes the same bounds)
-    // Tasks with a normal term or offset (ring: the face's vertices and those of their adjacent faces) go NGN to a group when
-    // their rings fit together, position-only tasks (ring 3) as many as fit; the two kinds are not mixed.
-    int k_hi = k_lo, total = 0;
-    bool grp_normal = false;
-    while(k_hi < k_end)
-    {
-      const int nrk = s_ringb[k_hi - k_begin][0];
-      const bool isn = s_usen[k_hi - k_begin] != 0; // the task differentiates a normal
-      if(k_hi == k_lo)
-        grp_normal = isn;
-      else if(total + nrk > RCAP || isn != grp_normal || (grp_normal && k_hi - k_lo >= (dbg_stop == 40 ? 1 : NGN))) // (40: dev switch, one per group)
-        break;
-      total += nrk;
-      k_hi++;
-    }
+    // group [k_lo, k_hi) from the list thread 0 made behind the ring-size scan (with 16 wavefronts, bounds every thread
+    // works out for itself cost the workgroup 16 issue slots per instruction)
+    const int k_lo = k_begin + s_gk[g], k_hi = k_begin + s_gk[g + 1];
+    const int total = s_rcum[k_hi - k_begin] - s_rcum[k_lo - k_begin];
+    const bool grp_normal = s_usen[k_lo - k_begin] != 0;
     const int ngn = grp_normal ? k_hi - k_lo : 0; // normal tasks of this group (their index in the group: k - k_lo)
-    if((int)tid >= k_lo && (int)tid < k_hi) // ring tables of the group
     {
-      int off0 = 0;
-      for(int kk = k_lo; kk < (int)tid; kk++) off0 += s_ringb[kk - k_begin][0];
-      const uint16_t * rg = s_ringb[tid - k_begin];
-      s_roff[tid] = off0;
-      for(int i = 0; i < rg[0]; i++)
+      // ring tables of the group: offsets from the cumulated sizes, one thread per (task, ring slot)
+      const int gbase = s_rcum[k_lo - k_begin];
+      for(int item = tid; item < (k_hi - k_lo) * MAXRING; item += EVAL_NT)
       {
-        s_rtask[off0 + i] = tid;
-        s_rvert[off0 + i] = rg[1 + i];
+        const int kk = k_lo + item / MAXRING, i = item % MAXRING;
+        const uint16_t * rg = s_ringb[kk - k_begin];
+        const int off0 = s_rcum[kk - k_begin] - gbase;
+        if(i == 0) s_roff[kk] = off0;
+        if(i < rg[0]) s_rvert[off0 + i] = rg[1 + i];
       }
     }
-    __syncthreads();
+    lds_barrier(); // (global stores of this phase stay in flight: nothing reads them before the next full barrier)
     if(k_lo == k_begin) EVAL_STAMP(8);
 
     if(tid < total) // B1: per ring vertex rest position, blended rotation, blended w
@@ -835,7 +888,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
       if(c / 2 != k || !(phi_live && plim > 0.0f))
         for(int r = 0; r < 4; r++) Jk[(int64_t)r * D + TD75 + c] = 0.0;
     }
-    __syncthreads();
+    lds_barrier(); // (global stores of this phase stay in flight: nothing reads them before the next full barrier)
     if(k_lo == k_begin) EVAL_STAMP(12);
     if(tid < 2 * (k_hi - k_lo)) // B4: d/dphi through calcTriangleVertexWeights (vertices detached)
     {
@@ -892,9 +945,8 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
         Jk[(int64_t)3 * D + TD75 + 2 * k + c] = (wn > 0.0f) ? (double)(wn * ndot) : 0.0;
       }
     }
-    __syncthreads();
+    lds_barrier();
     if(k_lo == k_begin) EVAL_STAMP(13);
-    k_lo = k_hi;
   }
   EVAL_STAMP(7);
 }
