@@ -232,10 +232,12 @@ __device__ inline void lds_barrier()
 }
 
 #ifndef SMPLPP_EVAL_NT
-#define SMPLPP_EVAL_NT 1024
+#define SMPLPP_EVAL_NT 768
 #endif
 // threads per workgroup of ik_eval_kernel: one workgroup per frame owns a CU (152 KB of LDS), and its phases are bound by
-// memory latency and per-item instruction count, so more wavefronts per SIMD both hide latency and shorten the item loops
+// memory latency and per-item instruction count, so more wavefronts per SIMD both hide latency and shorten the item loops —
+// but every instruction all threads execute alike (phase set-up, loop control) costs one issue slot per wavefront: 12
+// wavefronts (170 registers each, nothing spilled) beat 16 by 5 % and 8 by 1 % on the 6-target solve
 constexpr int EVAL_NT = SMPLPP_EVAL_NT;
 #ifdef SMPLPP_EVAL_STAMPS
 __device__ unsigned long long g_eval_stamps[64 * 16];
@@ -320,10 +322,12 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
   {
     const int * s_lvl = s_tree + TREE_LVL, * s_lvlj = s_tree + TREE_LVLJ;
     float * dgl = lds + L_DP; // [24][3][NB]
-    static_assert(EVAL_NT >= 512 + NJ * NB, "the beta columns take threads 512..");
+    // (beside the chain entries' threads when the workgroup is large enough, else sharing threads with them)
+    constexpr int BETA_T0 = (EVAL_NT >= 512 + NJ * NB) ? 512 : EVAL_NT - 256;
+    static_assert(BETA_T0 >= 0 && BETA_T0 + NJ * NB <= EVAL_NT, "the beta columns take NJ * NB threads from BETA_T0");
     // beta columns: thread (joint i, k) works at the joint's level; its regressor rows are loaded ahead of the steps
-    const bool isb = optimize_beta && tid >= 512 && tid < 512 + NJ * NB;
-    const int bi = isb ? (tid - 512) / NB : 0, bk = isb ? (tid - 512) % NB : 0, bp = s_par[bi];
+    const bool isb = optimize_beta && tid >= BETA_T0 && tid < BETA_T0 + NJ * NB;
+    const int bi = isb ? (tid - BETA_T0) / NB : 0, bk = isb ? (tid - BETA_T0) % NB : 0, bp = s_par[bi];
     const int blev = isb ? __popc(sAnc[bi]) - 1 : -1;
     float dj[3] = {0.f, 0.f, 0.f}, dt[3] = {0.f, 0.f, 0.f};
     if(isb)
