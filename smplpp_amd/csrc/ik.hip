@@ -245,13 +245,40 @@ __device__ unsigned long long g_eval_stamps[64 * 16];
 #else
 #define EVAL_STAMP(i) do {} while(0)
 #endif
-__global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ theta25,
-                                                      const float * __restrict__ verts_all, const float * __restrict__ rest_all,
-                                                      const float * __restrict__ Gp, const float * __restrict__ joints,
-                                                      const float * __restrict__ poserot, int K, int optimize_beta,
-                                                      int phi_live, int min_valid, float * __restrict__ pos804,
-                                                      double * __restrict__ e_out, double * __restrict__ J_out,
-                                                      int * __restrict__ skip, int dbg_stop, int tsplit, const int32_t * __restrict__ roles)
+// Cross-stream hand-over through a device flag (the other stream waits with hipStreamWaitValue32): every workgroup of the
+// producing kernel ends here; the last one to arrive publishes `tick`.  Measured on MI355X (tools/micro/waitvalue_cost.hip,
+// join_cost.hip): the waiting stream's next kernel starts 1.4 us after the flag is written, against 11.6 us after an event
+// recorded by the producer's stream fires (3.7 us when that event had fired more than 10 us before the waiter arrived).
+// What the consumer kernels read from the producer is written with st_agent (write-through to the device's coherence point),
+// so a workgroup only has to wait for its own stores: a device-scope release fence per workgroup would write back the whole
+// L2 of its XCD 256 times per kernel — including the lines of the kernel running beside it (the fused FK kernel went from 17
+// to 28 us that way).
+template<class T>
+__device__ inline void st_agent(T * p, T v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void wg_signal(unsigned * __restrict__ flag, unsigned * __restrict__ counter, unsigned tick)
+{
+  if(!flag) return;
+  __syncthreads(); // every thread's stores are issued and complete (s_waitcnt vmcnt(0) in front of the barrier)
+  if(threadIdx.x == 0)
+  {
+    if(__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+    {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(flag, tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+__device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArrays & ta, const float * __restrict__ theta25,
+                                             const float * __restrict__ verts_all, const float * __restrict__ rest_all,
+                                             const float * __restrict__ Gp, const float * __restrict__ joints,
+                                             const float * __restrict__ poserot, int K, int optimize_beta,
+                                             int phi_live, int min_valid, float * __restrict__ pos804,
+                                             double * __restrict__ e_out, double * __restrict__ J_out,
+                                             int * __restrict__ skip, int dbg_stop, int tsplit, const int32_t * __restrict__ roles)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_tree[TREE_SIZE];
@@ -286,7 +313,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
     if(tid < K && ta.posw[tb + tid] > 0.0f) atomicAdd(&s_valid, 1);
     __syncthreads();
     const int sk = (s_valid < min_valid) ? 1 : 0;
-    if(tid == 0) skip[f] = sk;
+    if(tid == 0) st_agent(&skip[f], sk); // (read by kernels of the other stream: see wg_signal)
     if(sk) return;
   }
 
@@ -578,13 +605,13 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
       ta.tang[(tb + k) * 6 + x * 2 + 1] = t2[x];
       pos804[(tb + k) * 3 + x] = pos[x];
       ta.vw[(tb + k) * 3 + x] = w[x];
-      ta.apos[(tb + k) * 3 + x] = ap[x];
+      st_agent(&ta.apos[(tb + k) * 3 + x], ap[x]);
       e_out[(f * K + k) * 4 + x] = (double)(wp * (ap[x] - tp[x])); // node.cpp:807
     }
     e_out[(f * K + k) * 4 + 3] = e3;
     // the re-projection's cull radius when the query point is the actual position (no surface coordinate can move): the
     // exact distance to the task's own face, from the vertices already in registers (same evaluation as the scan's)
-    ta.hint[tb + k] = tri_sqdist_vals(tri[0], tri[1], tri[2], tri[3], tri[4], tri[5], tri[6], tri[7], tri[8], ap[0], ap[1], ap[2]).x;
+    st_agent(&ta.hint[tb + k], tri_sqdist_vals(tri[0], tri[1], tri[2], tri[3], tri[4], tri[5], tri[6], tri[7], tri[8], ap[0], ap[1], ap[2]).x);
   }
   EVAL_STAMP(6);
   if(dbg_stop == 28) return;
@@ -953,6 +980,20 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
     if(k_lo == k_begin) EVAL_STAMP(13);
   }
   EVAL_STAMP(7);
+}
+
+__global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ theta25,
+                                                      const float * __restrict__ verts_all, const float * __restrict__ rest_all,
+                                                      const float * __restrict__ Gp, const float * __restrict__ joints,
+                                                      const float * __restrict__ poserot, int K, int optimize_beta,
+                                                      int phi_live, int min_valid, float * __restrict__ pos804,
+                                                      double * __restrict__ e_out, double * __restrict__ J_out,
+                                                      int * __restrict__ skip, int dbg_stop, int tsplit, const int32_t * __restrict__ roles,
+                                                      unsigned * __restrict__ sig_flag, unsigned * __restrict__ sig_counter, unsigned sig_tick)
+{
+  ik_eval_body(mv, ta, theta25, verts_all, rest_all, Gp, joints, poserot, K, optimize_beta, phi_live, min_valid, pos804, e_out, J_out, skip,
+               dbg_stop, tsplit, roles);
+  wg_signal(sig_flag, sig_counter, sig_tick); // (every exit of the body comes through here: a waiting stream is never left behind)
 }
 
 __global__ void ik_actual_normals_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all, int K, int64_t nk)
@@ -2132,11 +2173,11 @@ __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays
   }
 }
 
-__global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all,
-                                                           const float * __restrict__ pts, int64_t F, int K,
-                                                           const int * __restrict__ skip, int * __restrict__ list_cnt,
-                                                           const float * __restrict__ list_d, const int * __restrict__ list_f,
-                                                           int * __restrict__ dbg, int tsplit)
+__device__ __forceinline__ void proj_finish_body(const ModelView & mv, const TaskArrays & ta, const float * __restrict__ verts_all,
+                                                 const float * __restrict__ pts, int64_t F, int K,
+                                                 const int * __restrict__ skip, int * __restrict__ list_cnt,
+                                                 const float * __restrict__ list_d, const int * __restrict__ list_f,
+                                                 int * __restrict__ dbg, int tsplit)
 {
   // grid = n * tsplit: with few frames per GPU a frame's tasks are shared out (see ik_eval_kernel); the exhaustive fallback
   // below is sequential over a workgroup's tasks
@@ -2206,9 +2247,20 @@ __global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArra
       for(int x = 0; x < 3; x++) tri[i * 3 + x] = verts[3 * mv.faces[face * 3 + i] + x];
     (void)tri_sqdist_dev(verts, mv.faces, face, pts + (tb + k) * 3, c);
     triangle_weights_dev(c, tri, w); // calcVertexWeights(closest point), phi_ == 0 (:997-998)
-    ta.face[tb + k] = face;
-    for(int i = 0; i < 3; i++) ta.vw[(tb + k) * 3 + i] = w[i];
+    st_agent(&ta.face[tb + k], face); // (read by the evaluation on the other stream: see wg_signal)
+    for(int i = 0; i < 3; i++) st_agent(&ta.vw[(tb + k) * 3 + i], w[i]);
   }
+}
+
+__global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all,
+                                                           const float * __restrict__ pts, int64_t F, int K,
+                                                           const int * __restrict__ skip, int * __restrict__ list_cnt,
+                                                           const float * __restrict__ list_d, const int * __restrict__ list_f,
+                                                           int * __restrict__ dbg, int tsplit, unsigned * __restrict__ sig_flag,
+                                                           unsigned * __restrict__ sig_counter, unsigned sig_tick)
+{
+  proj_finish_body(mv, ta, verts_all, pts, F, K, skip, list_cnt, list_d, list_f, dbg, tsplit);
+  wg_signal(sig_flag, sig_counter, sig_tick);
 }
 
 __global__ void fill_f32_kernel(float * p, float v, int64_t n)
@@ -2265,7 +2317,12 @@ struct smplpp_ik
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool phi_locked = false;
-  bool side_pending = false; // a finish kernel is in flight on the side stream; ev_join marks its end
+  bool side_pending = false; // a finish kernel is in flight on the side stream; ev_join / the join flag marks its end
+  // hand-over between the two streams through device flags (wg_signal + hipStreamWaitValue32) instead of events: [0] fork
+  // flag, [16] its workgroup counter, [32] join flag, [48] its counter (one 64-byte line each)
+  unsigned * sig = nullptr;
+  unsigned tick_fork = 0, tick_join = 0;
+  bool use_flags = false;
   // development switches, read ONCE at creation (never in the per-call path): SMPLPP_DEBUG_SYNC, SMPLPP_IK_DBG_STOP,
   // SMPLPP_IK_OVERLAP=0 (re-projection behind the solve on one stream), SMPLPP_SCAN_BLOCKS
   bool dbg_sync = false, overlap_ok = true;
@@ -2444,6 +2501,17 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+  {
+    HIP_TRY(dalloc(s, &s->sig, 64));
+    HIP_TRY(hipMemset(s->sig, 0, sizeof(unsigned) * 64));
+    // stream memory operations are optional in HIP: probe once (flag 0 >= 0 is satisfied at once); SMPLPP_IK_EVENTS=1 keeps events
+    const char * e = getenv("SMPLPP_IK_EVENTS");
+    if(!(e && e[0] != '0'))
+    {
+      s->use_flags = hipStreamWaitValue32(s->side, s->sig, 0u, hipStreamWaitValueGte, 0xffffffffu) == hipSuccess;
+      (void)hipGetLastError();
+    }
+  }
   HIP_TRY(hipDeviceSynchronize());
   *out = s;
   return SMPLPP_OK;
@@ -2575,7 +2643,10 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   if(rc) return rc;
   if(s->side_pending) // the previous iteration's re-projection (side stream) wrote the faces / weights read from here on
   {
-    HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
+    if(s->use_flags)
+      HIP_TRY(hipStreamWaitValue32(st, s->sig + 32, s->tick_join, hipStreamWaitValueGte, 0xffffffffu));
+    else
+      HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
     s->side_pending = false;
   }
   const size_t shmem = sizeof(float) * L_END + L_ANC_BYTES;
@@ -2584,10 +2655,14 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   int tsplit = (n < 256) ? (int)(256 / n) : 1; // one round of workgroups (one per CU: 83 KB of LDS each)
   if(tsplit > K) tsplit = K;
   if(tsplit < 1) tsplit = 1;
-  hipExtLaunchKernelGGL(ik_eval_kernel, dim3((unsigned)(n * tsplit)), dim3(EVAL_NT), shmem, st, nullptr, eval_done, 0, view_of(m), s->ta, th25,
+  const bool fork_flag = eval_done && s->use_flags; // the side stream waits for this evaluation: flag instead of the event
+  if(fork_flag) s->tick_fork++;
+  hipExtLaunchKernelGGL(ik_eval_kernel, dim3((unsigned)(n * tsplit)), dim3(EVAL_NT), shmem, st, nullptr, fork_flag ? nullptr : eval_done, 0,
+                        view_of(m), s->ta, th25,
                         (const float *)s->verts, (const float *)s->rest, (const float *)m->ws.Gp.as<float>(), (const float *)s->joints,
                         (const float *)s->poserot, K, optimize_beta, phi_live, (int)min_valid, s->pts, s->e,
-                        s->J, s->skip, s->dbg_stop, tsplit, s->roles);
+                        s->J, s->skip, s->dbg_stop, tsplit, s->roles, fork_flag ? s->sig : (unsigned *)nullptr,
+                        fork_flag ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork);
   HIP_TRY(hipGetLastError());
   if(s->vp)
   {
@@ -2685,7 +2760,10 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
       hipStream_t pst = st;
       if(beside)
       {
-        HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+        if(s->use_flags)
+          HIP_TRY(hipStreamWaitValue32(s->side, s->sig, s->tick_fork, hipStreamWaitValueGte, 0xffffffffu));
+        else
+          HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
         pst = s->side;
       }
       int chunks = (int)(scan_blocks / s->n);
@@ -2705,9 +2783,13 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
       int fsplit = (s->n < 256) ? (int)(256 / s->n) : 1;
       if(fsplit > K) fsplit = K;
       if(fsplit < 1) fsplit = 1;
-      hipExtLaunchKernelGGL(proj_finish_kernel, dim3((unsigned)(s->n * fsplit)), dim3(256), 0, pst, nullptr, beside ? s->ev_join : nullptr, 0,
+      const bool join_flag = beside && s->use_flags;
+      if(join_flag) s->tick_join++;
+      hipExtLaunchKernelGGL(proj_finish_kernel, dim3((unsigned)(s->n * fsplit)), dim3(256), 0, pst, nullptr,
+                            (beside && !join_flag) ? s->ev_join : nullptr, 0,
                             view_of(m), s->ta, (const float *)s->verts, qpts, m->F, K, (const int *)s->skip, s->list_cnt, s->list_d,
-                            s->list_f, dbg ? dbg_buf : (int *)nullptr, fsplit);
+                            s->list_f, dbg ? dbg_buf : (int *)nullptr, fsplit, join_flag ? s->sig + 32 : (unsigned *)nullptr,
+                            join_flag ? s->sig + 48 : (unsigned *)nullptr, s->tick_join);
       HIP_TRY(hipGetLastError());
       if(beside) s->side_pending = true;
       if(dbg)
@@ -2727,7 +2809,10 @@ static int ik_join(smplpp_ik * s, hipStream_t st)
 {
   if(s->side_pending) // everything the caller does next on its stream is ordered behind the last re-projection
   {
-    HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
+    if(s->use_flags)
+      HIP_TRY(hipStreamWaitValue32(st, s->sig + 32, s->tick_join, hipStreamWaitValueGte, 0xffffffffu));
+    else
+      HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
     s->side_pending = false;
   }
   return SMPLPP_OK;

@@ -397,7 +397,7 @@ def _run_ik(smpl, g, n, iters, env, monkeypatch, **kw):
     """theta / beta / faces after `iters` iterations from seeded perturbed starts under the given environment switches."""
     from smplpp_amd.ik import IkSolver
 
-    for k in ("SMPLPP_IK_DBG_STOP", "SMPLPP_IK_OVERLAP"):
+    for k in ("SMPLPP_IK_DBG_STOP", "SMPLPP_IK_OVERLAP", "SMPLPP_IK_EVENTS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -422,8 +422,13 @@ def test_ik_reprojection_beside_the_solve_is_bit_identical(smpl, golden_ik_synth
     b = _run_ik(smpl, golden_ik_synth, 96, 12, {}, monkeypatch, **kw)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+    # the two streams hand over through device flags (hipStreamWaitValue32 on a word the producing kernel's last workgroup
+    # writes; what the consumers read is stored write-through): the event-based hand-over must give the same bits
+    c = _run_ik(smpl, golden_ik_synth, 96, 12, {"SMPLPP_IK_EVENTS": "1"}, monkeypatch, **kw)
+    for x, y in zip(a, c):
+        assert np.array_equal(x, y)
     # one iteration per call (the capture-fitting driver's pattern): the join at the end of every call
-    for k in ("SMPLPP_IK_DBG_STOP", "SMPLPP_IK_OVERLAP"):
+    for k in ("SMPLPP_IK_DBG_STOP", "SMPLPP_IK_OVERLAP", "SMPLPP_IK_EVENTS"):
         monkeypatch.delenv(k, raising=False)
     from smplpp_amd.ik import IkSolver
 
