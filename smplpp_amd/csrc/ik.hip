@@ -2320,6 +2320,7 @@ struct smplpp_ik
   bool side_pending = false; // a finish kernel is in flight on the side stream; ev_join / the join flag marks its end
   // hand-over between the two streams through device flags (wg_signal + hipStreamWaitValue32) instead of events: [0] fork
   // flag, [16] its workgroup counter, [32] join flag, [48] its counter (one 64-byte line each)
+  int * dbg_buf = nullptr;
   unsigned * sig = nullptr;
   unsigned tick_fork = 0, tick_join = 0;
   bool use_flags = false;
@@ -2702,6 +2703,14 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
   HIP_TRY(lds_opt_in(once_solve[0], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false>), (int)SOLVE_LDS_MAX));
   HIP_TRY(lds_opt_in(once_solve[1], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<true>), (int)SOLVE_LDS_MAX));
   HIP_TRY(lds_opt_in(once_solve[2], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false, 11>), (int)SOLVE_LDS_MAX));
+  if(s->use_flags && (s->tick_fork > 0x7fff0000u || s->tick_join > 0x7fff0000u))
+  {
+    // the hand-over flags carry iteration numbers compared with >=: start over long before they could wrap
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipStreamSynchronize(s->side));
+    HIP_TRY(hipMemset(s->sig, 0, sizeof(unsigned) * 64));
+    s->tick_fork = s->tick_join = 0;
+  }
   const bool dbg = s->dbg_sync;
   const int dbg_stop = s->dbg_stop;
   const bool overlap_ok = s->overlap_ok;
@@ -2777,8 +2786,8 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
       else SCAN_(0);
 #undef SCAN_
       HIP_TRY(hipGetLastError());
-      static int * dbg_buf = nullptr;
-      if(dbg && !dbg_buf) HIP_TRY(hipMalloc((void **)&dbg_buf, sizeof(int) * 8));
+      int *& dbg_buf = s->dbg_buf; // (SMPLPP_DEBUG_SYNC only; owned by the solver, on its device)
+      if(dbg && !dbg_buf) HIP_TRY(dalloc(s, &dbg_buf, 8));
       if(dbg) HIP_TRY(hipMemsetAsync(dbg_buf, 0, sizeof(int) * 8, st));
       int fsplit = (s->n < 256) ? (int)(256 / s->n) : 1;
       if(fsplit > K) fsplit = K;
