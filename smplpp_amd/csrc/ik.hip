@@ -305,38 +305,48 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   const int per_part = (K + tsplit - 1) / tsplit;
   const int k_begin = part * per_part, k_end = (k_begin + per_part < K) ? k_begin + per_part : K;
 
-  // node.cpp:785 — a frame with too few valid markers skips the whole solve block (no task refresh either)
+  // ---- set-up: every global load first (one round trip), then the frame constants into LDS
+  static_assert(EVAL_NT >= NJ * 12 && IK_MAXK <= 64, "one element of each frame constant per thread; validity by one ballot");
+  __shared__ int s_valid;
   {
-    __shared__ int s_valid;
-    if(tid == 0) s_valid = 0;
-    __syncthreads();
-    if(tid < K && ta.posw[tb + tid] > 0.0f) atomicAdd(&s_valid, 1);
+    const float pw = (tid < K) ? ta.posw[tb + tid] : 0.0f;
+    const float vR = (tid < NJ * 9) ? poserot[f * NJ * 9 + tid] : 0.0f;
+    const float vJ = (tid < NJ * 3) ? joints[f * NJ * 3 + tid] : 0.0f;
+    const float vG = (tid < NJ * 12) ? Gp[f * NJ * 12 + tid] : 0.0f;
+    // tree tables of the model (common.h TREE_*): ancestor masks (with the joint itself; depth(i) = popcount - 1), joints by level
+    const int vT = (tid < TREE_SIZE) ? mv.anc[tid] : 0;
+    const int vP = (tid < NJ) ? mv.parent[tid] : 0;
+    float th[3] = {0.f, 0.f, 0.f};
+    if(tid < 72)
+      for(int x = 0; x < 3; x++) th[x] = theta25[(f * (NJ + 1) + 1 + tid / 3) * 3 + x];
+    // node.cpp:785 — a frame with too few valid markers skips the whole solve block (no task refresh either)
+    if(tid < 64)
+    {
+      const unsigned long long m = __ballot(tid < K && pw > 0.0f);
+      if(tid == 0) s_valid = __popcll(m);
+    }
+    if(tid < NJ * 9) lds[L_R + tid] = vR;
+    if(tid < NJ * 3) lds[L_J + tid] = vJ;
+    if(tid < NJ * 12) lds[L_G + tid] = vG;
+    if(tid < TREE_SIZE) s_tree[tid] = vT;
+    if(tid < NJ) s_par[tid] = vP;
     __syncthreads();
     const int sk = (s_valid < min_valid) ? 1 : 0;
     if(tid == 0) st_agent(&skip[f], sk); // (read by kernels of the other stream: see wg_signal)
     if(sk) return;
+    if(tid < NJ * 3)
+    {
+      const int j = tid / 3, x = tid % 3, p = s_par[j];
+      lds[L_T + tid] = (j == 0) ? lds[L_J + x] : lds[L_J + tid] - lds[L_J + p * 3 + x];
+    }
+    if(tid < 72)
+    {
+      float dR[9];
+      rodrigues_grad_dev(th, tid % 3, dR);
+      for(int q = 0; q < 9; q++) lds[L_DR + tid * 9 + q] = dR[q];
+    }
+    __syncthreads();
   }
-
-  // ---- frame constants into LDS
-  for(int i = tid; i < NJ * 9; i += EVAL_NT) lds[L_R + i] = poserot[f * NJ * 9 + i];
-  for(int i = tid; i < NJ * 3; i += EVAL_NT) lds[L_J + i] = joints[f * NJ * 3 + i];
-  for(int i = tid; i < NJ * 12; i += EVAL_NT) lds[L_G + i] = Gp[f * NJ * 12 + i];
-  // tree tables of the model (common.h TREE_*): ancestor masks (with the joint itself; depth(i) = popcount - 1), joints by level
-  for(int i = tid; i < TREE_SIZE; i += EVAL_NT) s_tree[i] = mv.anc[i];
-  if(tid < NJ) s_par[tid] = mv.parent[tid];
-  __syncthreads();
-  for(int i = tid; i < NJ * 3; i += EVAL_NT)
-  {
-    const int j = i / 3, x = i % 3, p = mv.parent[j];
-    lds[L_T + i] = (j == 0) ? lds[L_J + x] : lds[L_J + i] - lds[L_J + p * 3 + x];
-  }
-  if(tid < 72)
-  {
-    float dR[9];
-    rodrigues_grad_dev(theta25 + (f * (NJ + 1) + 1 + tid / 3) * 3, tid % 3, dR);
-    for(int q = 0; q < 9; q++) lds[L_DR + tid * 9 + q] = dR[q];
-  }
-  __syncthreads();
 
   EVAL_STAMP(1);
   if(dbg_stop == 20) return; // (timing experiments only: SMPLPP_IK_DBG_STOP)
