@@ -465,16 +465,21 @@ __global__ __launch_bounds__(256) void vposer_jac_kernel(const float * __restric
 #pragma unroll
         for(int p = 0; p < 2; p++) st[sidx][t][p] = *reinterpret_cast<const v4fv *>(ap + (size_t)t * (32 * 2048) + ks * 2048 + p * 1024);
     };
-    load_stage(0, 0);
-    load_stage(1, 1);
-    load_stage(2, 2);
+    // every workgroup reads the same 1 MB at the same time: each starts its k loop at its own offset, so that at any instant the
+    // CUs ask the L2 channels for different lines (5 blockIdx mod 32: -2 % on the 512-frame latent IK iteration; offsets of
+    // blockIdx or blockIdx / 8 did nothing).  The k order only changes the fp32 summation order of a frame, the same way for
+    // the same position in the batch.
+    const int rot = (int)((blockIdx.x * 5u) & 31u);
+    load_stage(0, rot);
+    load_stage(1, (rot + 1) & 31);
+    load_stage(2, (rot + 2) & 31);
     for(int k4 = 0; k4 < 32; k4 += 4)
     {
 #pragma unroll
       for(int u = 0; u < 4; u++)
       {
-        const int ks = k4 + u;
-        load_stage((u + 3) & 3, ks + 3 < 32 ? ks + 3 : 31);
+        const int ks = (k4 + u + rot) & 31;
+        load_stage((u + 3) & 3, (ks + 3) & 31);
         const v4fv bh = *reinterpret_cast<const v4fv *>(D1f + ks * 2048 + l * 16);
         const v4fv bl = *reinterpret_cast<const v4fv *>(D1f + ks * 2048 + 1024 + l * 16);
         const v4fv ah = *reinterpret_cast<const v4fv *>(Af + ks * 64 + lh * 16);
