@@ -278,7 +278,8 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
                                              const float * __restrict__ poserot, int K, int optimize_beta,
                                              int phi_live, int min_valid, float * __restrict__ pos804,
                                              double * __restrict__ e_out, double * __restrict__ J_out,
-                                             int * __restrict__ skip, int dbg_stop, int tsplit, const int32_t * __restrict__ roles)
+                                             int * __restrict__ skip, int dbg_stop, int tsplit, const int32_t * __restrict__ roles,
+                                             const float * __restrict__ vjac, double * __restrict__ Jl_out)
 {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_tree[TREE_SIZE];
@@ -989,6 +990,48 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     lds_barrier();
     if(k_lo == k_begin) EVAL_STAMP(13);
   }
+  // ---- VPoser latent layout (node.cpp:761-772): the rows this workgroup wrote, over [pos 3 | root 3 | z 32 | aa22 3 | aa23 3 |
+  // phi | beta]: columns 0..5 and 69..74 of J75 pass through, columns 6..68 (joints 1..21) are pulled back through
+  // d(vposer out)/dz [63, 32] of the frame.  (A separate kernel for this cost the loop 19 us per iteration; here it is 768
+  // threads x 63 FMAs behind the rows they follow.)
+  if(Jl_out && k_end > k_begin)
+  {
+    __syncthreads(); // this workgroup's rows of J are complete (its stores have left the wavefronts)
+    const int bdim = optimize_beta ? NB : 0, Dl = TD44 + 2 * K + bdim, nrw = 4 * (k_end - k_begin);
+    float * svj = lds + L_DP;                                       // [63][32]  (the dp and ring-vertex regions are free now)
+    double * sJ = reinterpret_cast<double *>(lds + L_DP + 63 * 32); // [rows of a chunk][63]
+    static_assert((L_DP + 63 * 32) % 2 == 0, "sJ must be 8-byte aligned");
+    constexpr int LJ_CHUNK = ((L_END - L_DP - 63 * 32) / 2) / 63; // rows whose 63 pulled-back columns fit behind the decoder Jacobian
+    static_assert(LJ_CHUNK >= 4, "room for at least one task's rows");
+    const double * Jf = J_out + ((f * K + k_begin) * 4) * (int64_t)D;
+    double * Lf = Jl_out + ((f * K + k_begin) * 4) * (int64_t)Dl;
+    for(int i = tid; i < 63 * 32; i += EVAL_NT) svj[i] = vjac[f * 63 * 32 + i];
+    for(int r0 = 0; r0 < nrw; r0 += LJ_CHUNK)
+    {
+      const int nr = (nrw - r0 < LJ_CHUNK) ? nrw - r0 : LJ_CHUNK;
+      if(r0 > 0) __syncthreads(); // the previous chunk's readers are done with sJ
+      for(int i = tid; i < nr * 63; i += EVAL_NT) sJ[i] = Jf[(int64_t)(r0 + i / 63) * D + 6 + i % 63];
+      __syncthreads();
+      for(int item = tid; item < nr * Dl; item += EVAL_NT)
+      {
+        const int rl = item / Dl, c = item % Dl, r = r0 + rl;
+        double v;
+        if(c < 6)
+          v = Jf[(int64_t)r * D + c];
+        else if(c < 6 + 32)
+        {
+          double sacc = 0.0;
+          for(int q = 0; q < 63; q++) sacc += sJ[rl * 63 + q] * (double)svj[q * 32 + (c - 6)];
+          v = sacc;
+        }
+        else if(c < TD44)
+          v = Jf[(int64_t)r * D + 69 + (c - 38)];
+        else
+          v = Jf[(int64_t)r * D + TD75 + (c - TD44)];
+        Lf[(int64_t)r * Dl + c] = v;
+      }
+    }
+  }
   EVAL_STAMP(7);
 }
 
@@ -999,10 +1042,11 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
                                                       int phi_live, int min_valid, float * __restrict__ pos804,
                                                       double * __restrict__ e_out, double * __restrict__ J_out,
                                                       int * __restrict__ skip, int dbg_stop, int tsplit, const int32_t * __restrict__ roles,
-                                                      unsigned * __restrict__ sig_flag, unsigned * __restrict__ sig_counter, unsigned sig_tick)
+                                                      unsigned * __restrict__ sig_flag, unsigned * __restrict__ sig_counter, unsigned sig_tick,
+                                                      const float * __restrict__ vjac, double * __restrict__ Jl_out)
 {
   ik_eval_body(mv, ta, theta25, verts_all, rest_all, Gp, joints, poserot, K, optimize_beta, phi_live, min_valid, pos804, e_out, J_out, skip,
-               dbg_stop, tsplit, roles);
+               dbg_stop, tsplit, roles, vjac, Jl_out);
   wg_signal(sig_flag, sig_counter, sig_tick); // (every exit of the body comes through here: a waiting stream is never left behind)
 }
 
@@ -1023,47 +1067,6 @@ extern "C" int smplpp_debug_eval_stamps(unsigned long long * out)
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(smplpp_hip::g_eval_stamps), sizeof(unsigned long long) * 64 * 16);
 }
 #endif
-
-// J over the 44-d latent layout from J over theta75 (node.cpp:761-772): columns 0..5 and 69..74 pass through,
-// columns 6..68 (joints 1..21) are pulled back through d(vposer out)/dz [63,32].
-constexpr int LJ_ROWS = 8; // Jacobian rows per workgroup of ik_latent_jacobian_kernel
-__global__ __launch_bounds__(256) void ik_latent_jacobian_kernel(const double * __restrict__ J75, const float * __restrict__ vjac,
-                                                                  double * __restrict__ Jl, int K, int beta_dim,
-                                                                  const int * __restrict__ skip)
-{
-  // grid (frames, row chunks): the decoder Jacobian [63,32] of the frame and the chunk's rows of J75[:, 6:69] are staged in
-  // LDS once; one workgroup per frame walked 4K x (44 + 2K) entries with 63 dependent global loads per latent entry
-  // (145 us for a 41-marker frame)
-  const int64_t f = blockIdx.x;
-  if(skip[f]) return;
-  const int rows = 4 * K, r0 = blockIdx.y * LJ_ROWS, nr = (rows - r0 < LJ_ROWS) ? rows - r0 : LJ_ROWS;
-  const int D75 = TD75 + 2 * K + beta_dim, Dl = TD44 + 2 * K + beta_dim;
-  const double * Jf = J75 + (f * rows + r0) * (int64_t)D75;
-  double * Lf = Jl + (f * rows + r0) * (int64_t)Dl;
-  __shared__ float svj[63 * 32];
-  __shared__ double sJ[LJ_ROWS][63];
-  for(int i = threadIdx.x; i < 63 * 32; i += 256) svj[i] = vjac[f * 63 * 32 + i];
-  for(int i = threadIdx.x; i < nr * 63; i += 256) sJ[i / 63][i % 63] = Jf[(int64_t)(i / 63) * D75 + 6 + i % 63];
-  __syncthreads();
-  for(int item = threadIdx.x; item < nr * Dl; item += 256)
-  {
-    const int r = item / Dl, c = item % Dl;
-    double v;
-    if(c < 6)
-      v = Jf[(int64_t)r * D75 + c];
-    else if(c < 6 + 32)
-    {
-      double s = 0.0;
-      for(int q = 0; q < 63; q++) s += sJ[r][q] * (double)svj[q * 32 + (c - 6)];
-      v = s;
-    }
-    else if(c < TD44)
-      v = Jf[(int64_t)r * D75 + 69 + (c - 38)];
-    else
-      v = Jf[(int64_t)r * D75 + TD75 + (c - TD44)];
-    Lf[(int64_t)r * Dl + c] = v;
-  }
-}
 
 // theta25 from the latent configuration (node.cpp:763-771)
 __global__ void ik_splice_kernel(const float * __restrict__ g44, const float * __restrict__ vout /*[n,63]*/,
@@ -2673,14 +2676,9 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
                         (const float *)s->verts, (const float *)s->rest, (const float *)m->ws.Gp.as<float>(), (const float *)s->joints,
                         (const float *)s->poserot, K, optimize_beta, phi_live, (int)min_valid, s->pts, s->e,
                         s->J, s->skip, s->dbg_stop, tsplit, s->roles, fork_flag ? s->sig : (unsigned *)nullptr,
-                        fork_flag ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork);
+                        fork_flag ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork, s->vp ? (const float *)s->vjac : (const float *)nullptr,
+                        s->vp ? s->Jl : (double *)nullptr);
   HIP_TRY(hipGetLastError());
-  if(s->vp)
-  {
-    ik_latent_jacobian_kernel<<<dim3((unsigned)n, (unsigned)((4 * K + LJ_ROWS - 1) / LJ_ROWS)), dim3(256), 0, st>>>(s->J, s->vjac, s->Jl, K,
-                                                                                                                    optimize_beta ? NB : 0, s->skip);
-    HIP_TRY(hipGetLastError());
-  }
   s->have_eval = true;
   return SMPLPP_OK;
 }
