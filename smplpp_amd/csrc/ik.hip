@@ -1080,7 +1080,10 @@ __global__ void ik_splice_kernel(const float * __restrict__ g44, const float * _
   if(c < 6)
     v = g44[f * TD44 + c];
   else if(c < 69)
+  {
+    if(!vout) return; // (pass-through entries only: the decoder writes its 63 angles into theta25 itself)
     v = vout[f * 63 + (c - 6)];
+  }
   else
     v = g44[f * TD44 + 38 + (c - 69)];
   theta25[i] = v;
@@ -1651,7 +1654,8 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
                                                        float * __restrict__ theta, float * __restrict__ beta, float * __restrict__ pts,
                                                        int K, int theta_dim, int beta_dim, int phi_live, int enable_qp, int use_prior,
                                                        int chunk_rows, const int * __restrict__ skip, double * __restrict__ e2_out,
-                                                       int * __restrict__ status, int * __restrict__ sticky, double * __restrict__ x_out, int dbg_stop, int m_dim)
+                                                       int * __restrict__ status, int * __restrict__ sticky, double * __restrict__ x_out, int dbg_stop, int m_dim,
+                                                       float * __restrict__ theta25)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int64_t f = blockIdx.x;
@@ -2042,7 +2046,14 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   const bool ok = !s_bad;
   // config update (node.cpp:945-968), fp32
   for(int i = tid; i < theta_dim; i += 256)
-    if(ok) theta[f * theta_dim + i] += (float)xfull[i];
+    if(ok)
+    {
+      const float t = theta[f * theta_dim + i] + (float)xfull[i];
+      theta[f * theta_dim + i] = t;
+      // VPoser latent layout: the entries that pass through to theta25 (node.cpp:763-771) are kept current here
+      if(theta25 && i < 6) theta25[f * TD75 + i] = t;
+      if(theta25 && i >= 38) theta25[f * TD75 + 69 + (i - 38)] = t;
+    }
   for(int i = tid; i < beta_dim; i += 256)
     if(ok) beta[f * NB + i] += (float)xfull[theta_dim + 2 * K + i];
   for(int i = tid; pts && i < K * 3; i += 256) // p_k = actualPos_k + tangents_k . x_phi_k (:956-959); null: x_phi = 0 for all
@@ -2312,7 +2323,7 @@ struct smplpp_ik
   int64_t n = 0, K = 0;
   int theta_dim = TD75;
   TaskArrays ta{};
-  float *theta = nullptr, *beta = nullptr, *theta25 = nullptr, *vout = nullptr, *vjac = nullptr;
+  float *theta = nullptr, *beta = nullptr, *theta25 = nullptr, *vjac = nullptr;
   float *verts = nullptr, *rest = nullptr, *joints = nullptr, *poserot = nullptr, *pts = nullptr;
   double *e = nullptr, *J = nullptr, *Jl = nullptr, *e2 = nullptr, *xout = nullptr;
   int *skip = nullptr, *status = nullptr, *sticky = nullptr, *list_cnt = nullptr, *list_f = nullptr;
@@ -2489,7 +2500,6 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   if(vposer)
   {
     A_(Jl, nk * 4 * Dmax);
-    A_(vout, (size_t)n * 63);
     A_(vjac, (size_t)n * 63 * 32);
   }
 #undef A_
@@ -2505,6 +2515,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   fill_f32_kernel<<<grid(nk), 256>>>(s->ta.philim, 0.04f, nk);
   fill_f32_kernel<<<grid(nk), 256>>>(s->ta.noff, 0.0f, nk);
   HIP_TRY(hipMemset(s->theta, 0, sizeof(float) * n * s->theta_dim));
+  HIP_TRY(hipMemset(s->theta25, 0, sizeof(float) * n * 75));
   HIP_TRY(hipMemset(s->beta, 0, sizeof(float) * n * NB));
   HIP_TRY(hipMemset(s->skip, 0, sizeof(int) * n));
   HIP_TRY(hipMemcpy(s->roles, roles.data(), sizeof(int32_t) * roles.size(), hipMemcpyHostToDevice));
@@ -2588,6 +2599,12 @@ extern "C" int smplpp_ik_set_config(smplpp_ik * s, const float * beta, const flo
   hipMemcpyKind kind = space == SMPLPP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   if(beta) HIP_TRY(hipMemcpy(s->beta, beta, sizeof(float) * s->n * NB, kind));
   if(theta) HIP_TRY(hipMemcpy(s->theta, theta, sizeof(float) * s->n * s->theta_dim, kind));
+  if(theta && s->vp) // latent layout: the entries that pass through to theta25 (the decoder fills the rest at every evaluation)
+  {
+    ik_splice_kernel<<<dim3((unsigned)((s->n * 75 + 255) / 256)), 256>>>(s->theta, nullptr, s->theta25, s->n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(nullptr));
+  }
   return SMPLPP_OK;
 }
 
@@ -2646,9 +2663,10 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   const float * th25 = s->theta;
   if(s->vp) // node.cpp:761-772
   {
-    int rc = vposer_forward_device(s->vp, n, s->theta + 6, TD44, s->vout, 63, s->vjac, st);
+    // the decoder writes its 63 angles straight into theta25[:, 6:69]; the pass-through entries (root translation / rotation,
+    // joints 22-23) are kept current by whoever changes the configuration: smplpp_ik_set_config and the solve kernel's update
+    int rc = vposer_forward_device(s->vp, n, s->theta + 6, TD44, s->theta25 + 6, 75, s->vjac, st);
     if(rc) return rc;
-    ik_splice_kernel<<<dim3((unsigned)((n * 75 + 255) / 256)), 256, 0, st>>>(s->theta, s->vout, s->theta25, n);
     th25 = s->theta25;
   }
   s->vcur ^= 1;
@@ -2758,10 +2776,10 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
     const bool dual_only = rows < s->theta_dim && rows <= 63 && chunk_rows >= rows && D <= 192 && dbg_stop != 9;
 #define SOLVE_(DO) ik_solve_kernel<DO><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
     s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
-    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim)
+    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr)
 #define SOLVE11_() ik_solve_kernel<false, 11><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
     s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
-    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim)
+    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr)
     if(dual_only)
       SOLVE_(true);
     else if(ntr == 11)
