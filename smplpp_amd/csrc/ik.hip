@@ -3,8 +3,10 @@
 //  ik_eval_kernel    node.cpp:798-877.  The reference gets each Jacobian row by a full reverse-mode autograd pass
 //                    through the 6890-vertex FK graph (3-4 passes per task); here the same derivative is the analytic
 //                    forward-mode Jacobian of only the vertices the tasks touch: per frame the chain
-//                    derivatives dG'_i/dtheta_{j,k} of all 72 rotation columns are built once in LDS (83 KB), then every
-//                    task reads them for its face vertices (and their 1-rings when a normal is involved).
+//                    derivatives dG'_i/dtheta_{j,k} of all 72 rotation columns are built once in LDS (41 KB: three columns per
+//                    ancestor depth), one tree level per step, then every
+//                    task reads them for its face vertices (and their 1-rings when a normal is involved: per-face ring
+//                    tables built with the model).  In the VPoser layout it also writes the latent rows (node.cpp:761-772).
 //  ik_solve_kernel   node.cpp:883-968: A = J^T J + damping in fp64 built straight from J staged through LDS, right-looking
 //                    Cholesky of the packed lower-triangular augmented system in LDS (fp64) or the box QP by a primal
 //                    active set around it, config update, query points for the re-projection.
@@ -436,7 +438,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   EVAL_STAMP(2);
   if(dbg_stop == 21) return;
   // ---- phase A, in four steps so that nothing walks dependent HBM gathers serially:
-  //   A0  one thread per task: the ring list (topology only: cached per (face, uses-normal), rebuilt when the face changes)
+  //   A0  all threads: the ring lists from the per-face tables built with the model (topology only)
   //   A1  all threads: posed positions of the ring vertices -> LDS
   //   A2  one thread per (task, triangle vertex): vertex normal from those positions (tasks with a normal offset / term)
   //   A3  one thread per task: tangents, weight refresh, residual rows (node.cpp:803-820)
@@ -642,8 +644,8 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   static_assert(EVAL_NT >= 64 + NGN * 128 + NGN * 4, "B1 hands the map / count loads to thread ranges beyond the ring threads");
   for(int g = 0; g < s_ng; g++)
   {
-    // group [k_lo, k_hi) from the list thread 0 made behind the ring-size scan (with 16 wavefronts, bounds every thread
-    // works out for itself cost the workgroup 16 issue slots per instruction)
+    // group [k_lo, k_hi) from the list thread 0 made behind the ring-size scan (with 12 wavefronts, bounds every thread
+    // works out for itself cost the workgroup 12 issue slots per instruction)
     const int k_lo = k_begin + s_gk[g], k_hi = k_begin + s_gk[g + 1];
     const int total = s_rcum[k_hi - k_begin] - s_rcum[k_lo - k_begin];
     const bool grp_normal = s_usen[k_lo - k_begin] != 0;
