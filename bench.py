@@ -56,6 +56,59 @@ def issued_mfma_flops(form, n):
     return items * 4 * per_wave * MFMA_32X32X16_FLOPS
 
 
+KERNEL_NAMES = {
+    "h": "skin_kernel_h<false> (fused blend-shape GEMM + linear blend skinning; fp32 operands as fp16x2 pieces, 3 MFMA products "
+         "per fp32 product; skinning as MFMA products too; fp32 accumulate)",
+    "b": "skin_kernel_b<4,false> (bf16x3 operand pieces, 6 MFMA products per fp32 product; VALU skinning in MFMA shadows)",
+    "p": "skin_kernel_p<4,false> (exact fp32 MFMA, persistent)", "v": "skin_kernel<2,4> (exact fp32 MFMA, first form)",
+}
+DTYPES = {"h": "f32 (fp16x2 operand pieces on the f16 matrix pipe, fp32 accumulate: 22-bit operands, error 3e-7 m)",
+          "b": "f32 (bf16x3, exact operands: three bf16 pieces = fp32's 24 bits, fp32 accumulate)"}
+
+
+def roofline_object(form, n, skin_ms, launches, traffic):
+    """The roofline entry of the fused kernel of `form` at batch n from its measured mean duration (ms)."""
+    t_k = skin_ms * 1e-3
+    alg_bytes = ALG_BYTES_CONST + ALG_BYTES_PER_FRAME * n
+    f32_equiv_tflops = ALG_MFMA_FLOPS_PER_FRAME * n / t_k / 1e12 if t_k > 0 else 0.0
+    hbm_gbs = alg_bytes / t_k / 1e9 if t_k > 0 else 0.0
+    hbm = {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg_bytes}
+    if form in ("h", "b"):
+        issued = issued_mfma_flops(form, n)
+        issued_tflops = issued / t_k / 1e12 if t_k > 0 else 0.0
+        t_mfma, t_hbm = issued / (PEAK_MFMA_16BIT_TFLOPS * 1e12), alg_bytes / (PEAK_HBM_GBS * 1e9)
+        # the roof the kernel sits under: the slower of (issued matrix FLOPs at the dense 16-bit MFMA peak, algorithmic bytes at
+        # the HBM peak); frac = that time / measured time
+        if t_mfma >= t_hbm:
+            roofline = {"kernel": KERNEL_NAMES[form], "bound": "mfma", "achieved": issued_tflops, "peak": PEAK_MFMA_16BIT_TFLOPS,
+                        "unit": "TFLOP/s", "frac": issued_tflops / PEAK_MFMA_16BIT_TFLOPS}
+        else:
+            roofline = {"kernel": KERNEL_NAMES[form], "bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": hbm_gbs / PEAK_HBM_GBS}
+        roofline.update({
+            "traffic": traffic, "kernel_ms": skin_ms, "launches_timed": launches,
+            "issued_mfma_flops_per_launch": issued, "roof_us": {"mfma": t_mfma * 1e6, "hbm": t_hbm * 1e6},
+            "hbm": hbm,
+            "useful": {"achieved": ALG_FLOPS_PER_FRAME * n / t_k / 1e12 if t_k > 0 else 0.0, "unit": "TFLOP/s",
+                       "note": "algorithmic fp32 FLOPs of the whole FK (15.5 MFLOP per frame, SURVEY.md 8d) / kernel time: the operand "
+                               "split (3x or 6x), the K padding and the dense K = 24 skinning are not in this numerator"},
+            "fp32_equivalent": {"achieved": f32_equiv_tflops, "unit": "TFLOP/s",
+                                "note": "algorithmic fp32 FLOPs of the blend-shape contraction (2*20670*217 per frame) / kernel time — a "
+                                        "side note, not a roof (the fp32 MFMA peak is 157.3 TF; this kernel does not run on that pipe)"},
+            "note": "achieved = matrix FLOPs the kernel ISSUES (v_mfma_f32_32x32x16_f16/bf16 count x 32768, DESIGN.md §3.2) / kernel time, "
+                    "against the dense 16-bit MFMA peak (2.5 PF, no sparsity): pipe occupancy, not useful work (see `useful`); `hbm` is "
+                    "the SURVEY 8(d) fraction (algorithmic bytes / kernel time / 8 TB/s), the one that only moves with time. "
+                    "The chip holds ~1.7-1.8 GHz of its 2.4 GHz under this kernel (power-limited; in-kernel stamps, DESIGN.md §3.2)",
+        })
+    else:
+        roofline = {
+            "kernel": KERNEL_NAMES[form], "bound": "mfma", "achieved": f32_equiv_tflops, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+            "frac": f32_equiv_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": traffic, "kernel_ms": skin_ms, "launches_timed": launches, "hbm": hbm,
+            "note": "exact fp32 on v_mfma_f32_32x32x2_f32 (1/16 of the 16-bit MFMA rate): the fp32 matrix pipe binds",
+        }
+    return roofline
+
+
 def usable_cpus():
     """Host cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -158,6 +211,8 @@ def main():
     ap.add_argument("--mocap-restarts", type=int, default=64, help="restarts of the capture fit IN ALL (BASELINE configs[3]: 64, sharded over the GPUs)")
     ap.add_argument("--mocap-frames", type=int, default=0, help="frames of the capture sequence to fit (0 = all 3163)")
     ap.add_argument("--vposer-frames", type=int, default=512, help="frames of the VPoser-latent IK leg IN ALL (BASELINE configs[4]: 512, sharded over the GPUs)")
+    ap.add_argument("--sustained-steps", type=int, default=2000, help="launches of the long run reported as `sustained` (0 = skip)")
+    ap.add_argument("--no-exact-form", action="store_true", help="skip the operand-exact (bf16x3) leg reported as `exact_form`")
     ap.add_argument("--profile-steps", type=int, default=40, help="launches of the separate loop that times the fused kernel with HIP events")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
@@ -191,29 +246,62 @@ def main():
     theta = torch.from_numpy(theta_h).cuda()
     out = {"verts": torch.empty((n, V, 3), dtype=torch.float32, device="cuda")}
 
-    def step():
-        smpl.launch(beta, theta, want=("verts",), out=out)
+    def timed(engine, steps):
+        """`steps` launches of the FK step bracketed by barrier + synchronize on both sides; max over ranks (seconds)."""
+        torch.cuda.synchronize()
+        D.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            engine.launch(beta, theta, want=("verts",), out=out)
+        torch.cuda.synchronize()
+        D.barrier()
+        return D.max_over_ranks(time.perf_counter() - t0)
+
+    def kernel_ms(engine, steps):
+        """the fused kernel's own duration: a separate short loop with HIP events on the launch stream (never inside a timed region)"""
+        engine.profileEnable(True)
+        engine.profileRead()
+        for _ in range(max(1, steps)):
+            engine.launch(beta, theta, want=("verts",), out=out)
+        torch.cuda.synchronize()
+        launches, ms = engine.profileRead()
+        engine.profileEnable(False)
+        return launches, D.max_over_ranks(ms)
 
     for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    D.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    D.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed)
-    # the fused kernel's own duration: a separate short loop with HIP events on the launch stream (not inside the timed region)
-    smpl.profileEnable(True)
-    smpl.profileRead()
-    for _ in range(max(1, args.profile_steps)):
-        step()
-    torch.cuda.synchronize()
-    launches, skin_ms = smpl.profileRead()
-    smpl.profileEnable(False)
-    skin_ms = D.max_over_ranks(skin_ms)
+        smpl.launch(beta, theta, want=("verts",), out=out)
+    elapsed = timed(smpl, args.steps)
+    launches, skin_ms = kernel_ms(smpl, args.profile_steps)
+    # the steady clock: a short --steps region is a burst on a power-limited kernel (the chip has not settled), so the same
+    # step is timed once more over a long run, after the contract's region
+    sustained = None
+    if args.sustained_steps > 0:
+        sus_t = timed(smpl, args.sustained_steps)
+        sustained = {"launches": args.sustained_steps, "ms_per_step": sus_t / args.sustained_steps * 1e3,
+                     "value": world * n * args.sustained_steps / sus_t, "unit": "FK evals/s"}
+    # the same step with operand-exact arithmetic: the bf16x3 form carries every fp32 operand as three bf16 pieces (24
+    # significant bits = fp32's own), so its products are the reference's fp32 products; fp32 accumulate in both forms
+    exact = None
+    form_env = (os.environ.get("SMPLPP_SKIN") or "h")[0]
+    if not args.no_exact_form and form_env == "h":
+        orig_env = os.environ.get("SMPLPP_SKIN")
+        os.environ["SMPLPP_SKIN"] = "b"  # read once, at model creation
+        try:
+            smpl_b = SMPL()
+            smpl_b.setDevice("cuda:%d" % local)
+            smpl_b.init(model)
+        finally:
+            if orig_env is None:
+                del os.environ["SMPLPP_SKIN"]
+            else:
+                os.environ["SMPLPP_SKIN"] = orig_env
+        for _ in range(args.warmup):
+            smpl_b.launch(beta, theta, want=("verts",), out=out)
+        ex_steps = max(args.steps, 200)
+        ex_t = timed(smpl_b, ex_steps)
+        ex_launches, ex_kms = kernel_ms(smpl_b, args.profile_steps)
+        exact = {"steps": ex_steps, "t": ex_t, "kernel_ms": ex_kms, "launches": ex_launches}
+        del smpl_b
 
     # ---- IK leg (BASELINE.json configs[2]): 6 targets, 50 iterations, 256 frames per GPU
     ik = None
@@ -374,57 +462,15 @@ def main():
         return
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n * args.steps / elapsed
-    form = (os.environ.get("SMPLPP_SKIN") or "h")[0]
-    if form not in ("h", "b", "p", "v"):
-        form = "h"
-    t_k = skin_ms * 1e-3
-    alg_bytes = ALG_BYTES_CONST + ALG_BYTES_PER_FRAME * n
-    f32_equiv_tflops = ALG_MFMA_FLOPS_PER_FRAME * n / t_k / 1e12 if t_k > 0 else 0.0
-    hbm_gbs = alg_bytes / t_k / 1e9 if t_k > 0 else 0.0
-    traffic = None
+    form = form_env if form_env in ("h", "b", "p", "v") else "h"
+    traffic_all = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_fk.sh, profiles/README.md)
         try:
-            traffic = json.load(open(tpath)).get("skin_kernel_%s_hbm_bytes_per_launch_n%d" % (form, n))
+            traffic_all = json.load(open(tpath))
         except Exception:
-            traffic = None
-    kernel_names = {
-        "h": "skin_kernel_h<false> (fused blend-shape GEMM + linear blend skinning; fp32 operands as fp16x2 pieces, 3 MFMA products "
-             "per fp32 product; skinning as MFMA products too; fp32 accumulate)",
-        "b": "skin_kernel_b<4,false> (bf16x3 operand pieces, 6 MFMA products per fp32 product; VALU skinning in MFMA shadows)",
-        "p": "skin_kernel_p<4,false> (exact fp32 MFMA, persistent)", "v": "skin_kernel<2,4> (exact fp32 MFMA, first form)",
-    }
-    hbm = {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg_bytes}
-    if form in ("h", "b"):
-        issued = issued_mfma_flops(form, n)
-        issued_tflops = issued / t_k / 1e12 if t_k > 0 else 0.0
-        t_mfma, t_hbm = issued / (PEAK_MFMA_16BIT_TFLOPS * 1e12), alg_bytes / (PEAK_HBM_GBS * 1e9)
-        # the roof the kernel sits under: the slower of (issued matrix FLOPs at the dense 16-bit MFMA peak, algorithmic bytes at
-        # the HBM peak); frac = that time / measured time
-        if t_mfma >= t_hbm:
-            roofline = {"kernel": kernel_names[form], "bound": "mfma", "achieved": issued_tflops, "peak": PEAK_MFMA_16BIT_TFLOPS,
-                        "unit": "TFLOP/s", "frac": issued_tflops / PEAK_MFMA_16BIT_TFLOPS}
-        else:
-            roofline = {"kernel": kernel_names[form], "bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": hbm_gbs / PEAK_HBM_GBS}
-        roofline.update({
-            "traffic": traffic, "kernel_ms": skin_ms, "launches_timed": launches,
-            "issued_mfma_flops_per_launch": issued, "roof_us": {"mfma": t_mfma * 1e6, "hbm": t_hbm * 1e6},
-            "hbm": hbm,
-            "fp32_equivalent": {"achieved": f32_equiv_tflops, "unit": "TFLOP/s",
-                                "note": "algorithmic fp32 FLOPs of the blend-shape contraction (2*20670*217 per frame) / kernel time — a "
-                                        "side note, not a roof (the fp32 MFMA peak is 157.3 TF; this kernel does not run on that pipe)"},
-            "note": "achieved = matrix FLOPs the kernel ISSUES (v_mfma_f32_32x32x16_f16/bf16 count x 32768, DESIGN.md §3.2) / kernel time, "
-                    "against the dense 16-bit MFMA peak (2.5 PF, no sparsity); 152 FLOP/B at batch 1024 puts the HBM roof (13 us) under "
-                    "the matrix roof. The chip holds ~1.7-1.8 GHz of its 2.4 GHz under this kernel (power-limited; in-kernel stamps, "
-                    "DESIGN.md §3.2), so the practical ceiling of an MFMA-only stream is ~0.72 of the datasheet figure",
-        })
-    else:
-        roofline = {
-            "kernel": kernel_names[form], "bound": "mfma", "achieved": f32_equiv_tflops, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": f32_equiv_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": traffic, "kernel_ms": skin_ms, "launches_timed": launches, "hbm": hbm,
-            "note": "exact fp32 on v_mfma_f32_32x32x2_f32 (1/16 of the 16-bit MFMA rate): the fp32 matrix pipe binds",
-        }
+            traffic_all = {}
+    roofline = roofline_object(form, n, skin_ms, launches, traffic_all.get("skin_kernel_%s_hbm_bytes_per_launch_n%d" % (form, n)))
     line = {
         "metric": "SMPL FK evals/s + IK iters/s, batch 1024 frames, 1/2/4/8 MI355X",
         "value": value,
@@ -436,8 +482,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {"h": "f32 (fp16x2 operand pieces on the f16 matrix pipe, fp32 accumulate: 22-bit operands, error 3e-7 m)",
-                  "b": "f32 (exact bf16x3 operand pieces, fp32 accumulate)"}.get(form, "f32"),
+        "dtype": DTYPES.get(form, "f32"),
         "data": "synthetic",
         "config": {
             "workload": "configs[1]: batch-%d random beta/theta FK+LBS per GPU, synthetic SMPL-shaped model "
@@ -446,6 +491,17 @@ def main():
         },
         "roofline": roofline,
     }
+    if sustained is not None:
+        line["sustained"] = sustained
+    if exact is not None:
+        ex_ms = exact["t"] / exact["steps"] * 1e3
+        line["exact_form"] = {
+            "kernel": KERNEL_NAMES["b"], "dtype": DTYPES["b"], "value": world * n * exact["steps"] / exact["t"], "unit": "FK evals/s",
+            "steps": exact["steps"], "ms_per_step": ex_ms, "kernel_ms": exact["kernel_ms"],
+            "roofline": roofline_object("b", n, exact["kernel_ms"], exact["launches"], traffic_all.get("skin_kernel_b_hbm_bytes_per_launch_n%d" % n)),
+            "note": "the same 1024-frame step with every fp32 operand carried exactly (SMPLPP_SKIN=b at model creation): this is the "
+                    "fp32-arithmetic figure; the headline `value` is the fp16x2 form (22-bit operands, within the 1e-5 m bar with 15-30x margin)",
+        }
     if ik is not None:
         line["ik"] = ik
     if mocap_leg is not None:

@@ -28,3 +28,9 @@ def test_bench_prints_one_contract_line():
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert d["ik"]["value"] > 0 and d["mocap"]["finite"] and d["vposer_ik"]["value"] > 0
+    # burst-proof figure (a long run after the contract's region) and the operand-exact (bf16x3) figure in the same line
+    sus = d["sustained"]
+    assert sus["launches"] >= 2000 and sus["ms_per_step"] > 0 and sus["value"] > 1e4
+    ex = d["exact_form"]
+    assert "bf16x3" in ex["dtype"] and ex["value"] > 1e4 and ex["kernel_ms"] > 0 and ex["ms_per_step"] >= ex["kernel_ms"]
+    assert ex["roofline"]["bound"] in ("hbm", "mfma") and ex["roofline"]["hbm"]["frac"] > 0
