@@ -16,6 +16,7 @@
 // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch); all frame tiles of one vertex quad are
 // given to one XCD, consecutively, so each 338 KB slice of Bm is pulled into that XCD's L2 once per launch.
 #include "common.h"
+#include "pose_math.h"
 
 namespace smplpp_hip
 {
@@ -23,26 +24,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------------------------------------- pose kernel
-__device__ inline void rodrigues_dev(float t0, float t1, float t2, float * R)
-{
-  const float eps = 1e-8f;
-  float a0 = t0 + eps, a1 = t1 + eps, a2 = t2 + eps; // src/BlendShape.cpp:813-814
-  float angle = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
-  float k0 = t0 / angle, k1 = t1 / angle, k2 = t2 / angle; // :815
-  float K[9] = {0.0f, -k2, k1, k2, 0.0f, -k0, -k1, k0, 0.0f};
-  float s, co;
-  sincosf(angle, &s, &co); // (one range reduction for both)
-  const float c1 = 1.0f - co;
-#pragma unroll
-  for(int r = 0; r < 3; r++)
-#pragma unroll
-    for(int c = 0; c < 3; c++)
-    {
-      float kk = K[r * 3 + 0] * K[0 * 3 + c] + K[r * 3 + 1] * K[1 * 3 + c] + K[r * 3 + 2] * K[2 * 3 + c];
-      R[r * 3 + c] = ((r == c) ? 1.0f : 0.0f) + K[r * 3 + c] * s + kk * c1; // :841
-    }
-}
-
 // LDS traffic of one wavefront is executed in order, so the phases of a single-wavefront section only need the compiler
 // to keep that order (no s_barrier, and no vmcnt(0) drain of outstanding global stores as __syncthreads() would add).
 __device__ __forceinline__ void wave_sync()
@@ -82,7 +63,8 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
                                                    float * __restrict__ Gp, float * __restrict__ joints_out,
                                                    float * __restrict__ rot_out, float * __restrict__ xf44_out, int64_t n,
                                                    uint16_t * __restrict__ A3, _Float16 * __restrict__ A2h,
-                                                   _Float16 * __restrict__ G2h, float gscale, const int32_t * __restrict__ ctab)
+                                                   _Float16 * __restrict__ G2h, float gscale, const int32_t * __restrict__ ctab,
+                                                   const int16_t * __restrict__ kmap)
 {
   const int64_t f = blockIdx.x;
   const int tid = threadIdx.x;
@@ -138,7 +120,7 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
   {
     float R[9];
     const float * th = theta + (f * (NJ + 1) + 1 + tid) * 3; // theta[:,1:,:] (src/SMPL.cpp:685-686)
-    rodrigues_dev(th[0], th[1], th[2], R);
+    rodrigues9(th[0], th[1], th[2], R);
 #pragma unroll
     for(int q = 0; q < 9; q++) sR[tid][q] = R[q];
     if(rot_out)
@@ -167,9 +149,7 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
   }
   if(tid < NJ * 3) // joints (src/JointRegression.cpp:588-590 through the folded regressor)
   {
-    float s = j0v;
-#pragma unroll
-    for(int k = 0; k < NB; k++) s += jsv[k] * sBeta[k];
+    const float s = joint_coord(j0v, jsv, sBeta);
     sJ[tid / 3][tid % 3] = s;
     if(joints_out) joints_out[f * NJ * 3 + tid] = s;
   }
@@ -210,8 +190,9 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
 #pragma unroll
     for(int j = 0; j < 8; j++)
     {
+      const int k = kmap[8 * c + j]; // K order of the fp16x2 form (common.h: hp_kold); -1 = zero padding
       _Float16 a, b;
-      split_f16x2(sCoef[8 * c + j] * HB_SA, a, b);
+      split_f16x2((k >= 0 ? sCoef[k] : 0.0f) * HB_SA, a, b);
       hi[j] = a;
       lo[j] = b;
     }
@@ -254,11 +235,7 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
         const float g0 = __shfl(vprev, src + 0, 64), g1 = __shfl(vprev, src + 1, 64), g2 = __shfl(vprev, src + 2, 64),
                     g3 = __shfl(vprev, src + 3, 64);
         float v = x0[L];
-        if(p >= 0)
-        {
-          v = g0 * x0[L] + g1 * x1[L] + g2 * x2[L];
-          if(c == 3) v += g3;
-        }
+        if(p >= 0) v = chain_entry(g0, g1, g2, g3, x0[L], x1[L], x2[L], c == 3);
         if(lane < 60 && i >= 0)
         {
           vprev = v;
@@ -284,11 +261,11 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
           if(p < 0)
             v = (c < 3) ? sR[i][r * 3 + c] : sJ[i][r];
           else if(c < 3)
-            v = sG[p][r * 4 + 0] * sR[i][0 * 3 + c] + sG[p][r * 4 + 1] * sR[i][1 * 3 + c] + sG[p][r * 4 + 2] * sR[i][2 * 3 + c];
+            v = chain_entry(sG[p][r * 4 + 0], sG[p][r * 4 + 1], sG[p][r * 4 + 2], 0.0f, sR[i][0 * 3 + c], sR[i][1 * 3 + c], sR[i][2 * 3 + c], false);
           else
           {
             const float t0 = sJ[i][0] - sJ[p][0], t1 = sJ[i][1] - sJ[p][1], t2 = sJ[i][2] - sJ[p][2];
-            v = sG[p][r * 4 + 0] * t0 + sG[p][r * 4 + 1] * t1 + sG[p][r * 4 + 2] * t2 + sG[p][r * 4 + 3];
+            v = chain_entry(sG[p][r * 4 + 0], sG[p][r * 4 + 1], sG[p][r * 4 + 2], sG[p][r * 4 + 3], t0, t1, t2, true);
           }
           sG[i][e] = v;
         }
@@ -304,7 +281,7 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
   {
     const int i = e / 12, q = e % 12, r = q / 4, c = q % 4;
     float v = sG[i][q];
-    if(c == 3) v -= sG[i][r * 4 + 0] * sJ[i][0] + sG[i][r * 4 + 1] * sJ[i][1] + sG[i][r * 4 + 2] * sJ[i][2];
+    if(c == 3) v = relative_t(v, sG[i][r * 4 + 0], sG[i][r * 4 + 1], sG[i][r * 4 + 2], sJ[i][0], sJ[i][1], sJ[i][2]);
     if(Gp) Gp[(f * NJ + i) * 12 + q] = v;
     if(xf44_out) xf44_out[(f * NJ + i) * 16 + q] = v;
   }
@@ -320,9 +297,9 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
 #pragma unroll
     for(int j = 0; j < 8; j++)
     {
-      const int i = 8 * c + j;
+      const int i = kmap[224 + 8 * c + j]; // blend slot -> joint (common.h: HP_JSLOT)
       float v = sG[i][e];
-      if(cc == 3) v -= sG[i][r4 * 4 + 0] * sJ[i][0] + sG[i][r4 * 4 + 1] * sJ[i][1] + sG[i][r4 * 4 + 2] * sJ[i][2];
+      if(cc == 3) v = relative_t(v, sG[i][r4 * 4 + 0], sG[i][r4 * 4 + 1], sG[i][r4 * 4 + 2], sJ[i][0], sJ[i][1], sJ[i][2]);
       _Float16 a, b;
       split_f16x2(v * gscale, a, b);
       hi[j] = a;
@@ -539,7 +516,8 @@ static hipError_t launch_skin_w(const smplpp_model * m, int64_t n, const float *
 hipError_t launch_skin_persistent(const smplpp_model * m, int64_t n, const float * theta, const float * Gp_padded, float * verts,
                                   float * rest, hipStream_t st); // skin_p.hip (fp32 MFMA, one wave/SIMD, epilogue in the MFMA shadow)
 hipError_t launch_skin_bf16x3(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st); // skin_b.hip
-hipError_t launch_skin_f16x2(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st);  // skin_h.hip
+hipError_t launch_skin_f16x2(const smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * rest,
+                             hipStream_t st, bool pose); // skin_h.hip
 
 // Device-pointer FK (enqueue only).  Used by smplpp_fk and by the IK solver.
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
@@ -554,20 +532,27 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
   if(form == 'p' && n * m->V * 12 >= 0x7fffff00LL) form = 'v';
   const int64_t n64 = ((n + 63) / 64) * 64;
   HIP_TRY(ws.Gp.reserve(sizeof(float) * (size_t)n64 * NJ * 12)); // b / p stage whole frame tiles of G' (padding never stored)
-  if(form == 'h')
+  // h, standard SMPL tree, only vertices / rest shape wanted: the fused kernel computes the pose step of its frame tiles itself
+  // (skin_h.hip, POSE) — no pose_kernel launch, no A2h / G2h / G' round trip.  SMPLPP_POSE_FUSED=0 at model creation keeps the
+  // two-kernel path (A/B runs; tests compare the two bit for bit).
+  const bool pose_fused = form == 'h' && m->pose_fused && beta && !joints && !xforms44 && !poserot && (verts || rest);
+  if(pose_fused)
+  {
+  }
+  else if(form == 'h')
   {
     HIP_TRY(ws.A2h.reserve((size_t)(n64 / 64) * HB_KS * HB_A_BYTES));
     HIP_TRY(ws.G2h.reserve((size_t)(n64 / 64) * HB_G_BYTES));
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
                                                          ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr,
                                                          (verts || rest) ? ws.A2h.as<_Float16>() : nullptr,
-                                                         (verts || rest) ? ws.G2h.as<_Float16>() : nullptr, m->sG, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr);
+                                                         (verts || rest) ? ws.G2h.as<_Float16>() : nullptr, m->sG, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr, m->kmap);
   }
   else if(form == 'b')
   {
     HIP_TRY(ws.A3.reserve((size_t)(n64 / 64) * BB_KS * BB_A_BYTES));
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
-                                                         ws.Gp.as<float>(), joints, poserot, xforms44, n, ws.A3.as<uint16_t>(), nullptr, nullptr, 1.0f, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr);
+                                                         ws.Gp.as<float>(), joints, poserot, xforms44, n, ws.A3.as<uint16_t>(), nullptr, nullptr, 1.0f, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr, nullptr);
   }
   else
   {
@@ -581,7 +566,7 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
       zero_pad_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(ws.AT.as<float>(), ldA, n);
     }
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, ws.AT.as<float>(),
-                                                         ldA, ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr, nullptr, nullptr, 1.0f, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr);
+                                                         ldA, ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr, nullptr, nullptr, 1.0f, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr, nullptr);
   }
   HIP_TRY(hipGetLastError());
   if(verts || rest)
@@ -597,7 +582,7 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
       HIP_TRY(hipEventRecord(e0, st));
     }
     if(form == 'h')
-      HIP_TRY(launch_skin_f16x2(m, n, theta, verts, rest, st));
+      HIP_TRY(launch_skin_f16x2(m, n, beta, theta, verts, rest, st, pose_fused));
     else if(form == 'b')
       HIP_TRY(launch_skin_bf16x3(m, n, theta, verts, rest, st));
     else if(form == 'p' && ws.dummy.reserve(4096) == hipSuccess)

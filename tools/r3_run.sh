@@ -1,0 +1,9 @@
+#!/bin/bash
+# dev aid: FK tests + quick bench + kernel times on the GPU box
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; O=$ROOT/gpurun_out/r3run; mkdir -p $O; cd $ROOT
+timeout -k 10 900 python -m pytest tests/test_fk_gpu.py -x -q > $O/pytest_fk.txt 2>&1; rc=$?; tail -15 $O/pytest_fk.txt
+[ $rc -ne 0 ] && exit $rc
+timeout -k 10 120 python tools/quick_fk_bench.py 1024 400 2>/dev/null | tail -1 | tee $O/quick.txt
+SMPLPP_POSE_FUSED=0 timeout -k 10 120 python tools/quick_fk_bench.py 1024 400 2>/dev/null | tail -1 | tee -a $O/quick.txt
+for n in 1 64 256 4096; do timeout -k 10 120 python tools/quick_fk_bench.py $n 300 2>/dev/null | tail -1 | tee -a $O/quick.txt; done
+bash tools/kernel_times.sh 1024 > $O/ktimes.txt 2>&1; cat $O/ktimes.txt
