@@ -233,6 +233,7 @@ struct smplpp_model
   int32_t * parent = nullptr;  // [24]
   int16_t * kmap = nullptr;    // [HP_KMAP_SIZE] K order of the fp16x2 form (common.h: hp_kold, HP_JSLOT)
   bool std_tree = false;       // the kinematic tree is the standard SMPL tree (SMPL_PARENT): skin_h.hip may pose in-kernel
+  bool pose_wave = true;       // form h: pose_kernel_w (one wavefront per frame) instead of pose_kernel (SMPLPP_POSE_WAVE=0: the latter)
   bool pose_fused = false;     // ... and does (std_tree, form h, SMPLPP_POSE_FUSED != 0 at model creation)
   int32_t * lvl = nullptr;     // [25 + 24] kinematic tree by depth: level offsets, then the joints sorted by level
   int nlev = 0;

@@ -17,6 +17,7 @@
 // given to one XCD, consecutively, so each 338 KB slice of Bm is pulled into that XCD's L2 once per launch.
 #include "common.h"
 #include "pose_math.h"
+#include "pose_wave.h"
 
 namespace smplpp_hip
 {
@@ -320,6 +321,21 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
   PST(6);
 }
 
+// The pose step of the fp16x2 form, one wavefront per frame (pose_wave.h), four frames per workgroup: at batch 1024 one
+// workgroup per CU whose four wavefronts each run a single global round trip and ~3k cycles of lane-parallel work, instead of
+// four wavefronts sharing one frame through workgroup barriers (pose_kernel: 11k cycles per frame).
+__global__ __launch_bounds__(256) void pose_kernel_w(const float * __restrict__ beta, const float * __restrict__ theta,
+                                                     const float * __restrict__ J0, const float * __restrict__ JS,
+                                                     const int32_t * __restrict__ ctab, int nlev, const int16_t * __restrict__ kmap,
+                                                     float gscale, int64_t n, PoseWaveOut o)
+{
+  __shared__ __attribute__((aligned(16))) float scr[4][PW_SCR_FLOATS];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t f = (int64_t)blockIdx.x * 4 + wave;
+  if(f >= n) return;
+  pose_frame_wave(lane, f, beta, theta, J0, JS, ctab, nlev, kmap, gscale, scr[wave], o);
+}
+
 // rows [n, ldA) of AT are padding for the last 32-frame tile: keep them zero (re-zeroed whenever n changes)
 __global__ void zero_pad_kernel(float * __restrict__ AT, int64_t ldA, int64_t n)
 {
@@ -538,6 +554,14 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
   const bool pose_fused = form == 'h' && m->pose_fused && beta && !joints && !xforms44 && !poserot && (verts || rest);
   if(pose_fused)
   {
+  }
+  else if(form == 'h' && m->chain_fast && m->pose_wave)
+  {
+    HIP_TRY(ws.A2h.reserve((size_t)(n64 / 64) * HB_KS * HB_A_BYTES));
+    HIP_TRY(ws.G2h.reserve((size_t)(n64 / 64) * HB_G_BYTES));
+    PoseWaveOut o = {ws.Gp.as<float>(), joints, poserot, xforms44, (verts || rest) ? ws.A2h.as<_Float16>() : nullptr,
+                     (verts || rest) ? ws.G2h.as<_Float16>() : nullptr};
+    pose_kernel_w<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->lvl + NJ + 1 + NJ, m->nlev, m->kmap, m->sG, n, o);
   }
   else if(form == 'h')
   {

@@ -424,6 +424,8 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   {
     const char * pf = getenv("SMPLPP_POSE_FUSED"); // read once, here (default on)
     m->pose_fused = m->std_tree && m->form == 'h' && !(pf && pf[0] == '0');
+    const char * pw = getenv("SMPLPP_POSE_WAVE");
+    m->pose_wave = !(pw && pw[0] == '0');
   }
   {
     // joints by depth: the FK chain advances one tree level per step (SMPL: 9 levels)

@@ -93,28 +93,40 @@ def test_fk_batch1024_properties_and_sample(smpl, oracle_synth):
 
 
 
-@pytest.fixture(scope="module")
-def smpl_two_kernel(synth_model):
-    """The same model with the in-kernel pose switched off (SMPLPP_POSE_FUSED=0 is read when a model is created): pose_kernel
-    + fused kernel reading A2h / G2h."""
+def _smpl_with_env(model, **env):
+    """A model created under the given environment switches (they are read when a model is created)."""
     from smplpp_amd.smpl import SMPL
 
-    old = os.environ.get("SMPLPP_POSE_FUSED")
-    os.environ["SMPLPP_POSE_FUSED"] = "0"
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         s = SMPL()
         s.setDevice("cuda:0")
-        s.init(synth_model)
+        s.init(model)
     finally:
-        if old is None:
-            del os.environ["SMPLPP_POSE_FUSED"]
-        else:
-            os.environ["SMPLPP_POSE_FUSED"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     return s
 
 
+@pytest.fixture(scope="module")
+def smpl_two_kernel(synth_model):
+    """The same model with the in-kernel pose switched off: pose_kernel_w (one wavefront per frame) + fused kernel reading
+    A2h / G2h."""
+    return _smpl_with_env(synth_model, SMPLPP_POSE_FUSED="0")
+
+
+@pytest.fixture(scope="module")
+def smpl_first_pose_kernel(synth_model):
+    """... and with the first pose kernel (four wavefronts per frame, workgroup barriers between its phases)."""
+    return _smpl_with_env(synth_model, SMPLPP_POSE_FUSED="0", SMPLPP_POSE_WAVE="0")
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 200, 1024, 2500])
-def test_fk_in_kernel_pose_is_bit_identical_to_the_two_kernel_path(smpl, smpl_two_kernel, oracle_synth, n):
+def test_fk_in_kernel_pose_is_bit_identical_to_the_two_kernel_path(smpl, smpl_two_kernel, smpl_first_pose_kernel, oracle_synth, n):
     """When only vertices / rest shapes are wanted, the default fused kernel computes the pose step of its frame tiles itself
     (skin_h.hip, POSE: Rodrigues, joints, chain, relative transforms per workgroup, lane = frame) instead of reading the
     operands a pose_kernel launch wrote.  Same arithmetic in the same order (pose_math.h), so the two paths must agree bit for
@@ -134,6 +146,10 @@ def test_fk_in_kernel_pose_is_bit_identical_to_the_two_kernel_path(smpl, smpl_tw
     # a request that includes joints / transforms takes the two-kernel path: same vertices again
     c = smpl.launch(beta, theta)
     assert np.array_equal(c["verts"], a["verts"]) and np.array_equal(c["rest"], a["rest"])
+    # the two pose kernels (one wavefront per frame / four per frame) agree bit for bit on everything they write
+    d = smpl_first_pose_kernel.launch(beta, theta)
+    for k in ("verts", "rest", "joints", "xforms"):
+        assert np.array_equal(c[k], d[k]), (n, k)
 
 
 @pytest.mark.parametrize("form", ["h", "b", "p", "v"])

@@ -40,3 +40,12 @@ for it in sorted(set(items.tolist())):
     m = items == it
     print("  %d items: %d workgroups, duration %.2f .. %.2f us (mean %.2f), cycles mean %.0f, clock %.0f MHz" % (it, m.sum(), dur[m].min(), dur[m].max(), dur[m].mean(), cyc[m].mean(), (cyc[m] / np.maximum(en[m] - st[m], 1)).mean() * 100))
 print("  blockIdx & 7 -> XCC_ID:", [sorted(set(xcc[np.arange(256) % 8 == x].tolist())) for x in range(8)])
+for x in range(8):
+    m = (np.arange(256) % 8 == x)
+    print("  XCD %d: items %s, duration mean %.2f max %.2f us, end (rel. first start) mean %.2f max %.2f, clock %.0f MHz" % (
+        x, sorted(set(items[m].tolist())), dur[m].mean(), dur[m].max(), ((en[m] - t00) / 100.0).mean(), ((en[m] - t00) / 100.0).max(),
+        (cyc[m] / np.maximum(en[m] - st[m], 1)).mean() * 100))
+for it in sorted(set(items.tolist())):
+    for x in range(8):
+        m = (items == it) & (np.arange(256) % 8 == x)
+        if m.sum(): print("  items %d XCD %d: n %d dur %.2f..%.2f" % (it, x, m.sum(), dur[m].min(), dur[m].max()))
