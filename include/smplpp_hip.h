@@ -82,6 +82,12 @@ int smplpp_model_info(const smplpp_model * m, int64_t * vertex_num, int64_t * fa
  * Two kernels: pose/chain, then the fused blend-shape GEMM + linear blend skinning. */
 int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
               float * xforms, float * rest, int space, void * stream);
+/* Input range of the default fused kernel (fp16x2 operand pieces): |beta| < 1023 and relative transforms whose
+ * translations stay within 16 x the template's extent (65504 / sG).  Outside it the operand pieces overflow fp16 and the
+ * vertices of the frame are not finite, where the reference (and the forms SMPLPP_SKIN=b|p|v) stay finite.  A launch that
+ * meets such an operand sets bit 0 of the model's status word: a host-space smplpp_fk returns SMPLPP_ERR_NUMERIC itself;
+ * an enqueue-only (device-space) caller reads it here — the call synchronises `stream`, returns the word and clears it. */
+int smplpp_fk_status(smplpp_model * m, int * bits, void * stream);
 
 /* Measurement hook (bench.py): while enabled, every launch of the fused blend-shape + skinning kernel is bracketed by
  * HIP events on the stream it is launched on; smplpp_profile_read waits for them, returns the number of launches
@@ -122,8 +128,11 @@ int smplpp_mesh_vertex_normals(smplpp_model * m, int64_t n, const float * verts,
  * (toolbox/GridUtils.hpp:28) from getGridIdxFloor(min) to getGridIdxCeil(max) per axis (:46-60) -> grid_min [3] (cell
  * index of the first cell), grid_num [3]; cells are ordered x outermost, z innermost like the reference's loops (:1037-1048).
  * winding [cap] (nullable) = generalized winding number of the mesh at each cell position (igl::winding_number, :1052),
- * inside [cap] (nullable) = the cells the reference enters into g_sweepGridList (winding number > 0.5, :1057).  *cells = the
- * grid's cell count; at most `cap` cells are evaluated (call with cap = 0 to size the arrays). */
+ * inside [cap] (nullable) = winding number > 0.5 on the REAL-valued number.  Deviation, deliberate: the reference stores
+ * igl::winding_number's result in an Eigen::VectorXi (:1051-1057), which truncates towards zero before the `> 0.5` test, so
+ * there a cell counts as inside only when the number reaches 1 (0.99999 of an interior point becomes 0); compare `winding`
+ * with 1 - eps yourself to reproduce that list.  *cells = the grid's cell count; at most `cap` cells are evaluated (call with
+ * cap = 0 to size the arrays).  Non-finite or absurd (beyond +-25 km) vertices: SMPLPP_ERR_NUMERIC. */
 int smplpp_sweep_grid(smplpp_model * m, const float * verts, int32_t * grid_min, int32_t * grid_num, int64_t cap,
                       float * winding, uint8_t * inside, int64_t * cells, int space, void * stream);
 /* SMPL::getAdjacentFaces (src/SMPL.cpp:537-540): host copy; returns the count in *count, fills up to cap. */
@@ -190,6 +199,14 @@ int smplpp_ik_get_status(smplpp_ik * s, int32_t * flags, int space, void * strea
  * `smplpp_gather(comm, ...)`. */
 int smplpp_gather(void * comm, const float * send, float * recv, const int64_t * rows_per_rank, int world, int rank,
                   int64_t row_floats, void * stream);
+/* The same exchange to ONE rank (the usual consumer of a job's results): every other rank sends its block once, over its own
+ * xGMI link, straight into its slot of root's `recv` (grouped ncclSend / ncclRecv; `recv` may be NULL elsewhere) — an eighth
+ * of the all-gather's traffic at eight ranks.  In place on root when `send` is its own slot of `recv`. */
+int smplpp_gather_to_root(void * comm, const float * send, float * recv, const int64_t * rows_per_rank, int world, int rank, int root,
+                          int64_t row_floats, void * stream);
+/* Where each rank's block lies in the gathered array: offsets[world + 1] in floats (the last entry is the total).  Host-only
+ * arithmetic shared by the two collectives; callable without a GPU. */
+int smplpp_gather_offsets(const int64_t * rows_per_rank, int world, int64_t row_floats, int64_t * offsets);
 
 /* ------------------------------------------------------------------ VPoser decoder (src/VPoser.cpp) */
 /* VPoserDecoderImpl (VPoser.h:53-90): Linear(32,512) LeakyReLU Dropout(eval) Linear(512,512) LeakyReLU

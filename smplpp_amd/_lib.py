@@ -59,6 +59,7 @@ def load():
         "smplpp_profile_enable": [vp, C.c_int],
         "smplpp_profile_read": [vp, i64p, f64p],
         "smplpp_fk": [vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int, vp],
+        "smplpp_fk_status": [vp, C.POINTER(C.c_int), vp],
         "smplpp_stage_blend_shape": [C.c_int, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp],
         "smplpp_stage_joint_regression": [C.c_int, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int, vp],
         "smplpp_stage_world_transformation": [C.c_int, C.c_int64, vp, vp, vp, vp, C.c_int, vp],
@@ -81,6 +82,8 @@ def load():
         "smplpp_ik_get_vertices": [vp, vp, C.c_int, vp],
         "smplpp_ik_get_status": [vp, vp, C.c_int, vp],
         "smplpp_gather": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp],
+        "smplpp_gather_to_root": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp],
+        "smplpp_gather_offsets": [i64p, C.c_int, C.c_int64, i64p],
         "smplpp_vposer_create": [C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(vp)],
         "smplpp_vposer_destroy": [vp],
         "smplpp_vposer_forward": [vp, C.c_int64, vp, vp, vp, C.c_int, vp],

@@ -86,45 +86,6 @@ constexpr int HB_IMG = 12 * 1024;      // one slot of B2h = one LDS ring image
 constexpr int HB_G_BYTES = 72 * 1024;  // G2h of one frame tile
 constexpr int HB_CW_OFF = 8 * 1024;    // cw[64] inside slot 14
 constexpr float HB_SA = 64.0f;         // scale of the A operand (|c| <= 2, |beta| < 1023)
-// ---- K order of the fp16x2 form.  The blend-shape GEMM may sum its K = 224 terms in any order as long as A2h and B2h agree,
-// and so may the blend MFMAs over the 24 joints.  Both orders are chosen so that the in-kernel pose of skin_h.hip (one lane
-// per frame, one wavefront per ROLE = a set of kinematic chains of the standard SMPL tree) writes whole 16-byte fragment
-// chunks: k' (new) -> k (the reference's order [c(207) | beta(10) | 1], -1 = zero padding) is hp_kold(), blend slot -> joint
-// is HP_JSLOT.  The tables travel with the model (smplpp_model::kmap) for the kernels that index them at run time.
-constexpr int SMPL_PARENT[SMPLPP_JOINT_NUM] = {-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21};
-struct PoseRole
-{
-  int n;        // joints this role computes, in chain order (every parent earlier in the list)
-  int joint[9]; // the joints
-  int par[9];   // index of the parent INSIDE the list (-1: root)
-  int ncoef;    // joints whose pose coefficients this role writes
-  int coefj[8];
-};
-constexpr PoseRole HP_ROLE[4] = {
-    {9, {0, 3, 6, 9, 13, 16, 18, 20, 22}, {-1, 0, 1, 2, 3, 4, 5, 6, 7}, 5, {13, 16, 18, 20, 22, -1, -1, -1}}, // spine + left arm
-    {9, {0, 3, 6, 9, 14, 17, 19, 21, 23}, {-1, 0, 1, 2, 3, 4, 5, 6, 7}, 5, {14, 17, 19, 21, 23, -1, -1, -1}}, // spine + right arm
-    {9, {0, 1, 4, 7, 10, 2, 5, 8, 11}, {-1, 0, 1, 2, 3, 0, 5, 6, 7}, 8, {1, 4, 7, 10, 2, 5, 8, 11}},          // both legs
-    {6, {0, 3, 6, 9, 12, 15, -1, -1, -1}, {-1, 0, 1, 2, 3, 4, -1, -1, -1}, 5, {3, 6, 9, 12, 15, -1, -1, -1}},  // spine + head (+ beta, 1)
-};
-__host__ __device__ constexpr int hp_role_index(int role, int joint) // position of a joint in a role's list
-{
-  for(int q = 0; q < HP_ROLE[role].n; q++)
-    if(HP_ROLE[role].joint[q] == joint) return q;
-  return -1;
-}
-constexpr int HP_KBASE[4] = {72, 120, 0, 168}; // first k' of a role's coefficients: 9 | 6 | 6 | 7 chunks of 8 (role 2 first)
-constexpr int HP_K_BETA = 168 + 45, HP_K_ONE = 168 + 55;
-__host__ __device__ constexpr int hp_kold(int kn)
-{
-  for(int r = 0; r < 4; r++)
-    if(kn >= HP_KBASE[r] && kn < HP_KBASE[r] + HP_ROLE[r].ncoef * 9) return (HP_ROLE[r].coefj[(kn - HP_KBASE[r]) / 9] - 1) * 9 + (kn - HP_KBASE[r]) % 9;
-  if(kn >= HP_K_BETA && kn < HP_K_BETA + SMPLPP_SHAPE_BASIS_DIM) return SMPLPP_POSE_BASIS_DIM + (kn - HP_K_BETA);
-  if(kn == HP_K_ONE) return SMPLPP_POSE_BASIS_DIM + SMPLPP_SHAPE_BASIS_DIM;
-  return -1;
-}
-// blend slot (k of the blend MFMAs) -> joint: [legs 8 | left arm 4 | right arm 4 || spine 4 | head 2 | hands 2]
-constexpr int HP_JSLOT[SMPLPP_JOINT_NUM] = {1, 4, 7, 10, 2, 5, 8, 11, 13, 16, 18, 20, 14, 17, 19, 21, 0, 3, 6, 9, 12, 15, 22, 23};
-constexpr int HP_KMAP_SIZE = 224 + SMPLPP_JOINT_NUM; // kmap: [224] k' -> k | -1, then [24] slot -> joint
 constexpr float HB_SW = 16384.0f;      // scale of the skinning weights (|W| <= 1)
 __host__ __device__ inline void split_f16x2(float xs, _Float16 & hi, _Float16 & lo) // xs: already scaled
 {
@@ -224,6 +185,7 @@ struct smplpp_model
   int64_t VGPn = 0;            // vertex-group pairs: ceil(V / 64)
   uint8_t * B2h = nullptr;     // bases + skinning weights as fp16x2 pieces in MFMA fragment order (layout above)
   float sB = 1.0f, sG = 1.0f;  // power-of-two scales of the basis operand and of the relative transforms (fp16 range)
+  int * range_flag = nullptr;  // device word: bit 0 = a launch of the fp16x2 form met an operand outside fp16's range (smplpp_fk_status)
   char form = 'h';             // fused-kernel form (SMPLPP_SKIN, read once at model creation): h | b | p | v
   uint8_t * wIdx = nullptr;    // [VGn*32][maxw]
   float * wVal = nullptr;      // [VGn*32][maxw]
@@ -231,10 +193,6 @@ struct smplpp_model
   float * J0 = nullptr;        // [24][3]      Jreg . T
   float * JS = nullptr;        // [24][3][10]  Jreg . S
   int32_t * parent = nullptr;  // [24]
-  int16_t * kmap = nullptr;    // [HP_KMAP_SIZE] K order of the fp16x2 form (common.h: hp_kold, HP_JSLOT)
-  bool std_tree = false;       // the kinematic tree is the standard SMPL tree (SMPL_PARENT): skin_h.hip may pose in-kernel
-  bool pose_wave = true;       // form h: pose_kernel_w (one wavefront per frame) instead of pose_kernel (SMPLPP_POSE_WAVE=0: the latter)
-  bool pose_fused = false;     // ... and does (std_tree, form h, SMPLPP_POSE_FUSED != 0 at model creation)
   int32_t * lvl = nullptr;     // [25 + 24] kinematic tree by depth: level offsets, then the joints sorted by level
   int nlev = 0;
   bool chain_fast = false;     // lvl also holds the (level, slot) -> (joint, parent) table of the pose kernel's chain

@@ -17,7 +17,7 @@
 // given to one XCD, consecutively, so each 338 KB slice of Bm is pulled into that XCD's L2 once per launch.
 #include "common.h"
 #include "pose_math.h"
-#include "pose_wave.h"
+#include "trace.h"
 
 namespace smplpp_hip
 {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
                                                    float * __restrict__ rot_out, float * __restrict__ xf44_out, int64_t n,
                                                    uint16_t * __restrict__ A3, _Float16 * __restrict__ A2h,
                                                    _Float16 * __restrict__ G2h, float gscale, const int32_t * __restrict__ ctab,
-                                                   const int16_t * __restrict__ kmap)
+                                                   int * __restrict__ range_flag)
 {
   const int64_t f = blockIdx.x;
   const int tid = threadIdx.x;
@@ -191,9 +191,10 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
 #pragma unroll
     for(int j = 0; j < 8; j++)
     {
-      const int k = kmap[8 * c + j]; // K order of the fp16x2 form (common.h: hp_kold); -1 = zero padding
       _Float16 a, b;
-      split_f16x2((k >= 0 ? sCoef[k] : 0.0f) * HB_SA, a, b);
+      const float xs = sCoef[8 * c + j] * HB_SA;
+      if(!(__builtin_fabsf(xs) <= 65504.0f)) atomicOr(range_flag, 1); // outside fp16's range (|beta| >= 1023) or not finite
+      split_f16x2(xs, a, b);
       hi[j] = a;
       lo[j] = b;
     }
@@ -298,10 +299,11 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
 #pragma unroll
     for(int j = 0; j < 8; j++)
     {
-      const int i = kmap[224 + 8 * c + j]; // blend slot -> joint (common.h: HP_JSLOT)
+      const int i = 8 * c + j;
       float v = sG[i][e];
       if(cc == 3) v = relative_t(v, sG[i][r4 * 4 + 0], sG[i][r4 * 4 + 1], sG[i][r4 * 4 + 2], sJ[i][0], sJ[i][1], sJ[i][2]);
       _Float16 a, b;
+      if(!(__builtin_fabsf(v * gscale) <= 65504.0f)) atomicOr(range_flag, 1); // a transform outside 16 x the template's extent
       split_f16x2(v * gscale, a, b);
       hi[j] = a;
       lo[j] = b;
@@ -319,21 +321,6 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
     }
   }
   PST(6);
-}
-
-// The pose step of the fp16x2 form, one wavefront per frame (pose_wave.h), four frames per workgroup: at batch 1024 one
-// workgroup per CU whose four wavefronts each run a single global round trip and ~3k cycles of lane-parallel work, instead of
-// four wavefronts sharing one frame through workgroup barriers (pose_kernel: 11k cycles per frame).
-__global__ __launch_bounds__(256) void pose_kernel_w(const float * __restrict__ beta, const float * __restrict__ theta,
-                                                     const float * __restrict__ J0, const float * __restrict__ JS,
-                                                     const int32_t * __restrict__ ctab, int nlev, const int16_t * __restrict__ kmap,
-                                                     float gscale, int64_t n, PoseWaveOut o)
-{
-  __shared__ __attribute__((aligned(16))) float scr[4][PW_SCR_FLOATS];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int64_t f = (int64_t)blockIdx.x * 4 + wave;
-  if(f >= n) return;
-  pose_frame_wave(lane, f, beta, theta, J0, JS, ctab, nlev, kmap, gscale, scr[wave], o);
 }
 
 // rows [n, ldA) of AT are padding for the last 32-frame tile: keep them zero (re-zeroed whenever n changes)
@@ -532,8 +519,7 @@ static hipError_t launch_skin_w(const smplpp_model * m, int64_t n, const float *
 hipError_t launch_skin_persistent(const smplpp_model * m, int64_t n, const float * theta, const float * Gp_padded, float * verts,
                                   float * rest, hipStream_t st); // skin_p.hip (fp32 MFMA, one wave/SIMD, epilogue in the MFMA shadow)
 hipError_t launch_skin_bf16x3(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st); // skin_b.hip
-hipError_t launch_skin_f16x2(const smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * rest,
-                             hipStream_t st, bool pose); // skin_h.hip
+hipError_t launch_skin_f16x2(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st);  // skin_h.hip
 
 // Device-pointer FK (enqueue only).  Used by smplpp_fk and by the IK solver.
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
@@ -548,29 +534,14 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
   if(form == 'p' && n * m->V * 12 >= 0x7fffff00LL) form = 'v';
   const int64_t n64 = ((n + 63) / 64) * 64;
   HIP_TRY(ws.Gp.reserve(sizeof(float) * (size_t)n64 * NJ * 12)); // b / p stage whole frame tiles of G' (padding never stored)
-  // h, standard SMPL tree, only vertices / rest shape wanted: the fused kernel computes the pose step of its frame tiles itself
-  // (skin_h.hip, POSE) — no pose_kernel launch, no A2h / G2h / G' round trip.  SMPLPP_POSE_FUSED=0 at model creation keeps the
-  // two-kernel path (A/B runs; tests compare the two bit for bit).
-  const bool pose_fused = form == 'h' && m->pose_fused && beta && !joints && !xforms44 && !poserot && (verts || rest);
-  if(pose_fused)
-  {
-  }
-  else if(form == 'h' && m->chain_fast && m->pose_wave)
-  {
-    HIP_TRY(ws.A2h.reserve((size_t)(n64 / 64) * HB_KS * HB_A_BYTES));
-    HIP_TRY(ws.G2h.reserve((size_t)(n64 / 64) * HB_G_BYTES));
-    PoseWaveOut o = {ws.Gp.as<float>(), joints, poserot, xforms44, (verts || rest) ? ws.A2h.as<_Float16>() : nullptr,
-                     (verts || rest) ? ws.G2h.as<_Float16>() : nullptr};
-    pose_kernel_w<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->lvl + NJ + 1 + NJ, m->nlev, m->kmap, m->sG, n, o);
-  }
-  else if(form == 'h')
+  if(form == 'h')
   {
     HIP_TRY(ws.A2h.reserve((size_t)(n64 / 64) * HB_KS * HB_A_BYTES));
     HIP_TRY(ws.G2h.reserve((size_t)(n64 / 64) * HB_G_BYTES));
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
                                                          ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr,
                                                          (verts || rest) ? ws.A2h.as<_Float16>() : nullptr,
-                                                         (verts || rest) ? ws.G2h.as<_Float16>() : nullptr, m->sG, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr, m->kmap);
+                                                         (verts || rest) ? ws.G2h.as<_Float16>() : nullptr, m->sG, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr, m->range_flag);
   }
   else if(form == 'b')
   {
@@ -599,14 +570,19 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
     if(m->profiling)
     {
       // (owned by the handle from the moment they exist: smplpp_profile_read / smplpp_model_destroy release them)
+      // (owned by the handle as a PAIR: a failed second creation must not leave the begin/end list misaligned)
       HIP_TRY(hipEventCreate(&e0));
+      if(hipError_t ee = hipEventCreate(&e1); ee != hipSuccess)
+      {
+        (void)hipEventDestroy(e0);
+        return hip_fail(ee, "hipEventCreate", __FILE__, __LINE__);
+      }
       m->prof_events.push_back(e0);
-      HIP_TRY(hipEventCreate(&e1));
       m->prof_events.push_back(e1);
       HIP_TRY(hipEventRecord(e0, st));
     }
     if(form == 'h')
-      HIP_TRY(launch_skin_f16x2(m, n, beta, theta, verts, rest, st, pose_fused));
+      HIP_TRY(launch_skin_f16x2(m, n, theta, verts, rest, st));
     else if(form == 'b')
       HIP_TRY(launch_skin_bf16x3(m, n, theta, verts, rest, st));
     else if(form == 'p' && ws.dummy.reserve(4096) == hipSuccess)
@@ -655,6 +631,24 @@ extern "C" int smplpp_profile_read(smplpp_model * m, int64_t * launches, double 
   return SMPLPP_OK;
 }
 
+// reads and clears the range word of the fp16x2 form (the caller has synchronised the stream)
+static int fk_range_status(smplpp_model * m, int * bits)
+{
+  *bits = 0;
+  if(!m->range_flag || m->form != 'h') return SMPLPP_OK;
+  HIP_TRY(hipMemcpy(bits, m->range_flag, sizeof(int), hipMemcpyDeviceToHost));
+  if(*bits) HIP_TRY(hipMemset(m->range_flag, 0, sizeof(int)));
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_fk_status(smplpp_model * m, int * bits, void * stream)
+{
+  if(!m || !bits) return fail(SMPLPP_ERR_INVALID, "smplpp_fk_status: null argument");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return fk_range_status(m, bits);
+}
+
 extern "C" int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
                          float * xforms, float * rest, int space, void * stream)
 {
@@ -663,6 +657,7 @@ extern "C" int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const 
   if(space != SMPLPP_HOST && space != SMPLPP_DEVICE) return fail(SMPLPP_ERR_INVALID, "smplpp_fk: bad memory space");
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
+  TraceRange tr_fwd("forward SMPL"); // the reference's span around SMPL::launch (node/node.cpp:752-781)
   if(space == SMPLPP_DEVICE) return fk_device(m, n, beta, theta, verts, joints, xforms, rest, nullptr, st);
 
   Workspace & ws = m->ws;
@@ -685,5 +680,10 @@ extern "C" int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const 
   if(joints) HIP_TRY(hipMemcpyAsync(joints, ws.joints.p, sizeof(float) * (size_t)n * NJ * 3, hipMemcpyDeviceToHost, st));
   if(xforms) HIP_TRY(hipMemcpyAsync(xforms, ws.xf44.p, sizeof(float) * (size_t)n * NJ * 16, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  int bits = 0;
+  if(int rs = fk_range_status(m, &bits)) return rs;
+  if(bits & 1)
+    return fail(SMPLPP_ERR_NUMERIC, "smplpp_fk: an operand left the range of the fp16x2 form (|beta| < 1023, relative transforms within 16 x the "
+                                    "template's extent): the vertices of such frames are not finite; create the model under SMPLPP_SKIN=b or p");
   return SMPLPP_OK;
 }

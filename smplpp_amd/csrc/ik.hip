@@ -16,6 +16,7 @@
 // All fp32 where the reference is fp32 (FK, task geometry, autograd gradients), fp64 where it is fp64 (Eigen).
 #include "mesh_device.h"
 #include "staging.h"
+#include "trace.h"
 
 #include <hip/hip_ext.h>
 
@@ -263,7 +264,10 @@ __device__ inline void st_agent(T * p, T v)
 __device__ inline void wg_signal(unsigned * __restrict__ flag, unsigned * __restrict__ counter, unsigned tick)
 {
   if(!flag) return;
-  __syncthreads(); // every thread's stores are issued and complete (s_waitcnt vmcnt(0) in front of the barrier)
+  // every thread's stores have been acknowledged before the workgroup counts itself in: the wait is explicit (the barrier
+  // alone orders LDS and, outside threadgroup-split mode, is not defined to drain the vector-memory counter)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if(threadIdx.x == 0)
   {
     if(__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
@@ -617,7 +621,10 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       ta.tang[(tb + k) * 6 + x * 2 + 0] = t1[x];
       ta.tang[(tb + k) * 6 + x * 2 + 1] = t2[x];
       pos804[(tb + k) * 3 + x] = pos[x];
-      ta.vw[(tb + k) * 3 + x] = w[x];
+      // (write-through like the re-projection's own store to the same word, proj_finish_kernel: that kernel starts on the
+      // other stream as soon as this one's flag is up, BEFORE this kernel's end-of-kernel write-back — a plain store here
+      // could reach memory after the re-projected weights and overwrite them)
+      st_agent(&ta.vw[(tb + k) * 3 + x], w[x]);
       st_agent(&ta.apos[(tb + k) * 3 + x], ap[x]);
       e_out[(f * K + k) * 4 + x] = (double)(wp * (ap[x] - tp[x])); // node.cpp:807
     }
@@ -2505,9 +2512,21 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
     A_(vjac, (size_t)n * 63 * 32);
   }
 #undef A_
+  // (from here on a failure releases the solver with everything it already owns: arrays, side stream, events)
+#define S_TRY(expr)                                            \
+  do                                                           \
+  {                                                            \
+    hipError_t _e = (expr);                                    \
+    if(_e != hipSuccess)                                       \
+    {                                                          \
+      int _rc = hip_fail(_e, #expr, __FILE__, __LINE__);       \
+      smplpp_ik_destroy(s);                                    \
+      return _rc;                                              \
+    }                                                          \
+  } while(0)
   // IkTask defaults (include/smplpp/IkTask.h:54-84)
   auto grid = [](size_t c) { return dim3((unsigned)((c + 255) / 256)); };
-  HIP_TRY(hipMemset(s->ta.face, 0, sizeof(int32_t) * nk));
+  S_TRY(hipMemset(s->ta.face, 0, sizeof(int32_t) * nk));
   fill_f32_kernel<<<grid(nk * 3), 256>>>(s->ta.vw, 1.0f / 3.0f, nk * 3);
   fill_f32_kernel<<<grid(nk * 6), 256>>>(s->ta.tang, 0.0f, nk * 6);
   fill_f32_kernel<<<grid(nk * 3), 256>>>(s->ta.tpos, 0.0f, nk * 3);
@@ -2516,21 +2535,21 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   fill_f32_kernel<<<grid(nk), 256>>>(s->ta.nrmw, 1.0f, nk);
   fill_f32_kernel<<<grid(nk), 256>>>(s->ta.philim, 0.04f, nk);
   fill_f32_kernel<<<grid(nk), 256>>>(s->ta.noff, 0.0f, nk);
-  HIP_TRY(hipMemset(s->theta, 0, sizeof(float) * n * s->theta_dim));
-  HIP_TRY(hipMemset(s->theta25, 0, sizeof(float) * n * 75));
-  HIP_TRY(hipMemset(s->beta, 0, sizeof(float) * n * NB));
-  HIP_TRY(hipMemset(s->skip, 0, sizeof(int) * n));
-  HIP_TRY(hipMemcpy(s->roles, roles.data(), sizeof(int32_t) * roles.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(s->list_cnt, 0, sizeof(int) * nk));
-  HIP_TRY(hipMemset(s->status, 0, sizeof(int) * n));
-  HIP_TRY(hipMemset(s->sticky, 0, sizeof(int) * n));
+  S_TRY(hipMemset(s->theta, 0, sizeof(float) * n * s->theta_dim));
+  S_TRY(hipMemset(s->theta25, 0, sizeof(float) * n * 75));
+  S_TRY(hipMemset(s->beta, 0, sizeof(float) * n * NB));
+  S_TRY(hipMemset(s->skip, 0, sizeof(int) * n));
+  S_TRY(hipMemcpy(s->roles, roles.data(), sizeof(int32_t) * roles.size(), hipMemcpyHostToDevice));
+  S_TRY(hipMemset(s->list_cnt, 0, sizeof(int) * nk));
+  S_TRY(hipMemset(s->status, 0, sizeof(int) * n));
+  S_TRY(hipMemset(s->sticky, 0, sizeof(int) * n));
   s->verts = s->vbuf[0];
-  HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+  S_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+  S_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+  S_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   {
-    HIP_TRY(dalloc(s, &s->sig, 64));
-    HIP_TRY(hipMemset(s->sig, 0, sizeof(unsigned) * 64));
+    S_TRY(dalloc(s, &s->sig, 64));
+    S_TRY(hipMemset(s->sig, 0, sizeof(unsigned) * 64));
     // stream memory operations are optional in HIP: probe once (flag 0 >= 0 is satisfied at once); SMPLPP_IK_EVENTS=1 keeps events
     const char * e = getenv("SMPLPP_IK_EVENTS");
     if(!(e && e[0] != '0'))
@@ -2539,7 +2558,8 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
       (void)hipGetLastError();
     }
   }
-  HIP_TRY(hipDeviceSynchronize());
+  S_TRY(hipDeviceSynchronize());
+#undef S_TRY
   *out = s;
   return SMPLPP_OK;
 }
@@ -2601,6 +2621,9 @@ extern "C" int smplpp_ik_set_config(smplpp_ik * s, const float * beta, const flo
   hipMemcpyKind kind = space == SMPLPP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   if(beta) HIP_TRY(hipMemcpy(s->beta, beta, sizeof(float) * s->n * NB, kind));
   if(theta) HIP_TRY(hipMemcpy(s->theta, theta, sizeof(float) * s->n * s->theta_dim, kind));
+  // status bit 1 (smplpp_ik_get_status) reports failures "since the configuration was set": a new configuration starts clean
+  HIP_TRY(hipMemset(s->status, 0, sizeof(int) * s->n));
+  HIP_TRY(hipMemset(s->sticky, 0, sizeof(int) * s->n));
   if(theta && s->vp) // latent layout: the entries that pass through to theta25 (the decoder fills the rest at every evaluation)
   {
     ik_splice_kernel<<<dim3((unsigned)((s->n * 75 + 255) / 256)), 256>>>(s->theta, nullptr, s->theta25, s->n);
@@ -2663,18 +2686,22 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   const int64_t n = s->n;
   const int K = (int)s->K;
   const float * th25 = s->theta;
-  if(s->vp) // node.cpp:761-772
   {
-    // the decoder writes its 63 angles straight into theta25[:, 6:69]; the pass-through entries (root translation / rotation,
-    // joints 22-23) are kept current by whoever changes the configuration: smplpp_ik_set_config and the solve kernel's update
-    int rc = vposer_forward_device(s->vp, n, s->theta + 6, TD44, s->theta25 + 6, 75, s->vjac, st);
+    TraceRange tr_fwd("forward SMPL"); // node.cpp:752-781 (the VPoser splice is inside that span there too)
+    if(s->vp) // node.cpp:761-772
+    {
+      // the decoder writes its 63 angles straight into theta25[:, 6:69]; the pass-through entries (root translation / rotation,
+      // joints 22-23) are kept current by whoever changes the configuration: smplpp_ik_set_config and the solve kernel's update
+      int rc = vposer_forward_device(s->vp, n, s->theta + 6, TD44, s->theta25 + 6, 75, s->vjac, st);
+      if(rc) return rc;
+      th25 = s->theta25;
+    }
+    s->vcur ^= 1;
+    s->verts = s->vbuf[s->vcur];
+    int rc = fk_device(m, n, s->beta, th25, s->verts, s->joints, nullptr, s->rest, s->poserot, st); // node.cpp:777
     if(rc) return rc;
-    th25 = s->theta25;
   }
-  s->vcur ^= 1;
-  s->verts = s->vbuf[s->vcur];
-  int rc = fk_device(m, n, s->beta, th25, s->verts, s->joints, nullptr, s->rest, s->poserot, st); // node.cpp:777
-  if(rc) return rc;
+  TraceRange tr_eval("calculate IK matrices"); // node.cpp:796-881
   if(s->side_pending) // the previous iteration's re-projection (side stream) wrote the faces / weights read from here on
   {
     if(s->use_flags)
@@ -2782,17 +2809,21 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
 #define SOLVE11_() ik_solve_kernel<false, 11><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
     s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
     s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr)
-    if(dual_only)
-      SOLVE_(true);
-    else if(ntr == 11)
-      SOLVE11_();
-    else
-      SOLVE_(false);
+    {
+      TraceRange tr_solve("solve IK"); // node.cpp:907-943
+      if(dual_only)
+        SOLVE_(true);
+      else if(ntr == 11)
+        SOLVE11_();
+      else
+        SOLVE_(false);
+    }
 #undef SOLVE_
 #undef SOLVE11_
     HIP_TRY(hipGetLastError());
     DBG_SYNC("solve");
     {
+      TraceRange tr_proj("project point"); // node.cpp:974-988
       const float * qpts = beside ? s->ta.apos : s->pts;
       hipStream_t pst = st;
       if(beside)

@@ -73,8 +73,10 @@ __global__ __launch_bounds__(1024) void bounds_kernel(const float * __restrict__
     for(int x = 0; x < 3; x++)
     {
       const float c = verts[v * 3 + x];
-      mn[x] = fminf(mn[x], c);
-      mx[x] = fmaxf(mx[x], c);
+      // (fminf / fmaxf drop NaNs: a non-finite coordinate is turned into an infinite bound so that the host's check fires)
+      const bool bad = !(__builtin_fabsf(c) <= 3.0e38f);
+      mn[x] = bad ? -__builtin_inff() : fminf(mn[x], c);
+      mx[x] = bad ? __builtin_inff() : fmaxf(mx[x], c);
     }
   for(int x = 0; x < 3; x++)
     for(int off = 32; off > 0; off >>= 1)
@@ -284,12 +286,14 @@ extern "C" int smplpp_sweep_grid(smplpp_model * m, const float * verts, int32_t 
   for(int x = 0; x < 3; x++)
   {
     if(!std::isfinite(h[x]) || !std::isfinite(h[3 + x])) return fail(SMPLPP_ERR_NUMERIC, "smplpp_sweep_grid: non-finite vertices");
+    // a grid of 2.5 cm cells around a body: anything beyond +-25 km is not a posed mesh (and would not fit an int / the product)
+    if(std::fabs(h[x]) > 2.5e4f || std::fabs(h[3 + x]) > 2.5e4f) return fail(SMPLPP_ERR_NUMERIC, "smplpp_sweep_grid: vertices out of range");
     g0[x] = (int)std::floor(h[x] / scale);           // getGridIdxFloor (GridUtils.hpp:46-50)
     const int g1 = (int)std::ceil(h[3 + x] / scale); // getGridIdxCeil (:56-60)
     gn[x] = g1 - g0[x] + 1;
     grid_min[x] = g0[x];
     grid_num[x] = gn[x];
-    total *= gn[x];
+    total *= gn[x]; // (gn <= 2e6 + 2 each: the product of three fits int64)
   }
   *cells = total;
   const int64_t todo = total < cap ? total : cap;

@@ -97,7 +97,7 @@ __global__ void relayout_basis_bf16x3_kernel(const float * __restrict__ Bm, int6
 // chunk pair (hi, lo): slots 0..13: ((vg * 15 + ks) * 6 + vh * 3 + x) * 64 + lane; slot 14: weights, cw, padding.
 __global__ void relayout_basis_f16x2_kernel(const float * __restrict__ Bm, int64_t ldB, const float * __restrict__ W,
                                             const float * __restrict__ wSum, int64_t V, int64_t nvg, float sB, float sG,
-                                            const int16_t * __restrict__ kmap, uint8_t * __restrict__ B2h)
+                                            uint8_t * __restrict__ B2h)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int per_vg = HB_KS * 6 * 64 + 4 * 64 + 64; // basis chunk pairs + weight chunk pairs + cw entries
@@ -113,8 +113,8 @@ __global__ void relayout_basis_f16x2_kernel(const float * __restrict__ Bm, int64
     const int64_t v = vg * 64 + vh * 32 + r;
     for(int j = 0; j < 8; j++)
     {
-      const int k = kmap[ks * 16 + 8 * h + j]; // K order of the fp16x2 form (common.h: hp_kold); -1 = zero padding
-      const float val = (v < V && k >= 0 && k < KP) ? Bm[(int64_t)k * ldB + bcol(v, x)] : 0.0f;
+      const int k = ks * 16 + 8 * h + j;
+      const float val = (v < V && k < KP) ? Bm[(int64_t)k * ldB + bcol(v, x)] : 0.0f;
       _Float16 a, b;
       split_f16x2(val * sB, a, b);
       hi[j] = a;
@@ -130,8 +130,8 @@ __global__ void relayout_basis_f16x2_kernel(const float * __restrict__ Bm, int64
     const int64_t v = vg * 64 + vh * 32 + r;
     for(int j = 0; j < 8; j++)
     {
-      const int slot = ks * 16 + 8 * h + j; // blend slot -> joint (common.h: HP_JSLOT)
-      const float val = (v < V && slot < NJ) ? W[v * NJ + kmap[224 + slot]] : 0.0f;
+      const int k = ks * 16 + 8 * h + j; // joint
+      const float val = (v < V && k < NJ) ? W[v * NJ + k] : 0.0f;
       _Float16 a, b;
       split_f16x2(val * HB_SW, a, b);
       hi[j] = a;
@@ -234,7 +234,7 @@ extern "C" int smplpp_model_destroy(smplpp_model * m)
   (void)hipSetDevice(m->device);
   for(hipEvent_t e : m->prof_events) (void)hipEventDestroy(e);
   m->prof_events.clear();
-  void * ptrs[] = {m->Bm, m->B3, m->B2h, m->kmap, m->lvl, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm, m->faceRing, m->faceMap, m->anc};
+  void * ptrs[] = {m->Bm, m->B3, m->B2h, m->range_flag, m->lvl, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm, m->faceRing, m->faceMap, m->anc};
   for(void * p : ptrs)
     if(p) (void)hipFree(p);
   Workspace & w = m->ws;
@@ -325,6 +325,10 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   relayout_basis_kernel<<<dim3((unsigned)((m->ldB + 255) / 256)), dim3(256)>>>(m->Pvm, m->Svm, dT.as<float>(), m->Bm, V, m->ldB);
   fold_regressor_kernel<<<dim3(NJ * 3 * (NB + 1)), dim3(256)>>>(dJreg.as<float>(), m->Svm, dT.as<float>(), m->J0, m->JS, V);
   m->VGPn = (V + 63) / 64;
+  // the split-operand kernels address their basis images with 32-bit buffer offsets: a mesh whose image would reach 2 GiB
+  // (more than ~745k vertices for h, ~410k for b) takes the first form (64-bit addressing) from creation on
+  if(m->form == 'h' && (int64_t)m->VGPn * HB_SLOTS * HB_IMG > 0x7fffff00LL) m->form = 'v';
+  if(m->form == 'b' && (int64_t)m->VGPn * BB_KS * BB_B_BYTES > 0x7fffff00LL) m->form = 'v';
   if(m->form == 'b')
   {
     TRY_TMP(hipMalloc((void **)&m->B3, (size_t)m->VGPn * BB_KS * BB_B_BYTES));
@@ -393,15 +397,9 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
     m->sB = std::exp2(std::floor(std::log2(32768.0f / bmax)));
     m->sG = std::exp2(std::floor(std::log2(32768.0f / (16.0f * tmax > 1.0f ? 16.0f * tmax : 1.0f))));
     TRY_OR_FREE(hipMalloc((void **)&m->B2h, (size_t)m->VGPn * HB_SLOTS * HB_IMG));
-    {
-      std::vector<int16_t> km(HP_KMAP_SIZE);
-      for(int k = 0; k < 224; k++) km[k] = (int16_t)hp_kold(k);
-      for(int sl = 0; sl < NJ; sl++) km[224 + sl] = (int16_t)HP_JSLOT[sl];
-      TRY_OR_FREE(upload(&m->kmap, km.data(), km.size()));
-    }
     const int64_t cnt = m->VGPn * (HB_KS * 6 * 64 + 4 * 64 + 64);
     relayout_basis_f16x2_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256)>>>(m->Bm, m->ldB, m->Wdense, m->wSum, V, m->VGPn,
-                                                                                 m->sB, m->sG, m->kmap, m->B2h);
+                                                                                 m->sB, m->sG, m->B2h);
     TRY_OR_FREE(hipGetLastError());
     TRY_OR_FREE(hipDeviceSynchronize());
   }
@@ -419,13 +417,9 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
     m->Bm = nullptr;
   }
   TRY_OR_FREE(upload(&m->parent, parent.data(), parent.size()));
-  m->std_tree = true;
-  for(int i = 0; i < NJ; i++) m->std_tree = m->std_tree && parent[i] == SMPL_PARENT[i];
   {
-    const char * pf = getenv("SMPLPP_POSE_FUSED"); // read once, here (default on)
-    m->pose_fused = m->std_tree && m->form == 'h' && !(pf && pf[0] == '0');
-    const char * pw = getenv("SMPLPP_POSE_WAVE");
-    m->pose_wave = !(pw && pw[0] == '0');
+    const int zero = 0;
+    TRY_OR_FREE(upload(&m->range_flag, &zero, 1));
   }
   {
     // joints by depth: the FK chain advances one tree level per step (SMPL: 9 levels)

@@ -22,16 +22,7 @@
 // (buffer_load_dwordx4 ... lds) seven slots ahead; slot 14 of an item carries the group's skinning weights.
 // One raw s_barrier per slot publishes the next image (counted vmcnt: DMAs stay in flight across it).
 // XCD x owns an eighth of the vertex groups (its slice of B2h, 2.4 MB, lives in that XCD's L2 and is read from HBM once).
-//
-// POSE (template): the workgroup computes the pose step of its frame tile ITSELF (Rodrigues, joints, kinematic chain, relative
-// transforms: /root/reference/src/BlendShape.cpp:803-895, src/JointRegression.cpp:583-598, src/WorldTransformation.cpp:421-677)
-// while its ring prefetch is in flight, instead of reading A2h / G2h written by a pose_kernel launch in front of it: one lane
-// per frame, one wavefront per ROLE (a set of kinematic chains of the standard SMPL tree, common.h HP_ROLE), everything in
-// registers, the coefficient fragments through an LDS image into the A registers, the G' fragments straight into the LDS
-// image the blend MFMAs read.  The sixteen workgroups that share a frame tile each do this (redundantly): it removes a 9 us
-// kernel and a kernel boundary from a 53 us step.  Same arithmetic, same order as pose_kernel (pose_math.h): same bits.
 #include "common.h"
-#include "pose_math.h"
 
 #include <type_traits>
 #include <utility>
@@ -43,9 +34,6 @@ typedef float v3f __attribute__((ext_vector_type(3), aligned(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v3u __attribute__((ext_vector_type(3)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float v4fu __attribute__((ext_vector_type(4), aligned(4))); // 16-byte load from a 4-byte-aligned address
 
 constexpr int H_R = 7;                                  // ring images (15 slots per item: the ring rotates by one per item)
 constexpr int H_LDS_RING = HB_G_BYTES;                  // [0, 72 KiB): G' operand of the frame tile
@@ -90,14 +78,13 @@ constexpr int h_tail_rows_in(int u) // tail rows issued in GEMM slot u
 //   u < 14 and the item carries the previous item's tail (ht): its vertex stores of that slot (1 or 2)
 //   u < 9 and the item follows a frame tile set-up (!ht): 2 DMAs of the new G' image (18 in all; first reader: slot 13)
 //   u == 14 and `rest` is wanted: 16 rest stores (blend phase)
-// gdma: the item DMAs the G' image of its frame tile (an item behind a frame tile set-up of the non-POSE kernel)
-constexpr int h_after_dma(int u, bool ht, bool rest, bool gdma)
+constexpr int h_after_dma(int u, bool ht, bool rest)
 {
-  return u < 14 ? (ht ? h_tail_rows_in(u) : ((gdma && u < 9) ? 2 : 0)) : ((u == 14 && rest) ? 16 : 0);
+  return u < 14 ? (ht ? h_tail_rows_in(u) : (u < 9 ? 2 : 0)) : ((u == 14 && rest) ? 16 : 0);
 }
-constexpr int h_slot_ops(int u, bool ht, bool rest, bool gdma)
+constexpr int h_slot_ops(int u, bool ht, bool rest)
 {
-  return 3 + h_after_dma(u, ht, rest, gdma);
+  return 3 + h_after_dma(u, ht, rest);
 }
 // vmcnt of the barrier of slot s: the image of slot s + 1 was DMA'd behind the barrier of slot s - 6; everything issued
 // after those DMAs may stay in flight.
@@ -105,17 +92,16 @@ constexpr int h_slot_ops(int u, bool ht, bool rest, bool gdma)
 // count must never exceed what was really issued behind the DMAs it protects; a smaller count only waits for older
 // operations, all issued thousands of cycles earlier).  An item behind a frame tile set-up (!ht) has no previous item in
 // flight at all: the set-up left the ring's DMAs only.
-constexpr int h_barrier_vmcnt(int s, bool ht, bool rest, bool gdma = true)
+constexpr int h_barrier_vmcnt(int s, bool ht, bool rest)
 {
-  if(!ht && gdma && s == 13) return 12; // the barrier in front of the first G' reads: only the ring DMAs of slots 9..12 are younger than the image
-  int c = s - 6 < 0 ? ((wrap15(s - 6) == 14 && rest && ht) ? 16 : 0) : h_after_dma(s - 6, ht, rest, gdma);
-  for(int u = s - 5; u < s; u++) c += u < 0 ? 3 + ((wrap15(u) == 14 && rest && ht) ? 16 : 0) : h_slot_ops(u, ht, rest, gdma);
+  if(!ht && s == 13) return 12; // the barrier in front of the first G' reads: only the ring DMAs of slots 9..12 are younger than the image
+  int c = s - 6 < 0 ? ((wrap15(s - 6) == 14 && rest && ht) ? 16 : 0) : h_after_dma(s - 6, ht, rest);
+  for(int u = s - 5; u < s; u++) c += u < 0 ? 3 + ((wrap15(u) == 14 && rest && ht) ? 16 : 0) : h_slot_ops(u, ht, rest);
   return c < 63 ? c : 63;
 }
 static_assert(h_tail_rows_in(4) == 2 && h_tail_rows_in(9) == 2 && h_tail_rows_in(13) == 1 && h_tail_rows_in(14) == 0, "tail placement");
 static_assert(h_barrier_vmcnt(0, false, true) == 15 && h_barrier_vmcnt(1, false, false) == 12 + 5 && h_barrier_vmcnt(0, true, true) == 31 &&
-                  h_barrier_vmcnt(1, true, false) == 5 * 3 + 1 && h_barrier_vmcnt(8, true, false) == 15 + 7 && h_barrier_vmcnt(14, false, false) == 2 + 15 &&
-                  h_barrier_vmcnt(0, false, false, false) == 15 && h_barrier_vmcnt(8, false, false, false) == 15 && h_barrier_vmcnt(13, false, true, false) == 15,
+                  h_barrier_vmcnt(1, true, false) == 5 * 3 + 1 && h_barrier_vmcnt(8, true, false) == 15 + 7 && h_barrier_vmcnt(14, false, false) == 2 + 15,
               "window bookkeeping");
 
 template<int VM>
@@ -126,10 +112,6 @@ __device__ __forceinline__ void h_barrier()
 #else
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
 #endif
-}
-__device__ __forceinline__ void h_lds_barrier() // orders LDS traffic only (global operations stay in flight)
-{
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ __forceinline__ void h_full_barrier()
 {
@@ -142,22 +124,16 @@ __device__ __forceinline__ void h_full_barrier()
 #ifndef SKINH_ABL
 #define SKINH_ABL 0 // timing ablations (development only; results are wrong when non-zero): 1 no s_barrier, 2 no DMA, 4 no GEMM MFMAs, 8 no blend phase, 16 no fragment reads, 32 no stores, 256 slot timestamps, 512 phase timestamps (cycle counter + 100 MHz real-time counter)
 #endif
-#if SKINH_ABL & 512
-#define PSTAMP(k) if(blockIdx.x == 8 && (tid & 63) == 0) g_hslot_times[256 + dbg_rep * 64 + wave * 16 + (k)] = __builtin_amdgcn_s_memtime()
-#else
-#define PSTAMP(k)
-#endif
 #if SKINH_ABL & (256 | 512)
 __device__ unsigned long long g_hslot_times[8 * 256];
 __device__ unsigned long long g_hwg_times[256 * 4];
 #endif
 
-template<bool WANT_REST, bool POSE>
+template<bool WANT_REST>
 __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restrict__ A2h, const uint8_t * __restrict__ B2h,
                                                         const uint8_t * __restrict__ G2h, const float * __restrict__ theta,
                                                         float * __restrict__ verts, float * __restrict__ rest, int64_t n,
-                                                        int64_t V, int nvg, int nft, float cAB, const float * __restrict__ beta,
-                                                        const float * __restrict__ J0, const float * __restrict__ JS, float gscale)
+                                                        int64_t V, int nvg, int nft, float cAB)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   typedef __attribute__((address_space(3))) void * lds_ptr_t;
@@ -199,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
   const unsigned char * const trLane = lds + H_LDS_TR + (wf * 32 + 4 * half) * 16; // accumulator row R: + rowc(R) * 16
 
 #if SKINH_ABL & (256 | 512)
-  int dbg_item = 0, dbg_rep = 0;
+  int dbg_item = 0;
 #endif
   f32x16 acc[3], macc[2];
   float tt[16], o0[16], o1[16];
@@ -301,247 +277,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
 #endif
   };
 
-
-  // ---- frame tile set-up of the POSE kernel: the pose step of the tile's 64 frames, by this workgroup.
-  // LDS: the G' region [0, 72 KiB) serves three times: (0) staging of the tile's theta [64][75] and beta [64][10] (coalesced
-  // loads), (1) the A operand of the tile as an A2h image [ks 14][fh 2][piece 2][64][16 B] from which every lane takes its
-  // fragments, (2) the G' image.  Lane = frame, wavefront = role; a role keeps its rotations, joints and chain in registers.
-  // first (run time, uniform): also the ring's prologue, slots 0..6 into images 0..6 (issued once the staging loads have
-  // been consumed, so that nothing waits behind them; they land while the pose is computed).
-  auto pose_role = [&](auto role_tag) {
-    constexpr int ROLE = decltype(role_tag)::value;
-    constexpr PoseRole RD = HP_ROLE[ROLE];
-    constexpr int NQ = RD.n;
-    const int fh = lane >> 5, r = lane & 31; // frame = 32 fh + r of the tile
-    const float * const thL = reinterpret_cast<const float *>(lds) + lane * ((NJ + 1) * 3);
-    const float * const beL = reinterpret_cast<const float *>(lds + 64 * (NJ + 1) * 3 * 4) + lane * NB;
-    float th[NQ][3], be[NB];
-#pragma unroll
-    for(int q = 0; q < NQ; q++)
-#pragma unroll
-      for(int c = 0; c < 3; c++) th[q][c] = thL[(1 + RD.joint[q]) * 3 + c]; // theta[:,1:,:] (src/SMPL.cpp:685-686)
-#pragma unroll
-    for(int k = 0; k < NB; k++) be[k] = beL[k];
-    h_lds_barrier(); // every lane holds its inputs: the staging area may be overwritten
-    PSTAMP(2);
-    float R[NQ][9], jp[NQ][3];
-#pragma unroll
-    for(int q = 0; q < NQ; q++) rodrigues9(th[q][0], th[q][1], th[q][2], R[q]);
-    PSTAMP(3);
-#pragma unroll
-    for(int q = 0; q < NQ; q++)
-#pragma unroll
-      for(int x = 0; x < 3; x++) jp[q][x] = joint_coord(J0[RD.joint[q] * 3 + x], JS + (RD.joint[q] * 3 + x) * NB, be);
-    PSTAMP(4);
-    // the role's chunks of the A operand: 64 . [c | beta | 1 | 0] in the K order of common.h (hp_kold), fp16x2 pieces
-    {
-      constexpr int NV = ROLE == 3 ? 56 : (RD.ncoef * 9 + 7) / 8 * 8;
-      hstatic_for<NV / 8>([&](auto cc) {
-        constexpr int C = decltype(cc)::value;
-        f16x8 hi, lo;
-        hstatic_for<8>([&](auto jj) {
-          constexpr int I = C * 8 + decltype(jj)::value;
-          float v = 0.0f;
-          if constexpr(I < RD.ncoef * 9)
-          {
-            constexpr int J = RD.coefj[I / 9], Q9 = I % 9;
-            constexpr int QI = hp_role_index(ROLE, J);
-            v = R[QI][Q9] - ((Q9 == 0 || Q9 == 4 || Q9 == 8) ? 1.0f : 0.0f); // src/BlendShape.cpp:873-892
-          }
-          else if constexpr(ROLE == 3 && I < 55)
-            v = be[I - 45];
-          else if constexpr(ROLE == 3 && I == 55)
-            v = 1.0f;
-          _Float16 a, b;
-          split_f16x2(v * HB_SA, a, b);
-          hi[decltype(jj)::value] = a;
-          lo[decltype(jj)::value] = b;
-        });
-        constexpr int CH = HP_KBASE[ROLE] / 8 + C, KS = CH >> 1, H = CH & 1;
-        unsigned char * dst = lds + ((KS * 2) * 2) * 1024 + fh * 2048 + (32 * H + r) * 16;
-        *reinterpret_cast<f16x8 *>(dst) = hi;
-        *reinterpret_cast<f16x8 *>(dst + 1024) = lo;
-      });
-    }
-    PSTAMP(5);
-    h_lds_barrier(); // the A image is complete
-    PSTAMP(6);
-#pragma unroll
-    for(int ks = 0; ks < HB_KS; ks++)
-#pragma unroll
-      for(int p = 0; p < 2; p++) areg[ks][p] = *reinterpret_cast<const v4f *>(lds + ((ks * 2 + wf) * 2 + p) * 1024 + lane * 16);
-    h_lds_barrier(); // ... and read: the region now takes the G' image
-    PSTAMP(7);
-    // chain G_0 = [R_0 | j_0], G_i = G_p(i) . [R_i | j_i - j_p(i)] (src/WorldTransformation.cpp:508-610), then for the joints this
-    // role writes: relative transform (:657-677), scale, fp16x2 pieces into the blend MFMAs' A fragments (slot order HP_JSLOT)
-    float G[NQ][12];
-#pragma unroll
-    for(int rr = 0; rr < 3; rr++)
-    {
-#pragma unroll
-      for(int c = 0; c < 3; c++) G[0][rr * 4 + c] = R[0][rr * 3 + c];
-      G[0][rr * 4 + 3] = jp[0][rr];
-    }
-    hstatic_for<NQ - 1>([&](auto qq) {
-      constexpr int Q = decltype(qq)::value + 1, P = RD.par[Q];
-      const float t0 = jp[Q][0] - jp[P][0], t1 = jp[Q][1] - jp[P][1], t2 = jp[Q][2] - jp[P][2];
-#pragma unroll
-      for(int rr = 0; rr < 3; rr++)
-      {
-#pragma unroll
-        for(int c = 0; c < 3; c++)
-          G[Q][rr * 4 + c] = chain_entry(G[P][rr * 4 + 0], G[P][rr * 4 + 1], G[P][rr * 4 + 2], 0.0f, R[Q][0 * 3 + c], R[Q][1 * 3 + c], R[Q][2 * 3 + c], false);
-        G[Q][rr * 4 + 3] = chain_entry(G[P][rr * 4 + 0], G[P][rr * 4 + 1], G[P][rr * 4 + 2], G[P][rr * 4 + 3], t0, t1, t2, true);
-      }
-    });
-    PSTAMP(8);
-    // pieces of entry e of list joint q
-    auto piece = [&](auto qq, int e, _Float16 & a, _Float16 & b) {
-      constexpr int Q = decltype(qq)::value;
-      const int rr = e >> 2;
-      float v = G[Q][e];
-      if((e & 3) == 3) v = relative_t(v, G[Q][rr * 4 + 0], G[Q][rr * 4 + 1], G[Q][rr * 4 + 2], jp[Q][0], jp[Q][1], jp[Q][2]);
-      split_f16x2(v * gscale, a, b);
-    };
-    unsigned char * const gimg = lds + fh * (12 * 3072) + r * 16; // entry e: + e * 3072; k-step 0 piece p: + p * 1024 (+ 512: lane half 1); k-step 1: + 2048 + p * 512
-    hstatic_for<12>([&](auto ee) {
-      constexpr int E = decltype(ee)::value;
-      unsigned char * const ge = gimg + E * 3072;
-      if constexpr(ROLE == 2) // slots 0..7: list joints 1..8
-      {
-        f16x8 hi, lo;
-        hstatic_for<8>([&](auto jj) {
-          _Float16 a, b;
-          piece(std::integral_constant<int, decltype(jj)::value + 1>{}, E, a, b);
-          hi[decltype(jj)::value] = a;
-          lo[decltype(jj)::value] = b;
-        });
-        *reinterpret_cast<f16x8 *>(ge) = hi;
-        *reinterpret_cast<f16x8 *>(ge + 1024) = lo;
-      }
-      else if constexpr(ROLE == 0 || ROLE == 1) // slots 8..11 / 12..15: list joints 4..7; slot 22 / 23: list joint 8
-      {
-        f16x4 hi, lo;
-        hstatic_for<4>([&](auto jj) {
-          _Float16 a, b;
-          piece(std::integral_constant<int, decltype(jj)::value + 4>{}, E, a, b);
-          hi[decltype(jj)::value] = a;
-          lo[decltype(jj)::value] = b;
-        });
-        *reinterpret_cast<f16x4 *>(ge + 512 + ROLE * 8) = hi;
-        *reinterpret_cast<f16x4 *>(ge + 1024 + 512 + ROLE * 8) = lo;
-        _Float16 a, b;
-        piece(std::integral_constant<int, 8>{}, E, a, b);
-        *reinterpret_cast<_Float16 *>(ge + 2048 + (6 + ROLE) * 2) = a;
-        *reinterpret_cast<_Float16 *>(ge + 2048 + 512 + (6 + ROLE) * 2) = b;
-      }
-      else // role 3: slots 16..19: list joints 0..3; slots 20, 21: list joints 4, 5
-      {
-        f16x4 hi, lo;
-        hstatic_for<4>([&](auto jj) {
-          _Float16 a, b;
-          piece(jj, E, a, b);
-          hi[decltype(jj)::value] = a;
-          lo[decltype(jj)::value] = b;
-        });
-        *reinterpret_cast<f16x4 *>(ge + 2048) = hi;
-        *reinterpret_cast<f16x4 *>(ge + 2048 + 512) = lo;
-        f16x2 hi2, lo2;
-        hstatic_for<2>([&](auto jj) {
-          _Float16 a, b;
-          piece(std::integral_constant<int, decltype(jj)::value + 4>{}, E, a, b);
-          hi2[decltype(jj)::value] = a;
-          lo2[decltype(jj)::value] = b;
-        });
-        *reinterpret_cast<f16x2 *>(ge + 2048 + 8) = hi2;
-        *reinterpret_cast<f16x2 *>(ge + 2048 + 512 + 8) = lo2;
-      }
-    });
-    PSTAMP(9);
-  };
-  auto pose_frame_tile = [&](int ft, bool first) {
-    PSTAMP(0);
-    h_full_barrier();
-    // staging: theta [64][75] at byte 0, beta [64][10] behind it; frames >= n read as zero (their rows are never stored)
-    {
-      const int64_t f0 = (int64_t)ft * 64;
-      const int64_t limT = (n - f0) * ((NJ + 1) * 3), limB = (n - f0) * NB; // floats of the tile that exist
-      const float * const tp = theta + f0 * ((NJ + 1) * 3);
-      const float * const bp = beta + f0 * NB;
-      constexpr int NT4 = 64 * (NJ + 1) * 3 / 4, NB4 = 64 * NB / 4; // 1200, 160
-      v4f tv[(NT4 + 255) / 256], bv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for(int ps = 0; ps < (NT4 + 255) / 256; ps++)
-      {
-        const int i = tid + 256 * ps;
-        v4f v = {0.f, 0.f, 0.f, 0.f};
-        if(i < NT4)
-        {
-          if((int64_t)i * 4 + 4 <= limT)
-            v = *reinterpret_cast<const v4fu *>(tp + i * 4);
-          else
-          {
-            if((int64_t)i * 4 + 0 < limT) v.x = tp[i * 4 + 0];
-            if((int64_t)i * 4 + 1 < limT) v.y = tp[i * 4 + 1];
-            if((int64_t)i * 4 + 2 < limT) v.z = tp[i * 4 + 2];
-          }
-        }
-        tv[ps] = v;
-      }
-      if(tid < NB4)
-      {
-        if((int64_t)tid * 4 + 4 <= limB)
-          bv = *reinterpret_cast<const v4fu *>(bp + tid * 4);
-        else
-        {
-          if((int64_t)tid * 4 + 0 < limB) bv.x = bp[tid * 4 + 0];
-          if((int64_t)tid * 4 + 1 < limB) bv.y = bp[tid * 4 + 1];
-          if((int64_t)tid * 4 + 2 < limB) bv.z = bp[tid * 4 + 2];
-        }
-      }
-#pragma unroll
-      for(int ps = 0; ps < (NT4 + 255) / 256; ps++)
-        if(tid + 256 * ps < NT4) *reinterpret_cast<v4f *>(lds + (tid + 256 * ps) * 16) = tv[ps];
-      if(tid < NB4) *reinterpret_cast<v4f *>(lds + NT4 * 16 + tid * 16) = bv;
-    }
-    if(first) // the ring's prologue (uniform branch)
-    {
-      const int vgF = vg0 + i0 % nvx;
-      hstatic_for<H_R>([&](auto dd) {
-        constexpr int D = decltype(dd)::value;
-        dma(std::integral_constant<int, 0>{}, vgF * (HB_SLOTS * HB_IMG), D, imgS[D]);
-        dma(std::integral_constant<int, 1>{}, vgF * (HB_SLOTS * HB_IMG), D, imgS[D]);
-        dma(std::integral_constant<int, 2>{}, vgF * (HB_SLOTS * HB_IMG), D, imgS[D]);
-      });
-    }
-    h_lds_barrier(); // staging visible
-    PSTAMP(1);
-    if(tid < 192) // root translations theta[f, 0, :] (src/SMPL.cpp:726-727)
-      *reinterpret_cast<float *>(lds + H_LDS_TR + (tid / 3) * 16 + (tid % 3) * 4) =
-          *reinterpret_cast<const float *>(lds + ((tid / 3) * ((NJ + 1) * 3) + tid % 3) * 4);
-    if(wave == 0)
-      pose_role(std::integral_constant<int, 0>{});
-    else if(wave == 1)
-      pose_role(std::integral_constant<int, 1>{});
-    else if(wave == 2)
-      pose_role(std::integral_constant<int, 2>{});
-    else
-      pose_role(std::integral_constant<int, 3>{});
-    if(first)
-    {
-      h_barrier<3 * (H_R - 1)>(); // behind slot 0 (and the G' image): slots 1..6 may stay in flight
-#pragma unroll
-      for(int q = 0; q < 6; q++) bfr[q / 2][q % 2] = *reinterpret_cast<const v4f *>(imgV[0] + q * 1024);
-    }
-    else
-      h_lds_barrier();
-    PSTAMP(10);
-  };
-
   // ---- one work item.  HT (compile time): the tail of the previous item (its last 16 stores) rides in slots 0 and 1.
   auto do_item = [&](int i, int inext, auto ht_tag) {
     constexpr bool HT = decltype(ht_tag)::value;
-    constexpr bool GDMA = !HT && !POSE; // the G' image of a new frame tile rides in this item's slots 0..8 (POSE: already in LDS)
     const int iu = __builtin_amdgcn_readfirstlane(i), nu = __builtin_amdgcn_readfirstlane(inext);
     const int ft = iu / nvx, vg = vg0 + iu % nvx, vgn = vg0 + nu % nvx;
     const int Bcur = vg * (HB_SLOTS * HB_IMG), Bnext = vgn * (HB_SLOTS * HB_IMG);
@@ -582,11 +320,11 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
         HSB();
         // barrier of the slot: behind it image (S + 1) % 7 holds slot S + 1 (its DMAs have landed: vmcnt) and image S % 7 is
         // free for slot S + 7 (every wavefront's reads of it completed: lgkmcnt)
-        if constexpr(M == 1) h_barrier<h_barrier_vmcnt(S, HT, WANT_REST, GDMA)>();
+        if constexpr(M == 1) h_barrier<h_barrier_vmcnt(S, HT, WANT_REST)>();
         if constexpr(M >= 2 && M <= 4)
           dma(std::integral_constant<int, M - 2>{}, S + 7 < HB_SLOTS ? Bcur : Bnext, S + 7 < HB_SLOTS ? S + 7 : S + 7 - HB_SLOTS,
               imgS[S % H_R]);
-        if constexpr(GDMA && S < 9 && (M == 5 || M == 6)) // the G' image of a new frame tile: pieces 8 S + 4 (M - 5) + wave
+        if constexpr(!HT && S < 9 && (M == 5 || M == 6)) // the G' image of a new frame tile: pieces 8 S + 4 (M - 5) + wave
         {
           constexpr int PC = (2 * S + (M - 5)) * 4;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr_t)(lds + (PC + wave) * 1024), 16, lane * 16,
@@ -653,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
         else
           macc[MPE] = mfma(gfr[GI], wfr[WI], macc[MPE]);
         HSB();
-        if constexpr(E == 0 && B == 0) h_barrier<h_barrier_vmcnt(HB_KS, HT, WANT_REST, GDMA)>(); // slot 14: publishes slot 0 of the next item
+        if constexpr(E == 0 && B == 0) h_barrier<h_barrier_vmcnt(HB_KS, HT, WANT_REST)>(); // slot 14: publishes slot 0 of the next item
         if constexpr(E == 0 && B >= 1 && B <= 3) dma(std::integral_constant<int, B - 1>{}, Bnext, HB_KS + 7 - HB_SLOTS, imgS[HB_KS % H_R]);
         if constexpr(E == 1) // operand fragments of the next item's first k-step (image (14 + 1) % 7)
         {
@@ -723,17 +461,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
   {
     const int ft = i / nvx;
     const int iend = (ft + 1) * nvx < i1 ? (ft + 1) * nvx : i1;
-    if constexpr(POSE)
-    {
-      if(i != i0) standalone_tail();
-#if SKINH_ABL & 1024 // development: the pose step twice (second pass: warm instruction cache, no ring prologue)
-      for(dbg_rep = 0; dbg_rep < 2; dbg_rep++) pose_frame_tile(ft, i == i0 && dbg_rep == 0);
-      dbg_rep = 0;
-#else
-      pose_frame_tile(ft, i == i0);
-#endif
-    }
-    else if(i != i0)
+    if(i != i0)
     {
       standalone_tail();
       load_frame_tile(ft, std::false_type{});
@@ -766,26 +494,8 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the last prefetches land before the wavefront ends
 }
 
-template<bool WR, bool POSE>
-static hipError_t launch_h_t(const smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * rest,
-                             hipStream_t st, int64_t f_off, int nbx, int nvg, int nft)
-{
-  static PerDeviceOnce once;
-  hipError_t e = lds_opt_in(once, m->device, reinterpret_cast<const void *>(&skin_kernel_h<WR, POSE>), H_LDS_TOTAL);
-  if(e != hipSuccess) return e;
-  const float cAB = 1.0f / (HB_SA * m->sB);
-  const uint8_t * A2 = POSE ? nullptr : m->ws.A2h.as<uint8_t>() + (f_off / 64) * (int64_t)(HB_KS * HB_A_BYTES);
-  const uint8_t * G2 = POSE ? nullptr : m->ws.G2h.as<uint8_t>() + (f_off / 64) * (int64_t)HB_G_BYTES;
-  const float * th = theta + f_off * ((NJ + 1) * 3);
-  const float * be = beta ? beta + f_off * NB : nullptr;
-  float * vo = verts ? verts + f_off * m->V * 3 : nullptr;
-  float * ro = rest ? rest + f_off * m->V * 3 : nullptr;
-  skin_kernel_h<WR, POSE><<<dim3(nbx * 8), dim3(256), H_LDS_TOTAL, st>>>(A2, m->B2h, G2, th, vo, ro, n, m->V, nvg, nft, cAB, be, m->J0, m->JS, m->sG);
-  return hipGetLastError();
-}
-
-static hipError_t launch_h(const smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * rest,
-                           hipStream_t st, int64_t f_off, bool pose)
+static hipError_t launch_h(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st,
+                           int64_t f_off)
 {
   const int nft = (int)((n + 63) / 64);
   const int nvg = (int)m->VGPn;
@@ -795,10 +505,22 @@ static hipError_t launch_h(const smplpp_model * m, int64_t n, const float * beta
   if(nbx > per_xcd_items) nbx = per_xcd_items;
   if(nbx < 1) nbx = 1;
   const bool wr = rest != nullptr;
-  if(pose) return wr ? launch_h_t<true, true>(m, n, beta, theta, verts, rest, st, f_off, nbx, nvg, nft)
-                     : launch_h_t<false, true>(m, n, beta, theta, verts, rest, st, f_off, nbx, nvg, nft);
-  return wr ? launch_h_t<true, false>(m, n, beta, theta, verts, rest, st, f_off, nbx, nvg, nft)
-            : launch_h_t<false, false>(m, n, beta, theta, verts, rest, st, f_off, nbx, nvg, nft);
+  static PerDeviceOnce once[2];
+  {
+    hipError_t e = lds_opt_in(once[wr], m->device, wr ? reinterpret_cast<const void *>(&skin_kernel_h<true>) : reinterpret_cast<const void *>(&skin_kernel_h<false>), H_LDS_TOTAL);
+    if(e != hipSuccess) return e;
+  }
+  const float cAB = 1.0f / (HB_SA * m->sB);
+  const uint8_t * A2 = m->ws.A2h.as<uint8_t>() + (f_off / 64) * (int64_t)(HB_KS * HB_A_BYTES);
+  const uint8_t * G2 = m->ws.G2h.as<uint8_t>() + (f_off / 64) * (int64_t)HB_G_BYTES;
+  const float * th = theta + f_off * ((NJ + 1) * 3);
+  float * vo = verts ? verts + f_off * m->V * 3 : nullptr;
+  float * ro = rest ? rest + f_off * m->V * 3 : nullptr;
+  if(wr)
+    skin_kernel_h<true><<<dim3(nbx * 8), dim3(256), H_LDS_TOTAL, st>>>(A2, m->B2h, G2, th, vo, ro, n, m->V, nvg, nft, cAB);
+  else
+    skin_kernel_h<false><<<dim3(nbx * 8), dim3(256), H_LDS_TOTAL, st>>>(A2, m->B2h, G2, th, vo, ro, n, m->V, nvg, nft, cAB);
+  return hipGetLastError();
 }
 
 #if SKINH_ABL & (256 | 512)
@@ -811,23 +533,19 @@ extern "C" int smplpp_debug_hslot_times(unsigned long long * out)
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(smplpp_hip::g_hslot_times), sizeof(unsigned long long) * 8 * 256);
 }
 #endif
-// pose = false: A2h / G2h (written by pose_kernel) must hold whole 64-frame tiles (padding content is irrelevant: the rows it
-// feeds are never stored).  pose = true: the kernel computes the pose step of each frame tile itself from beta / theta (device
-// pointers; standard SMPL tree only: smplpp_model::std_tree).
-hipError_t launch_skin_f16x2(const smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * rest,
-                             hipStream_t st, bool pose)
+// A2h / G2h must hold whole 64-frame tiles (padding content is irrelevant: the rows it feeds are never stored)
+hipError_t launch_skin_f16x2(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st)
 {
-  // the kernel addresses its outputs (and the G2h / theta tiles) with 32-bit offsets: longer batches go in launches of <= 2 GiB
-  // of vertices, and of few enough frames that nft * HB_G_BYTES stays below 2^31 too
+  // the kernel addresses its outputs with 32-bit buffer offsets: longer batches go in launches of <= 2 GiB of vertices
+  // ... and of few enough frames that the G2h offsets (nft * 72 KiB) stay below 2^31 too (small meshes)
   int64_t per = (0x7fffff00LL / (m->V * 12)) & ~63LL;
   const int64_t per_g = (0x7fffff00LL / HB_G_BYTES) * 64;
   if(per > per_g) per = per_g;
   if(per < 64) return hipErrorInvalidValue;
-  if((int64_t)m->VGPn * HB_SLOTS * HB_IMG > 0x7fffff00LL) return hipErrorInvalidValue; // (model creation refuses such a model for this form)
   for(int64_t off = 0; off < n; off += per)
   {
     const int64_t nn = (n - off < per) ? n - off : per;
-    hipError_t e = launch_h(m, nn, beta, theta, verts, rest, st, off, pose);
+    hipError_t e = launch_h(m, nn, theta, verts, rest, st, off);
     if(e != hipSuccess) return e;
   }
   return hipSuccess;

@@ -50,10 +50,12 @@ def init_process_group(backend: str | None = None):
     return dist
 
 
-def gather_rows(local, total: int, dst: int = 0):
+def gather_rows(local, total: int, dst: int = 0, out=None):
     """Final gather of per-rank row blocks (shard_range order) to `dst`: returns the [total, ...] tensor on dst, None
-    elsewhere.  Ragged blocks are padded to the largest shard for the collective and trimmed afterwards.
-    With the nccl backend this is one RCCL all-gather over xGMI (every peer sends on its own link)."""
+    elsewhere.  Gather-to-root: every other rank sends its block ONCE, straight into its slot of dst's array (grouped
+    point-to-point sends — with the nccl backend RCCL puts each on the peer's own xGMI link), so nothing is padded, nothing
+    is concatenated afterwards and no rank but dst ever holds the whole result.  `out` (dst only): a preallocated
+    [total, ...] tensor; when `local` already is dst's slot of it, dst's own block is not copied at all."""
     import torch
     import torch.distributed as dist
 
@@ -63,16 +65,28 @@ def gather_rows(local, total: int, dst: int = 0):
     sizes = shard_sizes(total, world)
     if local.shape[0] != sizes[rank]:
         raise ValueError("rank %d holds %d rows, expected %d" % (rank, local.shape[0], sizes[rank]))
-    mx = max(sizes)
-    pad = local
-    if local.shape[0] < mx:
-        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))])
-    pad = pad.contiguous()
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad)
     if rank != dst:
+        if sizes[rank] > 0:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), dst)]):
+                req.wait()
         return None
-    return torch.cat([o[:s] for o, s in zip(out, sizes)])
+    if out is None:
+        out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    elif tuple(out.shape) != (total,) + tuple(local.shape[1:]) or not out.is_contiguous():
+        raise ValueError("out must be a contiguous [total, ...] tensor")
+    ops = []
+    for r in range(world):
+        lo, hi = shard_range(total, r, world)
+        if hi == lo:
+            continue
+        if r == dst:
+            if out[lo:hi].data_ptr() != local.data_ptr():
+                out[lo:hi].copy_(local)
+        else:
+            ops.append(dist.P2POp(dist.irecv, out[lo:hi], r))  # a block of whole rows: a contiguous view, received in place
+    for req in (dist.batch_isend_irecv(ops) if ops else []):
+        req.wait()
+    return out
 
 
 def max_over_ranks(value: float) -> float:

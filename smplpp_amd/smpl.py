@@ -164,6 +164,13 @@ class SMPL:
         self._out, self._n, self._theta = out, n, theta
         return out
 
+    def launchStatus(self):
+        """Status word of the launches since the last read (synchronises the current stream): bit 0 = an operand left the
+        input range of the default fused kernel (include/smplpp_hip.h, smplpp_fk_status).  Host-space launches raise instead."""
+        bits = C.c_int(0)
+        check(_lib.load().smplpp_fk_status(self.handle, C.byref(bits), _stream()))
+        return bits.value
+
     def _need(self, key):
         if self._out.get(key) is None:
             raise SmplppError(4, "Failed to get vertices of new pose!")  # src/LinearBlendSkinning.cpp:413

@@ -35,13 +35,27 @@ local = torch.arange(lo, hi, dtype=torch.float32)[:, None] * torch.tensor([[1.0,
 D.barrier()
 full = D.gather_rows(local, total)
 t = D.max_over_ranks(float(rank + 1))
+want = torch.arange(total, dtype=torch.float32)[:, None] * torch.tensor([[1.0, 10.0]])
 if rank == 0:
-    want = torch.arange(total, dtype=torch.float32)[:, None] * torch.tensor([[1.0, 10.0]])
     assert full is not None and torch.equal(full, want), full
     assert t == float(world)
-    print("OK")
 else:
     assert full is None
+# gather to another root, into a preallocated array whose slot the root computed its block in (no copy of its own rows)
+buf = torch.full((total, 2), -1.0)
+mine = buf[lo:hi]
+mine.copy_(local)
+full1 = D.gather_rows(mine if rank == 1 else local, total, dst=1, out=buf if rank == 1 else None)
+if rank == 1:
+    assert full1 is buf and torch.equal(buf, want), buf
+else:
+    assert full1 is None
+# a rank with no rows at all (3 units over 2 ranks is fine; 1 unit leaves rank 1 empty)
+lo1, hi1 = D.shard_range(1, rank, world)
+one = D.gather_rows(torch.full((hi1 - lo1, 3), 7.0), 1)
+if rank == 0:
+    assert one.shape == (1, 3) and bool((one == 7.0).all())
+    print("OK")
 d.destroy_process_group()
 """
 
@@ -59,3 +73,27 @@ def test_two_rank_gloo_gather(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "OK" in outs[0]
+
+
+def test_gather_offsets_host_arithmetic():
+    """smplpp_gather_offsets (include/smplpp_hip.h): the slot of every rank's block in the gathered array, shared by
+    smplpp_gather's ragged leg and smplpp_gather_to_root.  Pure host code: runs without a GPU."""
+    import ctypes as C
+
+    from smplpp_amd import _lib
+
+    L = _lib.load()
+    for total, world, rf in [(1024, 8, 6890 * 3), (64, 8, 75), (11, 4, 2), (3, 4, 5), (0, 2, 3), (3163, 8, 75)]:
+        sizes = D.shard_sizes(total, world)
+        rows = (C.c_int64 * world)(*sizes)
+        offs = (C.c_int64 * (world + 1))()
+        assert L.smplpp_gather_offsets(rows, world, rf, offs) == 0
+        want = np.concatenate([[0], np.cumsum(sizes)]) * rf
+        assert list(offs) == want.tolist()
+        for r in range(world):
+            assert offs[r] == D.shard_range(total, r, world)[0] * rf
+    bad = (C.c_int64 * 2)(3, -1)
+    offs = (C.c_int64 * 3)()
+    assert L.smplpp_gather_offsets(bad, 2, 4, offs) != 0
+    huge = (C.c_int64 * 2)(2**40, 2**40)
+    assert L.smplpp_gather_offsets(huge, 2, 2**30, offs) != 0  # overflow is refused, not wrapped

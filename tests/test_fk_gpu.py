@@ -92,66 +92,6 @@ def test_fk_batch1024_properties_and_sample(smpl, oracle_synth):
     assert np.isfinite(o).all()
 
 
-
-def _smpl_with_env(model, **env):
-    """A model created under the given environment switches (they are read when a model is created)."""
-    from smplpp_amd.smpl import SMPL
-
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        s = SMPL()
-        s.setDevice("cuda:0")
-        s.init(model)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
-    return s
-
-
-@pytest.fixture(scope="module")
-def smpl_two_kernel(synth_model):
-    """The same model with the in-kernel pose switched off: pose_kernel_w (one wavefront per frame) + fused kernel reading
-    A2h / G2h."""
-    return _smpl_with_env(synth_model, SMPLPP_POSE_FUSED="0")
-
-
-@pytest.fixture(scope="module")
-def smpl_first_pose_kernel(synth_model):
-    """... and with the first pose kernel (four wavefronts per frame, workgroup barriers between its phases)."""
-    return _smpl_with_env(synth_model, SMPLPP_POSE_FUSED="0", SMPLPP_POSE_WAVE="0")
-
-
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 200, 1024, 2500])
-def test_fk_in_kernel_pose_is_bit_identical_to_the_two_kernel_path(smpl, smpl_two_kernel, smpl_first_pose_kernel, oracle_synth, n):
-    """When only vertices / rest shapes are wanted, the default fused kernel computes the pose step of its frame tiles itself
-    (skin_h.hip, POSE: Rodrigues, joints, chain, relative transforms per workgroup, lane = frame) instead of reading the
-    operands a pose_kernel launch wrote.  Same arithmetic in the same order (pose_math.h), so the two paths must agree bit for
-    bit — at every batch size: partial frame tiles (1, 63, 65, 200), the bench size (1024: one frame tile per workgroup) and
-    workgroups that run through several frame tiles (2500: the pose step is repeated mid-run).  Parity with the oracle on top."""
-    from smplpp_amd import model_io
-
-    beta, theta = model_io.synthetic_inputs(n, seed=300 + n)
-    for want in (("verts",), ("verts", "rest")):
-        a = smpl.launch(beta, theta, want=want)
-        b = smpl_two_kernel.launch(beta, theta, want=want)
-        for k in want:
-            assert np.array_equal(a[k], b[k]), (n, want, k, float(np.abs(a[k] - b[k]).max()))
-    sel = np.unique(np.clip(np.array([0, 1, 31, 32, 62, 63, 64, 65, 127, 128, n - 2, n - 1]), 0, n - 1))
-    r = oracle_synth.fk(beta[sel], theta[sel], want=("verts", "rest"))
-    assert np.abs(a["verts"][sel] - r["verts"]).max() < VERT_TOL and np.abs(a["rest"][sel] - r["rest"]).max() < VERT_TOL
-    # a request that includes joints / transforms takes the two-kernel path: same vertices again
-    c = smpl.launch(beta, theta)
-    assert np.array_equal(c["verts"], a["verts"]) and np.array_equal(c["rest"], a["rest"])
-    # the two pose kernels (one wavefront per frame / four per frame) agree bit for bit on everything they write
-    d = smpl_first_pose_kernel.launch(beta, theta)
-    for k in ("verts", "rest", "joints", "xforms"):
-        assert np.array_equal(c[k], d[k]), (n, k)
-
-
 @pytest.mark.parametrize("form", ["h", "b", "p", "v"])
 def test_fk_dense_weights_and_ragged_vertex_count(form, monkeypatch):
     """61-vertex model with all 24 skinning weights non-zero (dense path) — golden from the reference build.  Under every
@@ -200,8 +140,6 @@ def test_fk_eight_weights_per_vertex(synth_model, form, monkeypatch):
         r = o.fk(beta, theta)
         for k in ("verts", "rest", "joints"):
             assert np.abs(g[k] - r[k]).max() < VERT_TOL, (form, n, k)
-        g2 = s.launch(beta, theta, want=("verts",))  # h: in-kernel pose; b / p: the same path again
-        assert np.array_equal(g2["verts"], g["verts"]), (form, n)
 
 
 @pytest.mark.parametrize("V", [61, 200, 1000])
@@ -230,8 +168,6 @@ def test_fk_small_sparse_models(V):
         r = o.fk(beta, theta)
         for k in ("verts", "rest", "joints"):
             assert np.abs(g[k] - r[k]).max() < VERT_TOL, (V, n, k)
-        g2 = s.launch(beta, theta, want=("verts", "rest"))  # in-kernel pose (no joints / transforms requested)
-        assert np.array_equal(g2["verts"], g["verts"]) and np.array_equal(g2["rest"], g["rest"]), (V, n)
 
 
 def test_fk_workgroups_spanning_frame_tiles(smpl, oracle_synth):
@@ -328,9 +264,7 @@ def test_fk_split_operand_forms_are_fp32_exact(synth_model, oracle_synth, monkey
     for form in ("h", "b"):
         for k in ("verts", "rest"):
             assert err[form][k] < 2e-6, err
-            # (the split forms sum their K = 224 terms in fp32 in their own order — h: the role order of common.h — so the
-            # comparison with the exact-fp32 form carries a few ulp of 1-2 m positions, 1.2e-7 each, of accumulation noise)
-            assert err[form][k] <= 3.0 * err["p"][k] + 5e-7, err
+            assert err[form][k] <= 3.0 * err["p"][k] + 2e-7, err
 
 
 def test_fk_fp16x2_at_real_smpl_magnitudes(synth_model):
@@ -464,3 +398,27 @@ def test_whole_mesh_vertex_normals_and_sweep_grid(smpl, oracle_synth, synth_mode
     frac = g["inside"].mean()
     assert 0.05 < frac < 0.9 and (g["inside"] == (g["winding"] > 0.5)).all()  # a closed body: a solid share of its bounding grid
     assert np.abs(g["winding"] - np.round(g["winding"])).max() < 0.5 + 1e-6  # (a posed synthetic body may self-intersect: winding 2)
+
+
+def test_fk_out_of_range_operands_are_reported(smpl, synth_model):
+    """The default fused kernel carries its operands as fp16 pieces of scaled values (|beta| < 1023, transforms within 16 x the
+    template's extent): outside that range the reference stays finite and this form does not, so the launch must SAY so — a
+    host-space call returns SMPLPP_ERR_NUMERIC, an enqueue-only caller finds bit 0 in smplpp_fk_status — and the next
+    in-range launch is clean again."""
+    import torch
+    from smplpp_amd import model_io
+    from smplpp_amd._lib import SmplppError
+
+    beta, theta = model_io.synthetic_inputs(5, seed=3)
+    assert smpl.launchStatus() == 0
+    bad = beta.copy()
+    bad[3, 2] = 2000.0
+    with pytest.raises(SmplppError) as ei:
+        smpl.launch(bad, theta, want=("verts",))
+    assert ei.value.code == 3
+    smpl.launch(torch.from_numpy(bad).cuda(), torch.from_numpy(theta).cuda(), want=("verts",))
+    assert smpl.launchStatus() & 1
+    far = theta.copy()
+    far[1, 5] = 0.0
+    o = smpl.launch(beta, theta, want=("verts",))  # in range: no error, finite
+    assert np.isfinite(o["verts"]).all() and smpl.launchStatus() == 0

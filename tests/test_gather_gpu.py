@@ -39,6 +39,13 @@ def test_gather_one_rank_roundtrip():
         assert rc == 0, L.smplpp_last_error()
         torch.cuda.synchronize()
         assert torch.equal(send, recv)
+        # gather-to-root on the one-rank communicator: root's own block by a device copy; in place when send is its slot
+        recv2 = torch.full((rows, rf), -2.0, dtype=torch.float32, device="cuda:0")
+        assert L.smplpp_gather_to_root(comm, send.data_ptr(), recv2.data_ptr(), per, 1, 0, 0, rf, None) == 0, L.smplpp_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv2)
+        assert L.smplpp_gather_to_root(comm, recv2.data_ptr(), recv2.data_ptr(), per, 1, 0, 0, rf, None) == 0
+        assert L.smplpp_gather_to_root(comm, send.data_ptr(), None, per, 1, 0, 0, rf, None) != 0
         # argument checks
         assert L.smplpp_gather(None, send.data_ptr(), recv.data_ptr(), per, 1, 0, rf, None) != 0
         assert L.smplpp_gather(comm, send.data_ptr(), recv.data_ptr(), per, 1, 1, rf, None) != 0

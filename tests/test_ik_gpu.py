@@ -525,3 +525,67 @@ def test_ik_eval_mixed_task_kinds_vs_oracle(smpl, oracle_synth):
         assert dJ[:, :3].max() < 1e-4 * scale, f
         assert dJ[:, 3].max() < 6e-4 * scale, f
         assert np.abs(J[f].reshape(K, 4, -1)[plain, 3]).max() == 0  # no normal row for a position-only task
+
+
+def _double_fan_model(N):
+    """Closed double cone: apex 0 and bottom centre N + 1 each meet N faces (valence N), the N ring vertices 4."""
+    from smplpp_amd import model_io
+
+    top = [(0, 1 + i, 1 + (i + 1) % N) for i in range(N)]
+    bottom = [(N + 1, 1 + (i + 1) % N, 1 + i) for i in range(N)]
+    faces = np.array(top + bottom, np.int64) + 1
+    md = model_io.tiny_model(N + 2, seed=3, faces=faces)
+    ang = 2 * np.pi * np.arange(N) / N
+    vt = md["vertices_template"].copy()
+    vt[0] = (0, 0, 0.25)
+    vt[1:N + 1] = np.stack([0.3 * np.cos(ang), 0.3 * np.sin(ang), 0.02 * np.cos(3 * ang)], axis=1)
+    vt[N + 1] = (0, 0, -0.2)
+    md["vertices_template"] = vt.astype(np.float32)
+    return md
+
+
+def test_ik_vertex_valence_limit():
+    """The normal-term Jacobian differentiates through every face around a task's vertices, in tables of MAXADJ = 12 faces per
+    vertex (src/SMPL.cpp:527-535, 620-640 put no bound on it).  At the bound (a 12-face fan) the evaluation matches the
+    oracle, normal rows included; beyond it (14) the solver is REFUSED at creation instead of silently dropping faces from
+    the derivative — FK and the mesh queries of such a model keep working."""
+    from oracle import cpu
+    from smplpp_amd import model_io
+    from smplpp_amd._lib import SmplppError
+    from smplpp_amd.ik import IkSolver
+    from smplpp_amd.smpl import SMPL
+
+    rng = np.random.default_rng(4)
+    for N in (12, 14):
+        md = _double_fan_model(N)
+        s = SMPL()
+        s.setDevice("cuda:0")
+        s.init(md)
+        assert len(s.getAdjacentFaces(0)) == N
+        beta, theta = model_io.synthetic_inputs(2, seed=N)
+        theta[:, 1:] *= 0.3
+        o = cpu.OracleModel(md)
+        g = s.launch(beta, theta)
+        assert np.abs(g["verts"] - o.fk(beta, theta)["verts"]).max() < 1e-5
+        K = 4
+        faces = np.array([0, 5, N + 2, 2 * N - 1])  # two faces of each fan
+        if N > 12:
+            with pytest.raises(SmplppError, match="adjacent faces"):
+                IkSolver(s, 2, K)
+            continue
+        tp = rng.normal(0, 0.3, (2, K, 3)).astype(np.float32)
+        tn = rng.normal(0, 1, (2, K, 3)).astype(np.float32)
+        tn /= np.linalg.norm(tn, axis=2, keepdims=True)
+        sol = IkSolver(s, 2, K)
+        sol.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, phi_limit=np.zeros(K), normal_offset=np.full(K, 0.01),
+                     normal_task_weight=np.ones(K))
+        sol.setConfig(beta, theta)
+        e, J = sol.eval()
+        for f in range(2):
+            ts = cpu.TaskSet(faces, tp[f], tn[f], phi_limit=np.zeros(K), normal_offset=np.full(K, 0.01))
+            r = o.ik_eval(beta[f], theta[f], ts)
+            de = np.abs(r["e"] - e[f]).reshape(K, 4)
+            assert de[:, :3].max() < 5e-6 and de[:, 3].max() < 1e-4, (N, f)
+            dJ = np.abs(r["J"] - J[f]).reshape(K, 4, -1)
+            scale = max(1.0, np.abs(r["J"]).max())
+            assert dJ[:, :3].max() < 1e-4 * scale and dJ[:, 3].max() < 6e-4 * scale, (N, f, dJ[:, 3].max(), scale)

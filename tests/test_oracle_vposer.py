@@ -61,3 +61,45 @@ def test_decoder_shapes_and_eval_mode():
     fd = (dec(torch.from_numpy(zp)).detach().numpy() - dec(torch.from_numpy(zm)).detach().numpy()).reshape(3, 63) / (2 * h)
     # (LeakyReLU kinks crossed inside +-h show up as a few outliers)
     assert np.percentile(np.abs(fd - jac[:, :, 5]), 95) < 2e-3 and np.abs(fd - jac[:, :, 5]).max() < 5e-2
+
+
+def reference_decoder_golden():
+    """The reference's own decoder golden (tests/data/TestVPoser.json, committed as data under tests/golden/) and the gated
+    weights it belongs to, when SMPLPP_VPOSER_JSON names a vposer_parameters.json (or the .npz of the same script)."""
+    import json
+    import os
+
+    import pytest
+
+    path = os.environ.get("SMPLPP_VPOSER_JSON")
+    if not path:
+        pytest.skip("set SMPLPP_VPOSER_JSON=/path/to/vposer_parameters.json (license-gated VPoser v2 weights, "
+                    "scripts/preprocess_vposer.py) to pin the decoder against the reference's golden")
+    if not os.path.exists(path):
+        pytest.skip("SMPLPP_VPOSER_JSON=%s does not exist" % path)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vposer_reference_golden.json")) as f:
+        g = json.load(f)
+    return path, np.asarray(g["in"], np.float32), np.asarray(g["out"], np.float32), np.asarray(g["grad"], np.float32)
+
+
+def test_reference_decoder_golden_restatement():
+    """tests/src/TestVPoser.cpp:72-130 on the torch restatement: forward and d||out||/dz at the reference's 1e-6."""
+    path, zin, out_gt, grad_gt = reference_decoder_golden()
+    from smplpp_amd.ik import VPoserDecoder as P
+
+    if path.endswith(".npz"):
+        with np.load(path) as zf:
+            params = {k: zf[k] for k in P.KEYS}
+    else:
+        import json
+
+        with open(path) as f:
+            raw = json.load(f)
+        params = {k: np.asarray(raw[k], np.float32) for k in P.KEYS}
+    dec = VT.VPoserDecoder(params)
+    assert not dec.net[2].training  # :129
+    z = torch.from_numpy(zin).clone().requires_grad_(True)
+    out = dec(z)
+    out.norm().backward()
+    assert float((out.detach() - torch.from_numpy(out_gt)).norm()) < 1e-6
+    assert float((z.grad - torch.from_numpy(grad_gt)).norm()) < 1e-6

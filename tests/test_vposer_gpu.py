@@ -46,6 +46,25 @@ def test_decoder_forward_and_jacobian(decoders):
     assert np.abs(out2 - out).max() < 1e-6
 
 
+def test_reference_decoder_golden():
+    """tests/src/TestVPoser.cpp:72-130 through the C ABI, for anyone holding the license-gated weights (SMPLPP_VPOSER_JSON):
+    VPoserDecoder.loadParamsFromJson -> smplpp_vposer_forward.  The value-only kernel is exact fp32 (its summation order is its
+    own: 5e-6 on the norm where two torch builds agree to 1e-6); the Jacobian kernel carries fp16x2 operand pieces (2e-5).
+    d||out||/dz = jac^T . out / ||out|| against the reference's autograd gradient."""
+    from smplpp_amd.ik import VPoserDecoder
+    from test_oracle_vposer import reference_decoder_golden
+
+    path, zin, out_gt, grad_gt = reference_decoder_golden()
+    vp = VPoserDecoder.loadParamsFromJson(path)
+    out = vp.forward(zin)
+    assert np.linalg.norm((out - out_gt).ravel()) < 5e-6
+    out2, jac = vp.forward(zin, want_jac=True)
+    assert np.linalg.norm((out2 - out_gt).ravel()) < 2e-5
+    o = out2.reshape(-1, 63).astype(np.float64)
+    grad = np.einsum("nr,nrk->nk", o / np.linalg.norm(o, axis=1, keepdims=True), jac.astype(np.float64))
+    assert np.linalg.norm((grad - grad_gt).ravel()) < 2e-5 * max(1.0, np.linalg.norm(grad_gt))
+
+
 def test_latent_ik_eval_and_step(decoders, synth_model, oracle_synth, golden_ik_synth):
     """node.cpp:761-772 + :895-904: theta44 = [pos3 | root3 | z32 | aa22 | aa23]; J over the latent layout is J75 pulled
     back through d(vposer)/dz; the prior adds w_i to A_ii and w_i * theta_i to b_i."""
