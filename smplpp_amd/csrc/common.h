@@ -22,6 +22,11 @@ constexpr int KP = 220;
 constexpr int K_BETA = NP;       // 207
 constexpr int K_ONE = NP + NB;   // 217
 constexpr int CT_LEV = 12;       // tree levels the pose kernel's register-resident chain table covers
+constexpr int CT_OFF = 52;       // smplpp_model::lvl: [25 level offsets | 24 joints by level | pad to 16 bytes | chain table 60 x CT_LEV x 2]
+// pose_kernel's operand array sP: rotations [24][9] | joints [24][3] | zero [4]; the chain table holds, per chain lane (60 =
+// 5 slots x 12 entries of a 3x4) and level, word 0 = joint | parent << 8 | parent's slot << 16 (0xff = none) and word 1 =
+// index of the lane's operand in sP | index of what is subtracted from it << 10 | stride << 20
+constexpr int CT_P_R = 0, CT_P_J = SMPLPP_JOINT_NUM * 9, CT_P_ZERO = CT_P_J + SMPLPP_JOINT_NUM * 3, CT_P_SIZE = CT_P_ZERO + 4;
 // tree tables of a model for the IK evaluation (smplpp_model::anc, int32): ancestor bit masks [24] | level offsets
 // [TREE_DMAX + 1] | joints sorted by level [24]
 constexpr int TREE_DMAX = 12;
@@ -192,10 +197,11 @@ struct smplpp_model
   float * wSum = nullptr;      // [VGn*32]  sum_j W[v,j] in ascending j (the blended homogeneous w)
   float * J0 = nullptr;        // [24][3]      Jreg . T
   float * JS = nullptr;        // [24][3][10]  Jreg . S
+  float * JSp = nullptr;       // [72][12] the two once more, a 48-byte row per joint coordinate: [JS row (10) | J0 | 0] (pose_kernel: three 16-byte loads)
   int32_t * parent = nullptr;  // [24]
   int32_t * lvl = nullptr;     // [25 + 24] kinematic tree by depth: level offsets, then the joints sorted by level
   int nlev = 0;
-  bool chain_fast = false;     // lvl also holds the (level, slot) -> (joint, parent) table of the pose kernel's chain
+  bool chain_fast = false;     // lvl also holds the pose kernel's chain table: per chain lane (60) and level (CT_LEV) joint | parent << 8 | parent's slot << 16 (0xff = none)
   int32_t * faces = nullptr;   // [F][3] 0-based
   int32_t * adjOff = nullptr;  // [V+1]
   int32_t * adjFace = nullptr; // [adjOff[V]] ascending face id per vertex

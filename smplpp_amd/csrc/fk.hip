@@ -50,15 +50,17 @@ __device__ __forceinline__ void block_sync_lds()
 #ifdef POSE_STAMP
 __device__ unsigned long long g_pose_stamps[16];
 #define PST(i) if(blockIdx.x == 512 && threadIdx.x == 0) g_pose_stamps[i] = __builtin_amdgcn_s_memtime()
+#define PSTC(i) if(blockIdx.x == 512 && threadIdx.x == 192) g_pose_stamps[i] = __builtin_amdgcn_s_memtime()
 extern "C" int smplpp_debug_pose_stamps(unsigned long long * out)
 {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pose_stamps), sizeof(unsigned long long) * 16);
 }
 #else
 #define PST(i)
+#define PSTC(i)
 #endif
 __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ beta, const float * __restrict__ theta,
-                                                   const float * __restrict__ J0, const float * __restrict__ JS,
+                                                   const float * __restrict__ J0, const float * __restrict__ JS, const float * __restrict__ JSp,
                                                    const int32_t * __restrict__ parent, const int32_t * __restrict__ lvl_off,
                                                    const int32_t * __restrict__ lvl_joint, int nlev, float * __restrict__ AT, int64_t ldA,
                                                    float * __restrict__ Gp, float * __restrict__ joints_out,
@@ -69,47 +71,74 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
 {
   const int64_t f = blockIdx.x;
   const int tid = threadIdx.x;
-  __shared__ float sR[NJ][9];
-  __shared__ float sJ[NJ][3];
-  __shared__ __attribute__((aligned(16))) float sG[NJ][12]; // global transforms [A | g], 3x4 row-major
+  // rotations [24][9] | joints [24][3] | zero[4] in ONE array: the chain's operand addresses are indices into it (CT_* below)
+  __shared__ float sP[CT_P_SIZE];
+  float(*sR)[9] = reinterpret_cast<float(*)[9]>(sP + CT_P_R);
+  float(*sJ)[3] = reinterpret_cast<float(*)[3]>(sP + CT_P_J);
+  float * const sZero = sP + CT_P_ZERO;
+  __shared__ __attribute__((aligned(16))) float sG[NJ + 1][12]; // global transforms [A | g], 3x4 row-major (+ a spare row: dead chain lanes store there)
   __shared__ float sBeta[NB];
   __shared__ float sCoef[224]; // the A operand row of this frame: [c(207) | beta(10) | 1 | 0...]
   __shared__ int sPar[NJ];
-  __shared__ float sZero[4];
   __shared__ int sLvl[NJ + 1 + NJ];
   if(f >= n) return;
   PST(0);
   // ---- phase 0 (the folded-regressor rows are fetched now, so their latency overlaps Rodrigues and the first barrier)
+  // fast path (ctab): the joints do not depend on the rotations — threads 64..135 compute them NOW, beside Rodrigues (beta
+  // straight from global memory: a uniform address), so that the chain wavefront can start at the first barrier
+  const int jt = ctab ? ((tid >= 64 && tid < 64 + NJ * 3) ? tid - 64 : -1) : (tid < NJ * 3 ? tid : -1);
   float j0v = 0.0f, jsv[NB];
 #pragma unroll
   for(int k = 0; k < NB; k++) jsv[k] = 0.0f;
-  if(tid < NJ * 3)
+  if(jt >= 0)
   {
-    j0v = J0[tid];
+    if(JSp) // [JS row | J0 | 0] in one 48-byte row: three loads instead of eleven
+    {
+      const float4 * row = reinterpret_cast<const float4 *>(JSp + jt * 12);
+      const float4 a = row[0], b = row[1], c = row[2];
+      jsv[0] = a.x; jsv[1] = a.y; jsv[2] = a.z; jsv[3] = a.w;
+      jsv[4] = b.x; jsv[5] = b.y; jsv[6] = b.z; jsv[7] = b.w;
+      jsv[8] = c.x; jsv[9] = c.y;
+      j0v = c.z;
+    }
+    else
+    {
+      j0v = J0[jt];
 #pragma unroll
-    for(int k = 0; k < NB; k++) jsv[k] = JS[tid * NB + k];
+      for(int k = 0; k < NB; k++) jsv[k] = JS[jt * NB + k];
+    }
   }
-  // chain wavefront: (joint, parent) of this lane's slot at every level (ctab: model.hip), in registers
-  int cti[CT_LEV], ctp[CT_LEV], cts[CT_LEV];
+  // chain wavefront: this lane's row of the chain table (model.hip, CT_*): per level the joint of its slot, the parent, the
+  // parent's slot, and WHERE its operand lies in sP — in registers
+  int cti[CT_LEV], ctp[CT_LEV], cts[CT_LEV], cta[CT_LEV];
 #pragma unroll
   for(int L = 0; L < CT_LEV; L++)
   {
     cti[L] = ctp[L] = -1;
     cts[L] = 0;
+    cta[L] = CT_P_ZERO | (CT_P_ZERO << 10) | (1 << 20);
   }
   if(ctab && tid >= 192 && tid < 192 + 60)
   {
-    const int slot = (tid - 192) / 12;
+    const int4 * row = reinterpret_cast<const int4 *>(ctab + (tid - 192) * (2 * CT_LEV));
+    int w[2 * CT_LEV];
+#pragma unroll
+    for(int q = 0; q < 2 * CT_LEV / 4; q++)
+    {
+      const int4 v = row[q];
+      w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
 #pragma unroll
     for(int L = 0; L < CT_LEV; L++)
-      if(L < nlev)
-      {
-        cti[L] = ctab[(L * 5 + slot) * 3 + 0];
-        ctp[L] = ctab[(L * 5 + slot) * 3 + 1];
-        cts[L] = ctab[(L * 5 + slot) * 3 + 2];
-      }
+    {
+      const int i = w[2 * L] & 0xff, p = (w[2 * L] >> 8) & 0xff;
+      cti[L] = i == 0xff ? -1 : i;
+      ctp[L] = p == 0xff ? -1 : p;
+      cts[L] = (w[2 * L] >> 16) & 0xff;
+      cta[L] = w[2 * L + 1];
+    }
   }
-  if(tid >= 64 && tid < 64 + NB) sBeta[tid - 64] = beta ? beta[f * NB + (tid - 64)] : 0.0f;
+  if(tid >= 160 && tid < 160 + NB) sBeta[tid - 160] = beta ? beta[f * NB + (tid - 160)] : 0.0f;
   if(tid < 4) sZero[tid] = 0.0f;
   if(!ctab) // (the tree tables in LDS serve the generic chain only)
   {
@@ -128,13 +157,22 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
 #pragma unroll
       for(int q = 0; q < 9; q++) rot_out[(f * NJ + tid) * 9 + q] = R[q];
   }
+  if(ctab && jt >= 0) // joints (src/JointRegression.cpp:588-590 through the folded regressor)
+  {
+    float be[NB];
+#pragma unroll
+    for(int k = 0; k < NB; k++) be[k] = beta ? beta[f * NB + k] : 0.0f;
+    const float s = joint_coord(j0v, jsv, be);
+    sJ[jt / 3][jt % 3] = s;
+    if(joints_out) joints_out[f * NJ * 3 + jt] = s;
+  }
   PST(1);
   block_sync_lds();
   PST(2);
   // ---- phase 1: coefficient k = tid (root joint has no pose corrective: src/BlendShape.cpp:884-887) and joint coordinate tid
-  if(tid < 224)
+  // (fast path: the chain wavefront has its own work in this phase; threads 0..31 take its 32 coefficients too)
+  for(int k = tid; k < 224 && (!ctab || tid < 192); k += ctab ? 192 : 256)
   {
-    const int k = tid;
     float a = 0.0f;
     if(k < NP)
     {
@@ -148,11 +186,57 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
     sCoef[k] = a;
     if(AT && k < KP) AT[(int64_t)k * ldA + f] = a;
   }
-  if(tid < NJ * 3) // joints (src/JointRegression.cpp:588-590 through the folded regressor)
+  if(!ctab && tid < NJ * 3) // joints (src/JointRegression.cpp:588-590 through the folded regressor)
   {
     const float s = joint_coord(j0v, jsv, sBeta);
     sJ[tid / 3][tid % 3] = s;
     if(joints_out) joints_out[f * NJ * 3 + tid] = s;
+  }
+  if(tid >= 192 && ctab)
+  {
+    // chain: G_0 = L_0, G_i = G_p(i) . L_i with L_i = [R_i | j_i - j_p(i)] (src/WorldTransformation.cpp:508-610), level by
+    // level; within a level the joints are independent (their parents are one level up).  Rotations and joints are both
+    // complete at the first barrier, so the chain runs beside the coefficient phase.  The lane's operand of every level (a
+    // column of R_i, or the offset j_i - j_p) does not depend on the chain: fetched up front, from addresses the host put
+    // into the table (no per-level address arithmetic: that was half of this wavefront's time).
+    PSTC(8);
+    const int lane = tid - 192, e = lane % 12, r = e / 4, c = e % 4;
+    float * const sGflat = &sG[0][0];
+    float x0[CT_LEV], x1[CT_LEV], x2[CT_LEV];
+#pragma unroll
+    for(int L = 0; L < CT_LEV; L++)
+    {
+      // (every level of the table, live or not — dead ones point at the zero words: one batch of loads, one wait)
+      const float * a = sP + (cta[L] & 0x3ff);
+      const float * b = sP + ((cta[L] >> 10) & 0x3ff);
+      const int st = cta[L] >> 20; // 3: a column of R_i, 1: j_i
+      const float a0 = a[0], a1 = a[st], a2 = a[2 * st], b0 = b[0], b1 = b[1], b2 = b[2];
+      x0[L] = a0 - b0;
+      x1[L] = a1 - b1;
+      x2[L] = a2 - b2;
+      if(ctp[L] < 0) x0[L] = (r == 0) ? x0[L] : (r == 1 ? x1[L] : x2[L]); // root: L_0 = [R_0 | j_0], entry (r, c) itself
+    }
+    PSTC(9);
+    // The parent's row comes out of the REGISTERS of the lanes that computed it one level earlier (ds_bpermute through
+    // __shfl: no LDS write -> wait -> read turn-around per level); the LDS copy is written on the side for phase 3.
+    float vprev = 0.0f;
+#pragma unroll
+    for(int L = 0; L < CT_LEV; L++)
+    {
+      if(L < nlev) // (wave-uniform)
+      {
+        const int i = cti[L], p = ctp[L], src = 12 * cts[L] + r * 4;
+        const float g0 = __shfl(vprev, src + 0, 64), g1 = __shfl(vprev, src + 1, 64), g2 = __shfl(vprev, src + 2, 64),
+                    g3 = __shfl(vprev, src + 3, 64);
+        const float vc = chain_entry(g0, g1, g2, g3, x0[L], x1[L], x2[L], c == 3);
+        const float v = p >= 0 ? vc : x0[L];
+        // (selects instead of a divergent branch: lanes without a joint at this level keep their value and store to a spare word)
+        const bool live = lane < 60 && i >= 0;
+        vprev = live ? v : vprev;
+        sGflat[live ? i * 12 + e : NJ * 12 + (lane & 3)] = v;
+      }
+    }
+    PSTC(10);
   }
   block_sync_lds();
   PST(3);
@@ -202,52 +286,7 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
     *reinterpret_cast<f16x8 *>(dst) = hi;
     *reinterpret_cast<f16x8 *>(dst + 64 * 8) = lo;
   }
-  if(tid >= 192 && ctab)
-  {
-    // chain: G_0 = L_0, G_i = G_p(i) . L_i with L_i = [R_i | j_i - j_p(i)] (src/WorldTransformation.cpp:508-610), level by
-    // level; within a level the joints are independent (their parents are one level up).  The lane's operand of every level
-    // (a column of R_i, or the offset j_i - j_p) does not depend on the chain: fetched up front.
-    const int lane = tid - 192, e = lane % 12, r = e / 4, c = e % 4;
-    // (branch-free: every lane issues the same six LDS reads per level back to back — divergent per-case reads cost a
-    // serialized LDS round trip per case and level, which was most of the chain's time)
-    float x0[CT_LEV], x1[CT_LEV], x2[CT_LEV];
-    const float * const zero3 = &sZero[0];
-#pragma unroll
-    for(int L = 0; L < CT_LEV; L++)
-    {
-      const int i = cti[L] >= 0 ? cti[L] : 0, p = ctp[L];
-      const float * a = (c < 3) ? &sR[i][c] : &sJ[i][0]; // column c of R_i (stride 3) or j_i (stride 1)
-      const int st = (c < 3) ? 3 : 1;
-      const float * b = (c == 3 && p >= 0) ? &sJ[p][0] : zero3;
-      const float a0 = a[0], a1 = a[st], a2 = a[2 * st], b0 = b[0], b1 = b[1], b2 = b[2];
-      x0[L] = a0 - b0;
-      x1[L] = a1 - b1;
-      x2[L] = a2 - b2;
-      if(p < 0) x0[L] = (r == 0) ? x0[L] : (r == 1 ? x1[L] : x2[L]); // root: L_0 = [R_0 | j_0], entry (r, c) itself
-    }
-    // The parent's row comes out of the REGISTERS of the lanes that computed it one level earlier (ds_bpermute through
-    // __shfl: no LDS write -> wait -> read turn-around per level); the LDS copy is written on the side for phase 3.
-    float vprev = 0.0f;
-#pragma unroll
-    for(int L = 0; L < CT_LEV; L++)
-    {
-      if(L < nlev) // (wave-uniform)
-      {
-        const int i = cti[L], p = ctp[L], src = 12 * cts[L] + r * 4;
-        const float g0 = __shfl(vprev, src + 0, 64), g1 = __shfl(vprev, src + 1, 64), g2 = __shfl(vprev, src + 2, 64),
-                    g3 = __shfl(vprev, src + 3, 64);
-        float v = x0[L];
-        if(p >= 0) v = chain_entry(g0, g1, g2, g3, x0[L], x1[L], x2[L], c == 3);
-        if(lane < 60 && i >= 0)
-        {
-          vprev = v;
-          sG[i][e] = v;
-        }
-      }
-    }
-    wave_sync();
-  }
-  else if(tid >= 192)
+  if(tid >= 192 && !ctab)
   {
     // generic trees (deeper than CT_LEV levels or wider than 5 joints per level): the same chain with its look-ups in LDS
     const int lane = tid - 192, slot = lane / 12, e = lane % 12, r = e / 4, c = e % 4;
@@ -276,7 +315,7 @@ __global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ be
     }
   }
   PST(4);
-  block_sync_lds();
+  if(!ctab) block_sync_lds(); // (fast path: the chain finished before the second barrier)
   PST(5);
   // ---- phase 3: relative transforms: translation -= A_i . j_i (src/WorldTransformation.cpp:657-677)
   for(int e = tid; e < NJ * 12; e += 256)
@@ -538,16 +577,16 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
   {
     HIP_TRY(ws.A2h.reserve((size_t)(n64 / 64) * HB_KS * HB_A_BYTES));
     HIP_TRY(ws.G2h.reserve((size_t)(n64 / 64) * HB_G_BYTES));
-    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
+    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->JSp, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
                                                          ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr,
                                                          (verts || rest) ? ws.A2h.as<_Float16>() : nullptr,
-                                                         (verts || rest) ? ws.G2h.as<_Float16>() : nullptr, m->sG, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr, m->range_flag);
+                                                         (verts || rest) ? ws.G2h.as<_Float16>() : nullptr, m->sG, m->chain_fast ? m->lvl + CT_OFF : nullptr, m->range_flag);
   }
   else if(form == 'b')
   {
     HIP_TRY(ws.A3.reserve((size_t)(n64 / 64) * BB_KS * BB_A_BYTES));
-    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
-                                                         ws.Gp.as<float>(), joints, poserot, xforms44, n, ws.A3.as<uint16_t>(), nullptr, nullptr, 1.0f, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr, nullptr);
+    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->JSp, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
+                                                         ws.Gp.as<float>(), joints, poserot, xforms44, n, ws.A3.as<uint16_t>(), nullptr, nullptr, 1.0f, m->chain_fast ? m->lvl + CT_OFF : nullptr, nullptr);
   }
   else
   {
@@ -560,8 +599,8 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
       int64_t cnt = (int64_t)KP * (ldA - n);
       zero_pad_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(ws.AT.as<float>(), ldA, n);
     }
-    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, ws.AT.as<float>(),
-                                                         ldA, ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr, nullptr, nullptr, 1.0f, m->chain_fast ? m->lvl + NJ + 1 + NJ : nullptr, nullptr);
+    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->JSp, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, ws.AT.as<float>(),
+                                                         ldA, ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr, nullptr, nullptr, 1.0f, m->chain_fast ? m->lvl + CT_OFF : nullptr, nullptr);
   }
   HIP_TRY(hipGetLastError());
   if(verts || rest)

@@ -196,6 +196,15 @@ __global__ __launch_bounds__(256) void fold_regressor_kernel(const float * __res
   }
 }
 
+// [72][12]: row t = [JS[t][0..9] | J0[t] | 0]
+__global__ void pack_regressor_rows_kernel(const float * __restrict__ J0, const float * __restrict__ JS, float * __restrict__ JSp)
+{
+  const int t = threadIdx.x;
+  for(int k = 0; k < NB; k++) JSp[t * 12 + k] = JS[t * NB + k];
+  JSp[t * 12 + 10] = J0[t];
+  JSp[t * 12 + 11] = 0.0f;
+}
+
 template<class T>
 static hipError_t upload(T ** dst, const T * src, size_t count)
 {
@@ -234,7 +243,7 @@ extern "C" int smplpp_model_destroy(smplpp_model * m)
   (void)hipSetDevice(m->device);
   for(hipEvent_t e : m->prof_events) (void)hipEventDestroy(e);
   m->prof_events.clear();
-  void * ptrs[] = {m->Bm, m->B3, m->B2h, m->range_flag, m->lvl, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm, m->faceRing, m->faceMap, m->anc};
+  void * ptrs[] = {m->Bm, m->B3, m->B2h, m->range_flag, m->lvl, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->JSp, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm, m->faceRing, m->faceMap, m->anc};
   for(void * p : ptrs)
     if(p) (void)hipFree(p);
   Workspace & w = m->ws;
@@ -324,6 +333,8 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   TRY_TMP(hipMalloc((void **)&m->JS, sizeof(float) * NJ * 3 * NB));
   relayout_basis_kernel<<<dim3((unsigned)((m->ldB + 255) / 256)), dim3(256)>>>(m->Pvm, m->Svm, dT.as<float>(), m->Bm, V, m->ldB);
   fold_regressor_kernel<<<dim3(NJ * 3 * (NB + 1)), dim3(256)>>>(dJreg.as<float>(), m->Svm, dT.as<float>(), m->J0, m->JS, V);
+  TRY_TMP(hipMalloc((void **)&m->JSp, sizeof(float) * NJ * 3 * 12));
+  pack_regressor_rows_kernel<<<dim3(1), dim3(NJ * 3)>>>(m->J0, m->JS, m->JSp);
   m->VGPn = (V + 63) / 64;
   // the split-operand kernels address their basis images with 32-bit buffer offsets: a mesh whose image would reach 2 GiB
   // (more than ~745k vertices for h, ~410k for b) takes the first form (64-bit addressing) from creation on
@@ -443,7 +454,12 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
     // lanes each): read once into registers instead of three dependent LDS look-ups per level.  chain_fast: the tree has at
     // most CT_LEV levels of at most 5 joints (SMPL: 9 levels, widest 5); other trees take the generic loop.
     m->chain_fast = nlev <= CT_LEV;
-    lv.resize(NJ + 1 + NJ + CT_LEV * 5 * 3, -1);
+    lv.resize(CT_OFF + 60 * CT_LEV * 2, 0);
+    for(int q = 0; q < 60 * CT_LEV; q++)
+    {
+      lv[CT_OFF + 2 * q] = 0x00ffff;
+      lv[CT_OFF + 2 * q + 1] = CT_P_ZERO | (CT_P_ZERO << 10) | (1 << 20);
+    }
     std::vector<int> slot_of(NJ, 0); // slot of a joint inside its level
     for(int L = 0; L < nlev && m->chain_fast; L++)
     {
@@ -453,9 +469,17 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
       {
         const int i = lv[NJ + 1 + lv[L] + q];
         slot_of[i] = q;
-        lv[NJ + 1 + NJ + (L * 5 + q) * 3 + 0] = i;
-        lv[NJ + 1 + NJ + (L * 5 + q) * 3 + 1] = parent[i];
-        lv[NJ + 1 + NJ + (L * 5 + q) * 3 + 2] = parent[i] >= 0 ? slot_of[parent[i]] : 0; // (the parent sits one level up: already placed)
+        const int p = parent[i];
+        const int word = i | ((p >= 0 ? p : 0xff) << 8) | ((p >= 0 ? slot_of[p] : 0) << 16); // (the parent sits one level up: already placed)
+        for(int e = 0; e < 12; e++)
+        {
+          const int c = e % 4;
+          // the lane's operand: column c of R_i (stride 3), or j_i minus j_p (root: minus zero)
+          const int aidx = c < 3 ? CT_P_R + i * 9 + c : CT_P_J + i * 3;
+          const int bidx = (c == 3 && p >= 0) ? CT_P_J + p * 3 : CT_P_ZERO;
+          lv[CT_OFF + ((q * 12 + e) * CT_LEV + L) * 2] = word;
+          lv[CT_OFF + ((q * 12 + e) * CT_LEV + L) * 2 + 1] = aidx | (bidx << 10) | ((c < 3 ? 3 : 1) << 20);
+        }
       }
     }
     TRY_OR_FREE(upload(&m->lvl, lv.data(), lv.size()));

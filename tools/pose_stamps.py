@@ -13,7 +13,10 @@ L = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
 L.smplpp_debug_pose_stamps.restype = ctypes.c_int
 assert L.smplpp_debug_pose_stamps(buf) == 0
-t = np.array(buf, dtype=np.uint64).astype(np.int64)[:7]
-names = ["loads + Rodrigues (thread 0)", "barrier 1", "phase 1 + barrier 2", "phase 2: chain (thread 0: A2h)", "barrier 3", "phase 3 stores"]
+tc = np.array(buf, dtype=np.uint64).astype(np.int64)
+t = tc[:7]
+names = ["loads + Rodrigues (thread 0)", "barrier 1", "phase 1 (chain beside it) + barrier 2", "phase 2 (thread 0: A2h)", "barrier 3 (generic trees only)", "phase 3 stores"]
 for i in range(6): print("%-34s %6d cycles" % (names[i], t[i + 1] - t[i]))
 print("total %d cycles" % (t[6] - t[0]))
+print("chain wavefront (fast path): barrier 1 -> start %d, operand prefetch %d, levels %d, -> barrier 2 passed (thread 0) %d" % (
+    tc[8] - tc[2], tc[9] - tc[8], tc[10] - tc[9], tc[3] - tc[10]))
