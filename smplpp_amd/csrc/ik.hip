@@ -2084,7 +2084,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
 // frame) takes the minimum of each list, applies the tie rule (lowest face id within 1e-6 relative of the minimum — every
 // face in that band passes the cull, whose slack is larger) and writes the new face id and area-ratio weights.  A list
 // that overflows (a far-off hint, e.g. the very first iteration) falls back to the exhaustive block scan.
-constexpr int PROJ_LIST = 512; // a marker 15 mm off a densely triangulated region has 100-400 faces inside its cull sphere
+constexpr int PROJ_LIST = 512; // (generous since the lists only take faces at least as close as the task's own: see proj_scan_kernel)
 constexpr int PROJ_MAXK = IK_MAXK;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -2104,6 +2104,7 @@ __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays
   const float * verts = verts_all + f * mv.V * 3;
   __shared__ float sp[PROJ_MAXK + 1][3];
   __shared__ float sreach[PROJ_MAXK + 1]; // sqrt of the hint distance: the cull radius of query k
+  __shared__ float sbound[PROJ_MAXK + 1]; // the hint distance itself (squared), with slack: no candidate farther than that can win
   const int64_t tb = f * K;
   if((int)threadIdx.x < K)
   {
@@ -2121,11 +2122,18 @@ __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays
       d = tri_sqdist_dev(verts, mv.faces, ta.face[tb + k], p, c);
     }
     sreach[k] = (d == d) ? sqrtf(d) : INFINITY;
+    // The task's own face is a candidate, at exactly this distance (same evaluation): the minimum is <= it, and every face the
+    // tie rule may prefer lies within 1e-6 relative of the minimum.  Survivors of the sphere cull beyond that bound are not
+    // listed at all — the lists shrink from hundreds of entries (every face inside the cull sphere of a marker 15 mm off a
+    // densely triangulated region: they overflowed in two of three frames of sample_walk.c3d and sent the finish kernel to
+    // its exhaustive fallback) to the handful of faces at least as close as the current one.
+    sbound[k] = (d == d) ? d * 1.00001f + 1e-30f : INFINITY;
   }
   else if((int)threadIdx.x == K) // the odd pair's second half: a query no face can reach
   {
     sp[K][0] = sp[K][1] = sp[K][2] = 1e18f;
     sreach[K] = 0.0f;
+    sbound[K] = 0.0f;
   }
   __syncthreads();
   if(dbg_stop == 10) return; // (timing experiments only: SMPLPP_IK_DBG_STOP)
@@ -2195,6 +2203,7 @@ __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays
         hit &= hit - 1;
         // survivor: exact distance from the vertices already in registers (the shared, non-inlined evaluation)
         const float d = tri_sqdist_vals(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], sp[k][0], sp[k][1], sp[k][2]).x;
+        if(!(d <= sbound[k])) continue; // farther than the task's own face: cannot be the closest (nor tie with it)
         const int slot = atomicAdd(&list_cnt[tb + k], 1);
         if(slot < PROJ_LIST)
         {
