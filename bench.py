@@ -19,7 +19,8 @@ Also reported in the same line:
   vposer_ik     configs[4]: VPoser-latent IK, 512 frames in all sharded over the GPUs;
   cpu_baseline  the reference's own compiled FK stages (oracle/_ref, libtorch-CPU) — or the C port when that
                 library is absent — timed on this box's host cores on a bounded sample (rank 0, N = 1 only);
-  final_gather_ms  (N > 1) the one RCCL all-gather of the results, the path's only exchange.
+  final_gather_ms  (N > 1) the gather of the results to rank 0 (grouped point-to-point sends over RCCL), the path's only exchange;
+  sustained     the same FK step over a 2000-launch run (steady clocks); exact_form: the step with operand-exact (bf16x3) arithmetic.
 """
 from __future__ import annotations
 
@@ -211,6 +212,9 @@ def main():
     ap.add_argument("--mocap-restarts", type=int, default=64, help="restarts of the capture fit IN ALL (BASELINE configs[3]: 64, sharded over the GPUs)")
     ap.add_argument("--mocap-frames", type=int, default=0, help="frames of the capture sequence to fit (0 = all 3163)")
     ap.add_argument("--vposer-frames", type=int, default=512, help="frames of the VPoser-latent IK leg IN ALL (BASELINE configs[4]: 512, sharded over the GPUs)")
+    ap.add_argument("--preroll-steps", type=int, default=0,
+                    help="extra untimed launches in front of the warm-up (profiling runs only: after idle the chip needs ~400 launches "
+                         "= 25 ms of load to reach its steady clocks; the contract's region is never pre-rolled by default)")
     ap.add_argument("--sustained-steps", type=int, default=2000, help="launches of the long run reported as `sustained` (0 = skip)")
     ap.add_argument("--no-exact-form", action="store_true", help="skip the operand-exact (bf16x3) leg reported as `exact_form`")
     ap.add_argument("--profile-steps", type=int, default=40, help="launches of the separate loop that times the fused kernel with HIP events")
@@ -268,17 +272,20 @@ def main():
         engine.profileEnable(False)
         return launches, D.max_over_ranks(ms)
 
-    for _ in range(args.warmup):
+    for _ in range(args.preroll_steps + args.warmup):
         smpl.launch(beta, theta, want=("verts",), out=out)
     elapsed = timed(smpl, args.steps)
     launches, skin_ms = kernel_ms(smpl, args.profile_steps)
-    # the steady clock: a short --steps region is a burst on a power-limited kernel (the chip has not settled), so the same
-    # step is timed once more over a long run, after the contract's region
+    # the steady clock: after idle the chip ramps its clocks UP over the first ~400 launches (57 -> 49 us per step over 25 ms,
+    # tools/fk_ramp.py), so a short --steps region right behind model creation is timed on a chip that has not settled; the
+    # same step is timed once more over a long run, after the contract's region
     sustained = None
     if args.sustained_steps > 0:
         sus_t = timed(smpl, args.sustained_steps)
         sustained = {"launches": args.sustained_steps, "ms_per_step": sus_t / args.sustained_steps * 1e3,
-                     "value": world * n * args.sustained_steps / sus_t, "unit": "FK evals/s"}
+                     "value": world * n * args.sustained_steps / sus_t, "unit": "FK evals/s",
+                     "note": "the same step over a long run behind the contract's region: the steady-clock figure (after idle the chip "
+                             "needs ~25 ms of load to ramp up; a 20-step region right after start-up is timed during that ramp)"}
     # the same step with operand-exact arithmetic: the bf16x3 form carries every fp32 operand as three bf16 pieces (24
     # significant bits = fp32's own), so its products are the reference's fp32 products; fp32 accumulate in both forms
     exact = None
@@ -443,7 +450,8 @@ def main():
                         "synthetic decoder weights" % (args.vposer_frames, world),
         }
 
-    # the only exchange of the path: the final gather of the results (one RCCL all-gather over xGMI), always timed when N > 1
+    # the only exchange of the path: the final gather of the results to rank 0 (every peer sends its block once, into its slot
+    # of rank 0's array: dist.gather_rows), always timed when N > 1
     gather_ms = None
     ranks_reported = 1
     if world > 1:

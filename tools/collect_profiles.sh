@@ -8,11 +8,11 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 100 --warmup 10 --no-ik --no-cpu-baseline --no-extra > $OUT/bench_under_trace.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --preroll-steps 600 --steps 100 --warmup 10 --no-ik --no-cpu-baseline --no-extra --no-exact-form --sustained-steps 0 > $OUT/bench_under_trace.json 2> $OUT/trace.err
 cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 i=1
 for P in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum"; do
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-ik --no-cpu-baseline --no-extra > $OUT/pass$i.json 2> $OUT/pass$i.err || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --preroll-steps 600 --steps 20 --warmup 5 --no-ik --no-cpu-baseline --no-extra --no-exact-form --sustained-steps 0 > $OUT/pass$i.json 2> $OUT/pass$i.err || echo "pass $i failed"
   i=$((i+1))
 done
 python3 $ROOT/tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt

@@ -3,7 +3,7 @@
 N=${1:-1024}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/ktimes; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/p -- python3 $ROOT/tools/quick_fk_bench.py $N 50 > $OUT/p.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/p -- python3 $ROOT/tools/quick_fk_bench.py $N 200 > $OUT/p.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 d = collections.defaultdict(list)
