@@ -15,6 +15,13 @@ for P in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --preroll-steps 600 --steps 20 --warmup 5 --no-ik --no-cpu-baseline --no-extra --no-exact-form --sustained-steps 0 > $OUT/pass$i.json 2> $OUT/pass$i.err || echo "pass $i failed"
   i=$((i+1))
 done
+# the operand-exact (bf16x3) form, reported by bench.py as exact_form: its traffic counters (the form is read at model creation)
+export SMPLPP_SKIN=b
+for P in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES"; do
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --preroll-steps 600 --steps 20 --warmup 5 --no-ik --no-cpu-baseline --no-extra --no-exact-form --sustained-steps 0 > $OUT/pass$i.json 2> $OUT/pass$i.err || echo "pass $i failed"
+  i=$((i+1))
+done
+unset SMPLPP_SKIN
 python3 $ROOT/tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
 cat $OUT/pmc_summary.txt
 python3 $ROOT/tools/make_traffic_json.py $OUT/pmc_summary.txt $OUT/traffic.json
