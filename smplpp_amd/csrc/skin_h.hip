@@ -121,6 +121,9 @@ __device__ __forceinline__ void h_full_barrier()
 #ifndef SKINH_STORE_AUX
 #define SKINH_STORE_AUX 0 // cache policy of the output stores (bit 0 sc0, bit 1 nt, bit 4 sc1)
 #endif
+#ifndef SKINH_DMA_IMM
+#define SKINH_DMA_IMM 1
+#endif
 #ifndef SKINH_ABL
 #define SKINH_ABL 0 // timing ablations (development only; results are wrong when non-zero): 1 no s_barrier, 2 no DMA, 4 no GEMM MFMAs, 8 no blend phase, 16 no fragment reads, 32 no stores, 256 slot timestamps, 512 phase timestamps (cycle counter + 100 MHz real-time counter)
 #endif
@@ -200,9 +203,14 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
   auto dma = [&](auto itag, int vgBase, int slot, int dst) {
     constexpr int I = decltype(itag)::value;
     if constexpr(SKINH_ABL & 2) return;
-    // (the instruction's immediate offset would move the LDS address too: the piece offset goes into soffset instead)
+    // the instruction's immediate offset moves the global address AND the LDS address: piece I of a wavefront's share lies
+    // I KiB further in both, so the three DMAs of a slot share one M0 and one soffset (two scalar set-ups fewer per piece)
+#if SKINH_DMA_IMM
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(lds + dst + wave * 3072), 16, voffDma, vgBase + slot * HB_IMG, I * 1024, 0);
+#else
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(lds + dst + wave * 3072 + I * 1024), 16, voffDma,
                                              vgBase + slot * HB_IMG + I * 1024, 0, 0);
+#endif
   };
 
   // row R of the tail of the previous item: verts = cw (M_t + cAB M_rot . acc) + root translation

@@ -1,6 +1,8 @@
 // Microbenchmark (development aid): bare f16 MFMA loops on random operands in registers, one wavefront per SIMD on every
 // CU: cycles per instruction (s_memtime), in-kernel clock (s_memtime / s_memrealtime) and wall time per unit of FLOPs for
 //   0: v_mfma_f32_32x32x16_f16   1: v_mfma_f32_16x16x32_f16   2: v_mfma_f32_32x32x8_f16 (the K = 8 form)
+//   3: 32x32x16 issued as DEPENDENT TRIPLES (acc0 x3, acc1 x3, acc2 x3: the order of skin_kernel_h's GEMM slots)
+//   4: 32x32x16 as one dependent chain (a single accumulator)   5: dependent pairs
 //   hipcc -O3 --offload-arch=gfx950 -o /tmp/mfma_shapes tools/micro/mfma_shapes.hip && /tmp/mfma_shapes
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -30,6 +32,21 @@ __global__ __launch_bounds__(256, 1) void k(const _Float16 * in, float * out, un
     {
 #pragma unroll
       for(int m = 0; m < 36; m++) acc32[m % 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m & 3], b[(m >> 2) & 3], acc32[m % 3], 0, 0, 0);
+    }
+    else if constexpr(MODE == 3)
+    {
+#pragma unroll
+      for(int m = 0; m < 36; m++) acc32[(m / 3) % 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m & 3], b[(m >> 2) & 3], acc32[(m / 3) % 3], 0, 0, 0);
+    }
+    else if constexpr(MODE == 4)
+    {
+#pragma unroll
+      for(int m = 0; m < 36; m++) acc32[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m & 3], b[(m >> 2) & 3], acc32[0], 0, 0, 0);
+    }
+    else if constexpr(MODE == 5)
+    {
+#pragma unroll
+      for(int m = 0; m < 36; m++) acc32[(m / 2) % 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m & 3], b[(m >> 2) & 3], acc32[(m / 2) % 3], 0, 0, 0);
     }
     else if constexpr(MODE == 1)
     {
@@ -109,6 +126,9 @@ int main()
     run<0>("v_mfma_f32_32x32x16_f16", 36, 2.0 * 32 * 32 * 16, din, dout, dcyc);
     run<1>("v_mfma_f32_16x16x32_f16", 72, 2.0 * 16 * 16 * 32, din, dout, dcyc);
     run<2>("v_mfma_f32_32x32x8_f16", 36, 2.0 * 32 * 32 * 8, din, dout, dcyc);
+    run<3>("32x32x16 dependent triples", 36, 2.0 * 32 * 32 * 16, din, dout, dcyc);
+    run<5>("32x32x16 dependent pairs", 36, 2.0 * 32 * 32 * 16, din, dout, dcyc);
+    run<4>("32x32x16 one chain", 36, 2.0 * 32 * 32 * 16, din, dout, dcyc);
   }
   return 0;
 }
