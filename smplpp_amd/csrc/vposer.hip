@@ -20,6 +20,11 @@ struct smplpp_vposer
   // layers 1 and 2 once more as fp16x2 pieces in MFMA fragment order (the A operand of the tangent GEMMs, layout below)
   uint8_t *w1h = nullptr, *w2h = nullptr;
   float sW1 = 1.f, sW2 = 1.f, sD1 = 1.f, sD2 = 1.f; // power-of-two scales: weights of layers 1 / 2, tangent blocks of layers 0 / 1
+  // vposer_jac2_kernel (several frames per workgroup): W0 once more as the B operand of layer 1's tangent GEMM (fragment order,
+  // scale sD1, no slopes) and the constant product C10 = W1 . W0 [512][32] (fp32, from an fp64 sum on the host)
+  uint8_t * w0h = nullptr;
+  float * c10 = nullptr;
+  int jac_form = 2; // SMPLPP_VPOSER_JAC=1: the one-frame-per-workgroup kernel for every batch size
 };
 
 namespace smplpp_hip
@@ -353,6 +358,24 @@ __device__ __forceinline__ float vdot8(const v4fv & w, const v4fv & a, float c)
   c = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 6, 7), __builtin_shufflevector(av, av, 6, 7), c, false);
   return c;
 }
+// the same with FOUR independent accumulators (one per element pair): back-to-back v_dot2 into ONE register wait for each other
+// (a dependent v_dot2c issues every ~16 cycles: four of them outlast the 32-cycle MFMA they were meant to hide behind)
+struct Dot4
+{
+  float c[4];
+};
+__device__ __forceinline__ void vdot8x4(const v4fv & w, const v4fv & a, Dot4 & d)
+{
+  const f16x8v wv = __builtin_bit_cast(f16x8v, w), av = __builtin_bit_cast(f16x8v, a);
+  d.c[0] = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 0, 1), __builtin_shufflevector(av, av, 0, 1), d.c[0], false);
+  d.c[1] = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 2, 3), __builtin_shufflevector(av, av, 2, 3), d.c[1], false);
+  d.c[2] = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 4, 5), __builtin_shufflevector(av, av, 4, 5), d.c[2], false);
+  d.c[3] = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 6, 7), __builtin_shufflevector(av, av, 6, 7), d.c[3], false);
+}
+__device__ __forceinline__ float dot4_sum(const Dot4 & d)
+{
+  return (d.c[0] + d.c[1]) + (d.c[2] + d.c[3]);
+}
 // per-frame power-of-two scale that puts max|v| of a 512-vector (two entries per thread) just under 2^14; red: [5] floats of LDS
 __device__ __forceinline__ float vscale512(float v0, float v1, float * red)
 {
@@ -450,7 +473,7 @@ __global__ __launch_bounds__(256) void vposer_jac_kernel(const float * __restric
   // the four tiles) and 8 A fragments from L2, prefetched three k-steps ahead; 12 MFMAs + 48 v_dot2
   {
     f32x16v acc[4];
-    float hq[4] = {0.f, 0.f, 0.f, 0.f};
+    Dot4 hq[4] = {{{0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}}};
 #pragma unroll
     for(int t = 0; t < 4; t++)
 #pragma unroll
@@ -490,9 +513,16 @@ __global__ __launch_bounds__(256) void vposer_jac_kernel(const float * __restric
           acc[t] = vmfma(st[u][t][0], bh, acc[t]);
           acc[t] = vmfma(st[u][t][0], bl, acc[t]);
           acc[t] = vmfma(st[u][t][1], bh, acc[t]);
-          hq[t] = vdot8(st[u][t][1], ah, hq[t]);
-          hq[t] = vdot8(st[u][t][0], al, hq[t]);
-          hq[t] = vdot8(st[u][t][0], ah, hq[t]);
+          vdot8x4(st[u][t][1], ah, hq[t]);
+          vdot8x4(st[u][t][0], al, hq[t]);
+          vdot8x4(st[u][t][0], ah, hq[t]);
+        }
+        // (four v_dot2 behind each MFMA instead of all 48 behind the twelve: see vposer_jac2_kernel)
+#pragma unroll
+        for(int i = 0; i < 12; i++)
+        {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         }
       }
     }
@@ -504,7 +534,8 @@ __global__ __launch_bounds__(256) void vposer_jac_kernel(const float * __restric
     for(int t = 0; t < 4; t++)
     {
       const int row = 32 * (4 * wave + t) + l31;
-      const float h = (hq[t] + __shfl_xor(hq[t], 32, 64)) * iv + b1[row];
+      const float hs = dot4_sum(hq[t]);
+      const float h = (hs + __shfl_xor(hs, 32, 64)) * iv + b1[row];
       sv[t] = (h > 0.0f) ? 1.0f : 0.01f;
       hv[t] = h * sv[t];
       if(lh == 0)
@@ -517,7 +548,7 @@ __global__ __launch_bounds__(256) void vposer_jac_kernel(const float * __restric
 #ifdef VPJ_DUMP
     jac[f * 63 * LAT + tid] = a2[tid];
     jac[f * 63 * LAT + tid + 256] = a2[tid + 256];
-    if(wave == 0) jac[f * 63 * LAT + 512 + l] = hq[0] * iv;
+    if(wave == 0) jac[f * 63 * LAT + 512 + l] = dot4_sum(hq[0]) * iv;
     if(wave == 0) jac[f * 63 * LAT + 576 + l] = (float)reinterpret_cast<const _Float16 *>(Af)[l] / sA1; // Af of k-step 0 and 1: hi(h0) hi(h1) lo(h0) lo(h1)
     return;
 #endif
@@ -555,7 +586,7 @@ __global__ __launch_bounds__(256) void vposer_jac_kernel(const float * __restric
   {
     const float sA2 = red[8];
     f32x16v acc;
-    float hq = 0.f;
+    Dot4 hq = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for(int r = 0; r < 16; r++) acc[r] = 0.0f;
     const uint8_t * ap = w2h + (size_t)wave * (32 * 2048) + l * 16;
@@ -581,13 +612,20 @@ __global__ __launch_bounds__(256) void vposer_jac_kernel(const float * __restric
         acc = vmfma(st[u][0], bh, acc);
         acc = vmfma(st[u][0], bl, acc);
         acc = vmfma(st[u][1], bh, acc);
-        hq = vdot8(st[u][1], ah, hq);
-        hq = vdot8(st[u][0], al, hq);
-        hq = vdot8(st[u][0], ah, hq);
+        vdot8x4(st[u][1], ah, hq);
+        vdot8x4(st[u][0], al, hq);
+        vdot8x4(st[u][0], ah, hq);
+#pragma unroll
+        for(int i = 0; i < 3; i++)
+        {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
       }
     }
     const int arow = 32 * wave + l31;
-    const float hsum = hq + __shfl_xor(hq, 32, 64); // (so aliases D1f, whose last readers passed two barriers ago)
+    const float hs2 = dot4_sum(hq);
+    const float hsum = hs2 + __shfl_xor(hs2, 32, 64); // (so aliases D1f, whose last readers passed two barriers ago)
     if(arow < OUT6 && lh == 0) so[arow * 33 + 32] = hsum * (iW2 / sA2) + b2[arow];
     const float u2 = iW2 / sD2;
 #pragma unroll
@@ -617,6 +655,349 @@ __global__ __launch_bounds__(256) void vposer_jac_kernel(const float * __restric
     float s = 0.f;
     for(int q = 0; q < 6; q++) s += sj[j * 18 + i * 6 + q] * so[(j * 6 + q) * 33 + c];
     jac[(f * 63 + row) * LAT + c] = s;
+  }
+  VPJ_T(6);
+}
+
+
+// ---- forward + Jacobian, NF frames per workgroup (vposer_jac2_kernel).
+// vposer_jac_kernel above is bound by its weight stream: per k-step a wavefront pulls 8 KB of W1 fragments for 384 cycles of
+// MFMA (85 B/clk per CU against the 64 B/clk a CU's vector memory path delivers), one frame per workgroup, one workgroup per CU
+// (its two 64 KiB tangent blocks fill the LDS).  Here NF frames share every weight fragment (NF x the MFMAs per byte), made
+// possible by NOT storing the layer-0 tangent block:  T0 = diag(s) W0 with LeakyReLU slopes s in {1, 0.01}, so
+//     W1 . T0 = 0.99 W1 . (m (.) W0) + 0.01 W1 . W0            (m = the rows with slope 1)
+// — the B operand of layer 1 is ONE W0 fragment stream (w0h, shared by all frames and workgroups, from L2 like the weights),
+// masked per frame in registers (a 1 KiB mask image per frame in LDS), and C10 = W1 . W0 is a constant of the model added in
+// fp32.  LDS then only holds the layer-1 tangent blocks (64 KiB per frame): NF = 2 fits.
+template<int NF>
+struct VJ2
+{
+  static constexpr int D2 = 0;                          // [NF][VJ_DF] layer-1 tangent blocks, fragment order
+  static constexpr int A2 = NF * VJ_DF;                 // [NF][512] fp32 layer-1 activations
+  static constexpr int SL = A2 + NF * HID * 4;          // [NF][512] fp32 layer-1 slopes
+  static constexpr int AF = SL + NF * HID * 4;          // [NF][VJ_AF] activation fragments of the layer being consumed
+  static constexpr int MK = AF + NF * VJ_AF;            // [NF][32 k-steps][2 halves][8 fp16] row masks of layer 0 (0xffff: slope 1)
+  static constexpr int SZ = MK + NF * 1024;             // [NF][32] latents
+  static constexpr int RED = SZ + NF * LAT * 4;         // [16] scratch of the scale reductions | 64 zero bytes (dead columns of the value tile)
+  static constexpr int TOTAL = RED + 64 + 64;
+};
+
+template<int NF>
+__global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restrict__ z, int64_t z_stride, const float * __restrict__ w0t,
+                                                          const float * __restrict__ b0, const float * __restrict__ b1,
+                                                          const float * __restrict__ b2, const uint8_t * __restrict__ w1h,
+                                                          const uint8_t * __restrict__ w2h, const uint8_t * __restrict__ w0h,
+                                                          const float * __restrict__ c10, float sD1, float sD2, float iW1, float iW2,
+                                                          float * __restrict__ out, int64_t out_stride, float * __restrict__ jac, int64_t n)
+{
+  typedef VJ2<NF> L;
+  extern __shared__ __attribute__((aligned(16))) unsigned char vl[];
+  float * red = reinterpret_cast<float *>(vl + L::RED);
+  const int64_t f0 = (int64_t)blockIdx.x * NF;
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, l31 = l & 31, lh = l >> 5;
+  VPJ_T(0);
+  // ---- layer 0 (+ LeakyReLU 0.01), rows tid and tid + 256 of every frame: the 64 weights of the two rows are loaded once
+  float w0a[LAT], w0b[LAT];
+#pragma unroll
+  for(int c = 0; c < LAT; c++)
+  {
+    w0a[c] = w0t[c * HID + tid];
+    w0b[c] = w0t[c * HID + tid + 256];
+  }
+  if(tid >= 128 && tid < 144) reinterpret_cast<float *>(vl + L::RED + 64)[tid - 128] = 0.0f;
+  if(tid < NF * LAT)
+  {
+    const int64_t f = f0 + tid / LAT < n ? f0 + tid / LAT : n - 1; // (a workgroup's spare frame repeats the last one; never stored)
+    reinterpret_cast<float *>(vl + L::SZ)[tid] = z[f * z_stride + tid % LAT];
+  }
+  __syncthreads();
+  float sA1[NF];
+#pragma unroll
+  for(int q = 0; q < NF; q++)
+  {
+    const float * sz = reinterpret_cast<const float *>(vl + L::SZ) + q * LAT;
+    float h0 = b0[tid], h1 = b0[tid + 256];
+#pragma unroll
+    for(int c = 0; c < LAT; c++)
+    {
+      h0 += w0a[c] * sz[c];
+      h1 += w0b[c] * sz[c];
+    }
+    const bool p0 = h0 > 0.0f, p1 = h1 > 0.0f;
+    h0 *= p0 ? 1.0f : 0.01f;
+    h1 *= p1 ? 1.0f : 0.01f;
+    // row masks in the B fragment's element order: row k is element k % 8 of lane half (k % 16) / 8 in k-step k / 16
+    unsigned short * mk = reinterpret_cast<unsigned short *>(vl + L::MK + q * 1024);
+    mk[(tid >> 4) * 16 + ((tid >> 3) & 1) * 8 + (tid & 7)] = p0 ? 0xffffu : 0u;
+    mk[((tid + 256) >> 4) * 16 + (((tid + 256) >> 3) & 1) * 8 + (tid & 7)] = p1 ? 0xffffu : 0u;
+    sA1[q] = vscale512(h0, h1, red);
+    vput_act(vl + L::AF + q * VJ_AF, tid, h0 * sA1[q]);
+    vput_act(vl + L::AF + q * VJ_AF, tid + 256, h1 * sA1[q]);
+  }
+  __syncthreads();
+  VPJ_T(1);
+  // ---- layer 1: wavefront w owns the row tiles 4w .. 4w + 3 of EVERY frame; per k-step 8 W1 fragments and 2 W0 fragments from
+  // L2 (prefetched three k-steps ahead), per frame a mask and 2 activation fragments from LDS, 12 MFMAs + 48 v_dot2
+  {
+    // The VALUE path (h1 = W1 a0 + b1) rides on the matrix pipe too: the activation vectors of the NF frames are columns 0 .. NF - 1
+    // of ONE more B tile (the other columns zero), three MFMAs per row tile and k-step for all frames together.  (v_dot2c_f32_f16
+    // on the same weight fragments, as vposer_jac_kernel does it, issues once per 16 cycles: its 48 per frame and k-step cost twice
+    // the 12 tangent MFMAs they were meant to hide behind.)
+    f32x16v acc[NF][4], vacc[4];
+#pragma unroll
+    for(int t = 0; t < 4; t++)
+    {
+#pragma unroll
+      for(int r = 0; r < 16; r++) vacc[t][r] = 0.0f;
+#pragma unroll
+      for(int q = 0; q < NF; q++)
+#pragma unroll
+        for(int r = 0; r < 16; r++) acc[q][t][r] = 0.0f;
+    }
+    // this lane's slice of the value tile: column l31 = frame (a zeroed slot of LDS for the columns beyond the frames)
+    const unsigned char * const avp = (l31 < NF) ? vl + L::AF + l31 * VJ_AF + lh * 16 : vl + L::RED + 64;
+    const int avs = (l31 < NF) ? 64 : 0;
+    const uint8_t * ap = w1h + (size_t)(4 * wave) * (32 * 2048) + l * 16;
+    const uint8_t * bp = w0h + l * 16;
+    v4fv st[4][4][2], sb[4][2];
+    auto load_stage = [&](int sidx, int ks) {
+#pragma unroll
+      for(int t = 0; t < 4; t++)
+#pragma unroll
+        for(int p = 0; p < 2; p++) st[sidx][t][p] = *reinterpret_cast<const v4fv *>(ap + (size_t)t * (32 * 2048) + ks * 2048 + p * 1024);
+      sb[sidx][0] = *reinterpret_cast<const v4fv *>(bp + ks * 2048);
+      sb[sidx][1] = *reinterpret_cast<const v4fv *>(bp + ks * 2048 + 1024);
+    };
+    const int rot = (int)((blockIdx.x * 5u) & 31u); // (every workgroup starts its k loop elsewhere: see vposer_jac_kernel)
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    // LDS operands of a k-step (value tile pieces, one row mask per frame), read one k-step ahead into a second register set
+    v4fv vah[2], val[2];
+    u4v mk[2][NF];
+    auto load_lds = [&](int slot, int ks) {
+      vah[slot] = *reinterpret_cast<const v4fv *>(avp + ks * avs);
+      val[slot] = *reinterpret_cast<const v4fv *>(avp + ks * avs + (avs >> 1));
+#pragma unroll
+      for(int q = 0; q < NF; q++) mk[slot][q] = *reinterpret_cast<const u4v *>(vl + L::MK + q * 1024 + ks * 32 + lh * 16);
+    };
+    load_stage(0, rot);
+    load_stage(1, (rot + 1) & 31);
+    load_stage(2, (rot + 2) & 31);
+    load_lds(0, rot);
+    for(int k4 = 0; k4 < 32; k4 += 4)
+    {
+#pragma unroll
+      for(int u = 0; u < 4; u++)
+      {
+        const int ks = (k4 + u + rot) & 31;
+        load_stage((u + 3) & 3, (ks + 3) & 31);
+        load_lds((u + 1) & 1, (ks + 1) & 31);
+        // (pinned: with 420 registers live the scheduler otherwise sinks these loads to just in front of their use three k-steps
+        // later — and the loop then waits out an L2 round trip per k-step)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for(int t = 0; t < 4; t++)
+        {
+          vacc[t] = vmfma(st[u][t][0], vah[u & 1], vacc[t]);
+          vacc[t] = vmfma(st[u][t][0], val[u & 1], vacc[t]);
+          vacc[t] = vmfma(st[u][t][1], vah[u & 1], vacc[t]);
+        }
+#pragma unroll
+        for(int q = 0; q < NF; q++)
+        {
+          const v4fv bh = __builtin_bit_cast(v4fv, __builtin_bit_cast(u4v, sb[u][0]) & mk[u & 1][q]);
+          const v4fv bl = __builtin_bit_cast(v4fv, __builtin_bit_cast(u4v, sb[u][1]) & mk[u & 1][q]);
+#pragma unroll
+          for(int t = 0; t < 4; t++)
+          {
+            acc[q][t] = vmfma(st[u][t][0], bh, acc[q][t]);
+            acc[q][t] = vmfma(st[u][t][0], bl, acc[q][t]);
+            acc[q][t] = vmfma(st[u][t][1], bh, acc[q][t]);
+          }
+        }
+      }
+    }
+    VPJ_T(2);
+    // the raw row sums of this wavefront's 128 rows sit in the lanes of column q < NF (frame q), rows (r & 3) + 8 (r >> 2) + 4 lh:
+    // dropped into LDS as they are; bias, LeakyReLU and slope by all threads, two rows each, behind the barrier
+    if(l31 < NF)
+    {
+      float * a2 = reinterpret_cast<float *>(vl + L::A2) + l31 * HID;
+#pragma unroll
+      for(int t = 0; t < 4; t++)
+#pragma unroll
+        for(int g = 0; g < 4; g++)
+          *reinterpret_cast<v4fv *>(a2 + 32 * (4 * wave + t) + 8 * g + 4 * lh) = v4fv{vacc[t][4 * g], vacc[t][4 * g + 1], vacc[t][4 * g + 2], vacc[t][4 * g + 3]};
+    }
+    __syncthreads();
+    {
+      const float bb0 = b1[tid], bb1 = b1[tid + 256];
+#pragma unroll
+      for(int q = 0; q < NF; q++)
+      {
+        float * a2 = reinterpret_cast<float *>(vl + L::A2) + q * HID;
+        float * sl1 = reinterpret_cast<float *>(vl + L::SL) + q * HID;
+        const float iv = iW1 / sA1[q];
+        const float h0 = a2[tid] * iv + bb0, h1 = a2[tid + 256] * iv + bb1;
+        const float s0 = (h0 > 0.0f) ? 1.0f : 0.01f, s1 = (h1 > 0.0f) ? 1.0f : 0.01f;
+        a2[tid] = h0 * s0;
+        a2[tid + 256] = h1 * s1;
+        sl1[tid] = s0;
+        sl1[tid + 256] = s1;
+      }
+    }
+    __syncthreads(); // slopes and activations of layer 1 are in LDS; every wavefront is done with the layer-0 fragments
+    // T1 = slope1 (.) (0.01 C10 + 0.99 W1 (m (.) W0)) into the B fragments of layer 2: this lane holds column l31 and, per tile, the
+    // rows (r & 3) + 8 (r >> 2) + 4 lh; the four rows of a register group g = r >> 2 are elements j = 4 lh .. 4 lh + 3 of lane
+    // 32 (g & 1) + column in k-step 2 tile + (g >> 1): one 8-byte store per piece
+    const float um = 0.99f * iW1 / sD1;
+#pragma unroll
+    for(int t = 0; t < 4; t++)
+#pragma unroll
+      for(int g = 0; g < 4; g++)
+      {
+        const int tile = 4 * wave + t, row0 = 32 * tile + 8 * g + 4 * lh;
+        float cc[4];
+#pragma unroll
+        for(int i = 0; i < 4; i++) cc[i] = 0.01f * c10[(row0 + i) * LAT + l31];
+#pragma unroll
+        for(int q = 0; q < NF; q++)
+        {
+          const float * sl1 = reinterpret_cast<const float *>(vl + L::SL) + q * HID;
+          f16x4v hi, lo;
+#pragma unroll
+          for(int i = 0; i < 4; i++)
+          {
+            _Float16 a, b;
+            split_f16x2(sl1[row0 + i] * (cc[i] + acc[q][t][4 * g + i] * um) * sD2, a, b);
+            hi[i] = a;
+            lo[i] = b;
+          }
+          unsigned char * dst = vl + L::D2 + q * VJ_DF + (2 * tile + (g >> 1)) * 2048 + (32 * (g & 1) + l31) * 16 + 8 * lh;
+          *reinterpret_cast<f16x4v *>(dst) = hi;
+          *reinterpret_cast<f16x4v *>(dst + 1024) = lo;
+        }
+      }
+  }
+  float sA2[NF];
+#pragma unroll
+  for(int q = 0; q < NF; q++)
+  {
+    const float * a2 = reinterpret_cast<const float *>(vl + L::A2) + q * HID;
+    sA2[q] = vscale512(a2[tid], a2[tid + 256], red);
+    vput_act(vl + L::AF + q * VJ_AF, tid, a2[tid] * sA2[q]);
+    vput_act(vl + L::AF + q * VJ_AF, tid + 256, a2[tid + 256] * sA2[q]);
+  }
+  __syncthreads();
+  VPJ_T(3);
+  // ---- layer 2: wavefront w owns rows 32 w .. 32 w + 31 (126 live) of every frame
+  {
+    f32x16v acc[NF], vacc;
+#pragma unroll
+    for(int r = 0; r < 16; r++) vacc[r] = 0.0f;
+#pragma unroll
+    for(int q = 0; q < NF; q++)
+#pragma unroll
+      for(int r = 0; r < 16; r++) acc[q][r] = 0.0f;
+    const unsigned char * const avp = (l31 < NF) ? vl + L::AF + l31 * VJ_AF + lh * 16 : vl + L::RED + 64;
+    const int avs = (l31 < NF) ? 64 : 0;
+    const uint8_t * ap = w2h + (size_t)wave * (32 * 2048) + l * 16;
+    // (nine MFMAs per k-step: three k-steps of lead are 900 cycles, less than an L2 round trip under load — seven here)
+    v4fv st[8][2];
+#pragma unroll
+    for(int s3 = 0; s3 < 7; s3++)
+    {
+      st[s3][0] = *reinterpret_cast<const v4fv *>(ap + s3 * 2048);
+      st[s3][1] = *reinterpret_cast<const v4fv *>(ap + s3 * 2048 + 1024);
+    }
+    v4fv vah[2], val[2], dbh[2][NF], dbl[2][NF];
+    auto load_lds = [&](int slot, int ks) {
+      vah[slot] = *reinterpret_cast<const v4fv *>(avp + ks * avs);
+      val[slot] = *reinterpret_cast<const v4fv *>(avp + ks * avs + (avs >> 1));
+#pragma unroll
+      for(int q = 0; q < NF; q++)
+      {
+        dbh[slot][q] = *reinterpret_cast<const v4fv *>(vl + L::D2 + q * VJ_DF + ks * 2048 + l * 16);
+        dbl[slot][q] = *reinterpret_cast<const v4fv *>(vl + L::D2 + q * VJ_DF + ks * 2048 + 1024 + l * 16);
+      }
+    };
+    load_lds(0, 0);
+    for(int k8 = 0; k8 < 32; k8 += 8)
+    {
+#pragma unroll
+      for(int u = 0; u < 8; u++)
+      {
+        const int ks = k8 + u, kn = ks + 7 < 32 ? ks + 7 : 31;
+        st[(u + 7) & 7][0] = *reinterpret_cast<const v4fv *>(ap + kn * 2048);
+        st[(u + 7) & 7][1] = *reinterpret_cast<const v4fv *>(ap + kn * 2048 + 1024);
+        load_lds((u + 1) & 1, ks + 1 < 32 ? ks + 1 : 31);
+        __builtin_amdgcn_sched_barrier(0);
+        vacc = vmfma(st[u][0], vah[u & 1], vacc);
+        vacc = vmfma(st[u][0], val[u & 1], vacc);
+        vacc = vmfma(st[u][1], vah[u & 1], vacc);
+#pragma unroll
+        for(int q = 0; q < NF; q++)
+        {
+          acc[q] = vmfma(st[u][0], dbh[u & 1][q], acc[q]);
+          acc[q] = vmfma(st[u][0], dbl[u & 1][q], acc[q]);
+          acc[q] = vmfma(st[u][1], dbh[u & 1][q], acc[q]);
+        }
+      }
+    }
+    __syncthreads(); // every wavefront is done with the tangent blocks: the layer-2 output so [126][33] of frame q takes its place
+    const float u2 = iW2 / sD2;
+    if(l31 < NF) // the layer-2 values of frame l31: rows (r & 3) + 8 (r >> 2) + 4 lh of this wavefront's tile
+    {
+      float iv2 = iW2 / sA2[0];
+#pragma unroll
+      for(int q = 1; q < NF; q++) iv2 = (l31 == q) ? iW2 / sA2[q] : iv2;
+      float * so = reinterpret_cast<float *>(vl + L::D2 + l31 * VJ_DF);
+#pragma unroll
+      for(int r = 0; r < 16; r++)
+      {
+        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if(row < OUT6) so[row * 33 + 32] = vacc[r] * iv2 + b2[row];
+      }
+    }
+#pragma unroll
+    for(int q = 0; q < NF; q++)
+    {
+      float * so = reinterpret_cast<float *>(vl + L::D2 + q * VJ_DF);
+#pragma unroll
+      for(int r = 0; r < 16; r++)
+      {
+        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if(row < OUT6) so[row * 33 + l31] = acc[q][r] * u2;
+      }
+    }
+  }
+  __syncthreads();
+  VPJ_T(4);
+  // ---- rotation tail: 6D -> axis-angle and its 3 x 6 Jacobian, one thread per (frame, joint); the chain rule into the 32 latent
+  // columns by all threads
+  if(tid < 21 * NF)
+  {
+    const int q = tid / 21, j = tid % 21;
+    const float * so = reinterpret_cast<const float *>(vl + L::D2 + q * VJ_DF);
+    float * sj = reinterpret_cast<float *>(vl + L::D2 + q * VJ_DF + 126 * 33 * 4); // [21][18] behind so
+    float o6[6], aa[3], j36[18];
+    for(int i = 0; i < 6; i++) o6[i] = so[(j * 6 + i) * 33 + 32];
+    sixd_to_aa(o6, aa, j36);
+    if(f0 + q < n)
+      for(int i = 0; i < 3; i++) out[(f0 + q) * out_stride + j * 3 + i] = aa[i];
+    for(int i = 0; i < 18; i++) sj[j * 18 + i] = j36[i];
+  }
+  __syncthreads();
+  VPJ_T(5);
+  for(int item = tid; item < NF * 63 * LAT; item += 256)
+  {
+    const int q = item / (63 * LAT), it = item % (63 * LAT);
+    if(f0 + q >= n) continue;
+    const float * so = reinterpret_cast<const float *>(vl + L::D2 + q * VJ_DF);
+    const float * sj = reinterpret_cast<const float *>(vl + L::D2 + q * VJ_DF + 126 * 33 * 4);
+    const int row = it / LAT, c = it % LAT, j = row / 3, i = row % 3;
+    float s = 0.f;
+    for(int k = 0; k < 6; k++) s += sj[j * 18 + i * 6 + k] * so[(j * 6 + k) * 33 + c];
+    jac[((f0 + q) * 63 + row) * LAT + c] = s;
   }
   VPJ_T(6);
 }
@@ -658,6 +1039,17 @@ __global__ void rotmat_to_aa_kernel(const float * __restrict__ rot, float * __re
 int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
                           float * jac, hipStream_t st)
 {
+  if(jac && v->jac_form == 2 && v->w0h && v->c10 && n > device_cus(v->device))
+  {
+    // more frames than CUs: two frames per workgroup share every weight fragment (vposer_jac2_kernel)
+    static PerDeviceOnce once2;
+    HIP_TRY(lds_opt_in(once2, v->device, reinterpret_cast<const void *>(&vposer_jac2_kernel<2>), VJ2<2>::TOTAL));
+    vposer_jac2_kernel<2><<<dim3((unsigned)((n + 1) / 2)), dim3(256), VJ2<2>::TOTAL, st>>>(z, z_stride, v->w0t, v->b0, v->b1, v->b2, v->w1h, v->w2h,
+                                                                                         v->w0h, v->c10, v->sD1, v->sD2, 1.0f / v->sW1,
+                                                                                         1.0f / v->sW2, out, out_stride, jac, n);
+    HIP_TRY(hipGetLastError());
+    return SMPLPP_OK;
+  }
   if(jac)
   {
     static PerDeviceOnce oncej;
@@ -687,6 +1079,8 @@ extern "C" int smplpp_vposer_destroy(smplpp_vposer * v)
     if(p) (void)hipFree(p);
   if(v->w1h) (void)hipFree(v->w1h);
   if(v->w2h) (void)hipFree(v->w2h);
+  if(v->w0h) (void)hipFree(v->w0h);
+  if(v->c10) (void)hipFree(v->c10);
   delete v;
   return SMPLPP_OK;
 }
@@ -740,6 +1134,37 @@ extern "C" int smplpp_vposer_create(int device, const float * w0, const float * 
     v->sD2 = pow2_under(16384.0f, 512.0f * m1 * m0);
     if(e == hipSuccess) e = upload_frag(&v->w1h, w1, HID, HID, v->sW1);
     if(e == hipSuccess) e = upload_frag(&v->w2h, w2, OUT6, HID, v->sW2);
+    if(e == hipSuccess)
+    {
+      // W0 [512][32] as the B operand of layer 1 (k = row of W0): [32 k-steps][piece 2][64 lanes (32 h + column)][8 fp16]
+      std::vector<_Float16> t((size_t)32 * 2 * 64 * 8);
+      for(int row = 0; row < HID; row++)
+        for(int c = 0; c < LAT; c++)
+        {
+          _Float16 hi, lo;
+          split_f16x2(w0[(size_t)row * LAT + c] * v->sD1, hi, lo);
+          const size_t o = (((size_t)(row >> 4) * 2) * 64 + 32 * ((row >> 3) & 1) + c) * 8 + (row & 7);
+          t[o] = hi;
+          t[o + 64 * 8] = lo;
+        }
+      e = hipMalloc((void **)&v->w0h, sizeof(_Float16) * t.size());
+      if(e == hipSuccess) e = hipMemcpy(v->w0h, t.data(), sizeof(_Float16) * t.size(), hipMemcpyHostToDevice);
+    }
+    if(e == hipSuccess)
+    {
+      std::vector<float> c((size_t)HID * LAT);
+      for(int r = 0; r < HID; r++)
+        for(int cc = 0; cc < LAT; cc++)
+        {
+          double sum = 0.0;
+          for(int k = 0; k < HID; k++) sum += (double)w1[(size_t)r * HID + k] * (double)w0[(size_t)k * LAT + cc];
+          c[(size_t)r * LAT + cc] = (float)sum;
+        }
+      e = hipMalloc((void **)&v->c10, sizeof(float) * c.size());
+      if(e == hipSuccess) e = hipMemcpy(v->c10, c.data(), sizeof(float) * c.size(), hipMemcpyHostToDevice);
+    }
+    const char * jf = getenv("SMPLPP_VPOSER_JAC"); // read once, here (1: the one-frame-per-workgroup kernel for every batch size)
+    v->jac_form = (jf && jf[0] == '1') ? 1 : 2;
   }
   if(e != hipSuccess)
   {
