@@ -1230,6 +1230,32 @@ __device__ inline void stage_rows(double * dst, const double * __restrict__ src,
   }
 }
 
+// the first W columns of cr rows (row stride D in HBM) packed at stride W in LDS, eight loads in flight per thread
+__device__ inline void stage_rows_cols(double * dst, const double * __restrict__ src, int cr, int W, int D)
+{
+  // (the copy is a chain of HBM round trips, ~1.5 us each with a single workgroup pulling: sixteen loads in flight per thread —
+  // the 164 x 75 block of a motion solve in three round trips instead of six)
+  const int tid = threadIdx.x, cnt = cr * W;
+  constexpr int U = 16;
+  for(int q0 = 0; q0 < cnt; q0 += 256 * U)
+  {
+    double t[U];
+#pragma unroll
+    for(int u = 0; u < U; u++)
+    {
+      const int q = q0 + u * 256 + tid, qq = q < cnt ? q : cnt - 1;
+      const int rr = qq / W;
+      t[u] = src[(int64_t)rr * D + (qq - rr * W)];
+    }
+#pragma unroll
+    for(int u = 0; u < U; u++)
+    {
+      const int q = q0 + u * 256 + tid;
+      if(q < cnt) dst[q] = t[u];
+    }
+  }
+}
+
 // Factorisation + both substitutions of the packed (r + 1) x (r + 1) augmented matrix [S v; v' *] by ONE wavefront, lane i
 // owning row i. Register form (r <= RMAX <= 32): the row lives in registers, a column's entries reach the other lanes by
 // v_readlane (an SGPR operand of the FMA), so a column costs its pivot's rsqrt plus (r - k) FMAs and no LDS round trip;
@@ -1441,7 +1467,7 @@ __device__ inline void solve_dual(double * M, const double * __restrict__ J, con
 template<int NT>
 __device__ inline void build_and_factor_reg(double * M, const double * __restrict__ J, const double * __restrict__ rowv, double * Jc,
                                             const double * diag, const double * bpri, const int * idx, int nf, int D, int rows,
-                                            int chunk_rows, double * lraw /*[2][16*NT]*/, double * ldiag /*[4]*/, double * dinv /*[nf]*/, int * bad,
+                                            int chunk_rows, double * lraw /*[2][4][16*NT]*/, double * ldiag /*[4]*/, double * dinv /*[nf]*/, int * bad,
                                             int dbg_stop = 0)
 {
   // thread (ty, tx): tx in the HIGH bits, so the 16 holders of a column (one tx, all ty) sit in one wavefront and the other
@@ -1476,25 +1502,40 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
       colB[u] = (mk < nf) ? idx[mk] : -2;
       tacc[u] = d4{0.0, 0.0, 0.0, 0.0};
     }
-    for(int c0 = 0; c0 < rows; c0 += chunk_rows)
+    // only the columns up to the last free one are staged (the free set is ascending), rows packed at that width: a motion
+    // solve with its surface coordinates pinned reads 75 of its 157 columns — half the traffic, and all 164 rows in ONE chunk
+    const int W = nf > 0 ? idx[nf - 1] + 1 : 1;
+    const int crows = (int)(((int64_t)chunk_rows * D) / W);
+    for(int c0 = 0; c0 < rows; c0 += crows)
     {
-      const int cr = (rows - c0 < chunk_rows) ? rows - c0 : chunk_rows;
+      const int cr = (rows - c0 < crows) ? rows - c0 : crows;
       __syncthreads();
-      stage_rows(Jc, J + (int64_t)c0 * D, cr * D);
+      if(W == D)
+        stage_rows(Jc, J + (int64_t)c0 * D, cr * D);
+      else
+        stage_rows_cols(Jc, J + (int64_t)c0 * D, cr, W, D);
       __syncthreads();
       for(int r0 = 0; r0 < cr; r0 += 4)
       {
         const int r = r0 + lq;
         const bool rin = r < cr;
         const double rv = rowv[c0 + (rin ? r : 0)];
-        const double * Jr = Jc + (rin ? r : 0) * D;
+        const double * Jr = Jc + (rin ? r : 0) * W;
+        // (every tile's two operands are read first, then the MFMAs: a read -> wait -> MFMA pair per tile paid the LDS round
+        // trip TPW times per four rows)
+        double ja[TPW], jb[TPW];
 #pragma unroll
         for(int u = 0; u < TPW; u++)
         {
-          if(!live[u]) continue;
-          const double ja = Jr[colA[u] >= 0 ? colA[u] : 0], jb = Jr[colB[u] >= 0 ? colB[u] : 0];
-          const double va = !rin ? 0.0 : (colA[u] >= 0 ? ja : (colA[u] == -1 ? rv : 0.0));
-          const double vb = (rin && colB[u] >= 0) ? jb : 0.0;
+          ja[u] = Jr[colA[u] >= 0 ? colA[u] : 0];
+          jb[u] = Jr[colB[u] >= 0 ? colB[u] : 0];
+        }
+#pragma unroll
+        for(int u = 0; u < TPW; u++)
+        {
+          if(!live[u]) continue; // (wave-uniform)
+          const double va = !rin ? 0.0 : (colA[u] >= 0 ? ja[u] : (colA[u] == -1 ? rv : 0.0));
+          const double vb = (rin && colB[u] >= 0) ? jb[u] : 0.0;
           tacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, tacc[u], 0, 0, 0);
         }
       }
@@ -1540,35 +1581,36 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
       if(i == nf && k < nf) acc[a][b] += bpri[idx[k]];
     }
   if(dbg_stop == 4) return;
-  // factorisation, TWO columns per barrier.  The holders of columns j0 and j1 = j0 + 1 publish their raw entries; one
-  // barrier later every thread forms, from those two published columns alone, the corrected column j1
-  //   c_i = a_{i,j1} - a_{i,j0} a_{j1,j0} / d0      (d0 = a_{j0,j0}),   d1 = c_{j1}
-  // for the rows and columns it owns and applies the rank-2 update  a_ik -= a_{i,j0} a_{k,j0} / d0 + c_i c_k / d1
-  // to its registers (the elements of column j1 itself take only the first term and become c).  Nothing but two
-  // reciprocals sits between the barrier and the update; square roots are taken once, after the loop.
-  // lraw: [2 (pair parity)][2 (column of the pair)][16 NT], zeroed: rows beyond nf are never published.
+  // factorisation, FOUR columns per barrier (round 2: two; the loop is a chain of barrier -> pivot reciprocals -> update, and
+  // its length, not its arithmetic, is what it costs: 38 steps of ~1.9 k cycles for the 76 columns of a motion solve).  The
+  // holders of columns j_0 .. j_3 publish their raw entries R_q; one barrier later every thread forms, from those four published
+  // columns alone, the corrected columns
+  //   C_q = R_q - sum_{s<q} C_s L_qs,   L_qs = C_s[j_q] / d_s,   d_s = C_s[j_s]        (an LDL^T of the 4 x 4 pivot block)
+  // for the rows and columns it owns and applies the rank-4 update  a_ik -= sum_s C_s[i] C_s[k] / d_s  to its registers (the
+  // elements of column j_q itself take only the terms s < q and so become C_q).  Nothing but four reciprocals sits between the
+  // barrier and the update; square roots are taken once, after the loop.
+  // lraw: [2 (step parity)][4 (column of the step)][16 NT], zeroed: rows beyond nf are never published.
   constexpr int LS = 16 * NT;
   bool kcol[NT]; // tx + 16 a is a column of the system (not the rhs row, not padding)
 #pragma unroll
   for(int a = 0; a < NT; a++) kcol[a] = tx + 16 * a < nf;
-  for(int q = tid; q < 4 * LS; q += 256) lraw[q] = 0.0;
+  for(int q = tid; q < 8 * LS; q += 256) lraw[q] = 0.0;
   __syncthreads();
-  int pair = 0;
+  int par = 0;
 #pragma unroll
   for(int bj = 0; bj < NT; bj++)
   {
-    for(int jj = 0; jj < 16; jj += 2)
+    for(int jj = 0; jj < 16; jj += 4)
     {
-      const int j0 = 16 * bj + jj, j1 = j0 + 1;
+      const int j0 = 16 * bj + jj;
       if(j0 >= nf) break; // uniform
-      const bool two = j1 < nf; // uniform
-      double * l0 = lraw + (pair & 1) * 2 * LS;
-      double * l1 = l0 + LS;
-      pair++;
-      if(tx == jj || (two && tx == jj + 1)) // the holders publish (both columns live in tile column bj)
+      const int ncol = nf - j0 < 4 ? nf - j0 : 4; // uniform: live columns of this step
+      double * lb = lraw + (par & 1) * 4 * LS;
+      par++;
+      if(tx >= jj && tx < jj + ncol) // the holders publish (all four columns live in tile column bj)
       {
-        double * lp = (tx == jj) ? l0 : l1;
-        const int jc = (tx == jj) ? j0 : j1;
+        double * lp = lb + (tx - jj) * LS;
+        const int jc = j0 + (tx - jj);
 #pragma unroll
         for(int a = bj; a < NT; a++)
         {
@@ -1577,44 +1619,61 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
         }
       }
       __syncthreads();
-      double d0 = l0[j0];
-      if(!(d0 > 0.0))
+      // LDL^T of the pivot block from the published entries R_s[j_q], s <= q (broadcast reads); dead columns: inv = 0, L = 0
+      double inv[4], L[4][4];
       {
-        *bad = 1;
-        d0 = 1.0;
+        double Cj[4][4]; // Cj[s][q] = C_s[j_q], q >= s
+#pragma unroll
+        for(int sidx = 0; sidx < 4; sidx++)
+        {
+#pragma unroll
+          for(int q = sidx; q < 4; q++)
+          {
+            double v = (q < ncol) ? lb[sidx * LS + j0 + q] : 0.0;
+#pragma unroll
+            for(int t = 0; t < sidx; t++) v -= Cj[t][q] * L[sidx][t];
+            Cj[sidx][q] = v;
+          }
+          double d = Cj[sidx][sidx];
+          if(sidx < ncol && !(d > 0.0)) *bad = 1;
+          if(!(sidx < ncol && d > 0.0)) d = 1.0;
+          double r = __builtin_amdgcn_rcp(d);
+          r = r * (2.0 - d * r);
+          r = r * (2.0 - d * r);
+          inv[sidx] = (sidx < ncol) ? r : 0.0;
+#pragma unroll
+          for(int q = sidx + 1; q < 4; q++) L[q][sidx] = (q < ncol) ? Cj[sidx][q] * inv[sidx] : 0.0;
+        }
       }
-      double inv0 = __builtin_amdgcn_rcp(d0);
-      inv0 = inv0 * (2.0 - d0 * inv0);
-      inv0 = inv0 * (2.0 - d0 * inv0);
-      const double m = two ? l0[j1] * inv0 : 0.0;
-      double d1 = two ? l1[j1] - l0[j1] * m : 1.0;
-      if(!(d1 > 0.0))
-      {
-        *bad = 1;
-        d1 = 1.0;
-      }
-      double inv1 = __builtin_amdgcn_rcp(d1);
-      inv1 = inv1 * (2.0 - d1 * inv1);
-      inv1 = inv1 * (2.0 - d1 * inv1);
-      if(!two) inv1 = 0.0;
-      double ri0[NT], ci[NT], sk0[NT], sk1[NT]; // rows: raw column j0, corrected column j1; columns: the same, scaled
+      double ri[4][NT], sk[4][NT]; // per live column s: C_s at this thread's rows, C_s / d_s at its columns (zero where the update does not apply)
 #pragma unroll
       for(int a = bj; a < NT; a++)
       {
         const int i = ty + 16 * a, k = tx + 16 * a;
-        const double r0i = l0[i], r1i = l1[i], r0k = l0[k], r1k = l1[k];
-        const bool irow = (a > bj || i > j0); // strictly below the first pivot
-        ri0[a] = irow ? r0i : 0.0;
-        ci[a] = (a > bj || i > j1) ? r1i - r0i * m : 0.0; // strictly below the second pivot
-        const bool kc = kcol[a] && (a > bj || k > j0);
-        sk0[a] = kc ? r0k * inv0 : 0.0;
-        sk1[a] = (kcol[a] && (a > bj || k > j1)) ? (r1k - r0k * m) * inv1 : 0.0;
+        double ci[4], ck[4];
+#pragma unroll
+        for(int q = 0; q < 4; q++)
+        {
+          double vi = lb[q * LS + i], vk = lb[q * LS + k];
+#pragma unroll
+          for(int t = 0; t < q; t++)
+          {
+            vi -= ci[t] * L[q][t];
+            vk -= ck[t] * L[q][t];
+          }
+          // (entries above a column's pivot are never published: whatever the slot holds there is masked, here and below)
+          ci[q] = (a > bj || i > j0 + q) ? vi : 0.0;
+          ck[q] = (a > bj || k > j0 + q) ? vk : 0.0;
+          ri[q][a] = (q < ncol) ? ci[q] : 0.0;
+          sk[q][a] = (q < ncol && kcol[a]) ? ck[q] * inv[q] : 0.0;
+        }
       }
-      // (the elements of column j1 itself get only the j0 term — their sk1 is zero — and so become the corrected column)
+      // (the elements of column j_q itself get only the terms s < q — their sk[s >= q] is zero — and so become the corrected column)
 #pragma unroll
       for(int a = bj; a < NT; a++)
 #pragma unroll
-        for(int b = bj; b <= a; b++) acc[a][b] -= ri0[a] * sk0[b] + ci[a] * sk1[b];
+        for(int b = bj; b <= a; b++)
+          acc[a][b] -= (ri[0][a] * sk[0][b] + ri[1][a] * sk[1][b]) + (ri[2][a] * sk[2][b] + ri[3][a] * sk[3][b]);
     }
   }
   __syncthreads();
@@ -1680,8 +1739,8 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   double * lo = bpri + D;
   double * hi = lo + D;
   double * rowv = hi + D;
-  double * lraw = rowv + rows; // [2][2][16 NTR] published column pairs of the register-tiled factorisation
-  double * ldiag = lraw + 64 * NTR; // [4] (spare)
+  double * lraw = rowv + rows; // [2][4][16 NTR] published columns of the register-tiled factorisation (four per step)
+  double * ldiag = lraw + 128 * NTR; // [4] (spare)
   double * dinv = ldiag + 4;   // [D] reciprocal pivots for the back substitution
   int * idx = reinterpret_cast<int *>(dinv + D);
   int * state = idx + D; // 0 free, -1 at lo, +1 at hi, 2 pinned (empty box)
@@ -2803,7 +2862,7 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
     // which leaves 75 of the 157 unknowns of a 41-marker motion solve and room for its 164 Jacobian rows in two chunks
     const int m_dim = D - ((!phi_live || s->phi_locked) ? 2 * K : 0);
     const int ntr = (m_dim + 1 <= 96 || m_dim + 1 > 176) ? 6 : 11; // tiles of the register-tiled factorisation (176 < m_dim + 1: all-LDS path)
-    const size_t fixed = sizeof(double) * ((size_t)(m_dim + 1) * (m_dim + 2) / 2 + 7 * (size_t)D + 2 * (size_t)rows + 64 * (size_t)ntr + 4) + sizeof(int) * 2 * (size_t)D;
+    const size_t fixed = sizeof(double) * ((size_t)(m_dim + 1) * (m_dim + 2) / 2 + 7 * (size_t)D + 2 * (size_t)rows + 128 * (size_t)ntr + 4) + sizeof(int) * 2 * (size_t)D;
     const size_t budget = SOLVE_LDS_MAX;
     int chunk_rows = (int)((budget - fixed) / (sizeof(double) * (size_t)D));
     if(chunk_rows > rows) chunk_rows = rows;
