@@ -2343,10 +2343,15 @@ __device__ __forceinline__ void proj_finish_body(const ModelView & mv, const Tas
   {
     const int k = k_begin + threadIdx.x;
     const int face = s_face[k];
-    float tri[9], w[3], c[3];
+    float tri[9], w[3];
+    const float * qp = pts + (tb + k) * 3;
+    const float q0 = qp[0], q1 = qp[1], q2 = qp[2];
     for(int i = 0; i < 3; i++)
       for(int x = 0; x < 3; x++) tri[i * 3 + x] = verts[3 * mv.faces[face * 3 + i] + x];
-    (void)tri_sqdist_dev(verts, mv.faces, face, pts + (tb + k) * 3, c);
+    // the closest point from the triangle already in registers, through the one shared evaluation (tri_sqdist_dev would gather
+    // the face's vertices a second time: two more dependent round trips in a kernel that is nothing but round trips)
+    const float4 cp = tri_sqdist_vals(tri[0], tri[1], tri[2], tri[3], tri[4], tri[5], tri[6], tri[7], tri[8], q0, q1, q2);
+    const float c[3] = {cp.y, cp.z, cp.w};
     triangle_weights_dev(c, tri, w); // calcVertexWeights(closest point), phi_ == 0 (:997-998)
     st_agent(&ta.face[tb + k], face); // (read by the evaluation on the other stream: see wg_signal)
     for(int i = 0; i < 3; i++) st_agent(&ta.vw[(tb + k) * 3 + i], w[i]);
