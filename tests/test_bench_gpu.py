@@ -29,6 +29,8 @@ def test_bench_prints_one_contract_line():
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert d["ik"]["value"] > 0 and d["mocap"]["finite"] and d["vposer_ik"]["value"] > 0
     # burst-proof figure (a long run after the contract's region) and the operand-exact (bf16x3) figure in the same line
+    cold = d["cold_start"]
+    assert cold["ms_per_step"] > 0 and cold["value"] > 1e4
     sus = d["sustained"]
     assert sus["launches"] >= 2000 and sus["ms_per_step"] > 0 and sus["value"] > 1e4
     ex = d["exact_form"]
