@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; O=$ROOT/gpurun_out/$TAG; mkdir -p $O; cd $ROOT
 bash tools/collect_profiles.sh $TAG > $O/collect.log 2>&1; tail -12 $O/collect.log
 bash tools/ik_timeline.sh > $O/ik_timeline.txt 2>&1
 bash tools/vposer_timeline.sh > $O/vposer_timeline.txt 2>&1
-bash tools/r3_mocap.sh > $O/mocap_full_sequence.txt 2>&1
+bash tools/mocap_full_profile.sh > $O/mocap_full_sequence.txt 2>&1
 bash tools/mocap_timeline.sh 64 > $O/mocap_timeline.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 SMPLPP_ROCTX=1 rocprofv3 --marker-trace --kernel-trace --output-format csv -d $O/mk -- python3 $ROOT/tools/quick_ik.py > $O/mk.log 2>&1

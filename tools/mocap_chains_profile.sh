@@ -1,5 +1,5 @@
 #!/bin/bash
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; O=$ROOT/gpurun_out/r3mocap8; rm -rf $O; mkdir -p $O; cd $ROOT
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; O=$ROOT/gpurun_out/mocap_chains; rm -rf $O; mkdir -p $O; cd $ROOT
 R=${1:-8}
 timeout -k 10 300 python tools/mocap_full.py $R 800 2>/dev/null | tail -1 | tee $O/plain.txt
 cd /tmp && export TMPDIR=/tmp

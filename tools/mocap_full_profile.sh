@@ -1,5 +1,5 @@
 #!/bin/bash
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; O=$ROOT/gpurun_out/r3mocap; rm -rf $O; mkdir -p $O; cd $ROOT
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; O=$ROOT/gpurun_out/mocap_full; rm -rf $O; mkdir -p $O; cd $ROOT
 timeout -k 10 300 python tools/mocap_full.py 64 2>/dev/null | tail -1 | tee $O/plain.txt
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tr -- python3 $ROOT/tools/mocap_full.py 64 > $O/traced.txt 2> $O/err.txt

@@ -1,5 +1,5 @@
 #!/bin/bash
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; O=$ROOT/gpurun_out/r3mocap; mkdir -p $O; cd $ROOT
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; O=$ROOT/gpurun_out/mocap_full; mkdir -p $O; cd $ROOT
 SMPLPP_DEBUG_SYNC=1 timeout -k 10 600 python tools/mocap_full.py 64 > $O/dbg_out.txt 2> $O/dbg_err.txt
 tail -1 $O/dbg_out.txt
 grep "project lists" $O/dbg_err.txt > $O/lists.txt
