@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev aid: A/B of library variants on one box, alternating, past the clock ramp. usage: bash tools/r3_ab.sh <variant.so> [reps]
+# dev aid: A/B of library variants on one box, alternating, past the clock ramp. usage: bash tools/ab_fk.sh <variant.so> [reps]
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT; V=$1; R=${2:-3}
 timeout -k 10 300 python -m pytest tests/test_fk_gpu.py -x -q 2>&1 | tail -2
 for i in $(seq $R); do
