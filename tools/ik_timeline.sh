@@ -3,7 +3,8 @@
 # usage (GPU box, repo root): bash tools/ik_timeline.sh
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/iktl; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $OUT/bench.json 2> $OUT/err.txt
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/quick_ik.py > $OUT/out.txt 2> $OUT/err.txt
+cat $OUT/out.txt
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/*/*kernel_trace.csv")[0]
