@@ -1,10 +1,11 @@
 // SMPL::launch (/root/reference/src/SMPL.cpp:671-737) as two gfx950 kernels.
 //
-//  pose_kernel   one 64-lane wavefront per frame: Rodrigues x24 (src/BlendShape.cpp:803-844), pose coefficients
+//  pose_kernel   one workgroup (four wavefronts) per frame: Rodrigues x24 (src/BlendShape.cpp:803-844), pose coefficients
 //                vec(R)[9:] - vec(I)[9:] (:865-895), joints = J0 + JS.beta (src/JointRegression.cpp:583-598, folded),
 //                FK chain over the kinematic tree and relative transforms (src/WorldTransformation.cpp:421-677).
-//                Writes the K-major A operand AT[220][ldA] and G'[n][24][3x4].
-//  skin_kernel   fused: rest = T + S.beta + P.c as ONE fp32 GEMM [frames x 220] x [220 x 3V] on
+//                Writes the A operand of the fused kernel of the model's form (A2h + G2h fragments for skin_h.hip, A3 for
+//                skin_b.hip, the K-major AT[220][ldA] for the fp32 forms) and G'[n][24][3x4] in fp32.
+//  skin_kernel   (the FIRST form of the fused kernel, SMPLPP_SKIN=v; the default is skin_kernel_h, skin_h.hip) fused: rest = T + S.beta + P.c as ONE fp32 GEMM [frames x 220] x [220 x 3V] on
 //                v_mfma_f32_32x32x2_f32 (exact fp32; bf16/fp16 operands would break the 1e-5 m bound), then in the
 //                epilogue, on the accumulator registers, linear blend skinning with the frame tile's G' staged in LDS
 //                (src/JointRegression.cpp:551-565, src/LinearBlendSkinning.cpp:445-553).  No [n,V,4,4] intermediate,
@@ -41,11 +42,16 @@ __device__ __forceinline__ void block_sync_lds()
 
 // grid = n frames, block = 256 (four wavefronts per frame: the kernel is a chain of dependent latencies, so the work of a
 // frame is spread over as many lanes as it has independent pieces).
-//   phase 0  theta/beta in, Rodrigues x24
-//   phase 1  220 pose/shape coefficients (one per thread) -> AT (fp32 forms) / LDS (bf16x3 form); 72 joint coordinates
-//   phase 2  wavefront 0..1: the 84 bf16x3 fragment chunks of A3; wavefront 3: the kinematic chain, one tree LEVEL at a
-//            time (lane = (joint of the level, entry of its 3x4 transform); SMPL: 9 levels instead of 23 sequential joints)
-//   phase 3  relative transforms G', 4x4 outputs
+// Trees with at most CT_LEV levels of at most 5 joints (SMPL: 9 levels; ctab != null) take the fast path:
+//   phase 0  theta in, Rodrigues x24 (threads 0..23) BESIDE the 72 joint coordinates (threads 64..135: they need beta and the
+//            folded regressor only); the chain wavefront fetches its table row
+//   barrier 1
+//   phase 1  220 pose/shape coefficients (threads 0..191) BESIDE the kinematic chain (wavefront 3): one tree LEVEL at a time,
+//            lane = (joint of the level, entry of its 3x4 transform), operands from host-built LDS addresses in one batch,
+//            the parent's row by ds_bpermute from the lanes that computed it
+//   barrier 2
+//   phase 2  the fragment chunks of the A operand (A2h / A3), relative transforms G', G2h fragments, 4x4 outputs
+// Other trees: joints in phase 1, the chain in phase 2 with its look-ups in LDS, a third barrier, then the outputs.
 // levels: [nlev + 1] offsets into lvl_joint, then the joints sorted by depth (built at model creation).
 #ifdef POSE_STAMP
 __device__ unsigned long long g_pose_stamps[16];
