@@ -1732,7 +1732,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
                                                        int K, int theta_dim, int beta_dim, int phi_live, int enable_qp, int use_prior,
                                                        int chunk_rows, const int * __restrict__ skip, double * __restrict__ e2_out,
                                                        int * __restrict__ status, int * __restrict__ sticky, double * __restrict__ x_out, int dbg_stop, int m_dim,
-                                                       float * __restrict__ theta25)
+                                                       float * __restrict__ theta25, float * __restrict__ theta_copy)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int64_t f = blockIdx.x;
@@ -1787,6 +1787,8 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     if(tid == 0 && e2_out) e2_out[f] = 0.0;
     if(pts)
       for(int k = tid; k < K * 3; k += 256) pts[tb * 3 + k] = ta.apos[tb * 3 + k];
+    if(theta_copy)
+      for(int i = tid; i < theta_dim; i += 256) theta_copy[f * theta_dim + i] = theta[f * theta_dim + i];
     return;
   }
   __builtin_amdgcn_s_setprio(3); // a latency chain: its few wavefronts issue ahead of the face scan that shares the CU
@@ -2151,14 +2153,18 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   const bool ok = !s_bad;
   // config update (node.cpp:945-968), fp32
   for(int i = tid; i < theta_dim; i += 256)
+  {
+    float t = theta[f * theta_dim + i];
     if(ok)
     {
-      const float t = theta[f * theta_dim + i] + (float)xfull[i];
+      t = t + (float)xfull[i];
       theta[f * theta_dim + i] = t;
       // VPoser latent layout: the entries that pass through to theta25 (node.cpp:763-771) are kept current here
       if(theta25 && i < 6) theta25[f * TD75 + i] = t;
       if(theta25 && i >= 38) theta25[f * TD75 + 69 + (i - 38)] = t;
     }
+    if(theta_copy) theta_copy[f * theta_dim + i] = t; // the sequence driver's record of this frame's result (last iteration of a frame)
+  }
   for(int i = tid; i < beta_dim; i += 256)
     if(ok) beta[f * NB + i] += (float)xfull[theta_dim + 2 * K + i];
   for(int i = tid; pts && i < K * 3; i += 256) // p_k = actualPos_k + tangents_k . x_phi_k (:956-959); null: x_phi = 0 for all
@@ -2400,8 +2406,22 @@ __global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArra
                                                            const int * __restrict__ skip, int * __restrict__ list_cnt,
                                                            const float * __restrict__ list_d, const int * __restrict__ list_f,
                                                            int * __restrict__ dbg, int tsplit, unsigned * __restrict__ sig_flag,
-                                                           unsigned * __restrict__ sig_counter, unsigned sig_tick)
+                                                           unsigned * __restrict__ sig_counter, unsigned sig_tick,
+                                                           const float * __restrict__ next_tpos, const uint8_t * __restrict__ next_valid)
 {
+  if(next_tpos) // the sequence driver's frame switch (SeqHook): the evaluation that read the old targets is over, the next one waits for this kernel
+  {
+    const int64_t f = blockIdx.x / tsplit;
+    const int part = (int)(blockIdx.x % tsplit), per_part = (K + tsplit - 1) / tsplit;
+    const int k = part * per_part + (int)threadIdx.x;
+    if((int)threadIdx.x < per_part && k < K)
+    {
+      const int64_t i = f * K + k;
+      const bool v = next_valid[i] != 0;
+      ta.posw[i] = v ? 1.0f : 0.0f;
+      for(int x = 0; x < 3; x++) ta.tpos[i * 3 + x] = v ? next_tpos[i * 3 + x] : 0.0f;
+    }
+  }
   proj_finish_body(mv, ta, verts_all, pts, F, K, skip, list_cnt, list_d, list_f, dbg, tsplit);
   wg_signal(sig_flag, sig_counter, sig_tick);
 }
@@ -2859,7 +2879,18 @@ extern "C" int smplpp_ik_eval(smplpp_ik * s, int optimize_beta, double * e, doub
 
 // `iters` iterations enqueued on st (+ the solver's side stream); leaves the last re-projection pending on the side
 // stream (s->side_pending) — the caller joins (ik_join) before anything else may touch the task arrays or the mesh.
-static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optimize_beta_from, int64_t min_valid, hipStream_t st)
+// What the sequence driver wants done around the LAST of the iterations: the configuration after it recorded (by the solve
+// kernel itself) and the NEXT frame's targets put in place (by the re-projection's finish kernel, wherever it runs: the
+// evaluation that read the old targets is over by then, nothing else reads them, and the next evaluation waits for it).
+struct SeqHook
+{
+  float * theta_record = nullptr;        // [n][theta_dim]
+  const float * next_tpos = nullptr;     // [n][K][3]
+  const uint8_t * next_valid = nullptr;  // [n][K]
+};
+
+static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optimize_beta_from, int64_t min_valid, hipStream_t st,
+                              const SeqHook * hook = nullptr)
 {
   int rc = SMPLPP_OK;
   smplpp_model * m = s->m;
@@ -2913,12 +2944,14 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
     // theta is never bound, so the free set keeps at least theta_dim unknowns: with fewer residual rows than that every pass
     // (also every active-set pass of the QP) takes the dual form
     const bool dual_only = rows < s->theta_dim && rows <= 63 && chunk_rows >= rows && D <= 192 && dbg_stop != 9;
+    const bool last = hook && it == iters - 1;
+    float * theta_record = last ? hook->theta_record : nullptr;
 #define SOLVE_(DO) ik_solve_kernel<DO><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
     s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
-    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr)
+    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr, theta_record)
 #define SOLVE11_() ik_solve_kernel<false, 11><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
     s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
-    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr)
+    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr, theta_record)
     {
       TraceRange tr_solve("solve IK"); // node.cpp:907-943
       if(dual_only)
@@ -2967,7 +3000,8 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
                             (beside && !join_flag) ? s->ev_join : nullptr, 0,
                             view_of(m), s->ta, (const float *)s->verts, qpts, m->F, K, (const int *)s->skip, s->list_cnt, s->list_d,
                             s->list_f, dbg ? dbg_buf : (int *)nullptr, fsplit, join_flag ? s->sig + 32 : (unsigned *)nullptr,
-                            join_flag ? s->sig + 48 : (unsigned *)nullptr, s->tick_join);
+                            join_flag ? s->sig + 48 : (unsigned *)nullptr, s->tick_join, last ? hook->next_tpos : (const float *)nullptr,
+                            last ? hook->next_valid : (const uint8_t *)nullptr);
       HIP_TRY(hipGetLastError());
       if(beside) s->side_pending = true;
       if(dbg)
@@ -3069,13 +3103,27 @@ extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * 
   HIP_TRY(hipMemsetAsync(s->sticky, 0, sizeof(int) * s->n, st));
   const int64_t cnt = nk > ntheta ? nk : ntheta;
   const dim3 grid((unsigned)((cnt + 255) / 256));
-  for(int64_t t = 0; t <= T; t++)
+  // frame 0's targets go in here; every later switch and every frame's record ride on the iterations themselves (SeqHook): no
+  // kernel of its own between one frame's solve and the next frame's pose step
+  ik_seq_frame_kernel<<<grid, 256, 0, st>>>(tp.d, vl.d, s->ta.tpos, s->ta.posw, nk, nullptr, nullptr, 0);
+  HIP_TRY(hipGetLastError());
+  for(int64_t t = 0; t < T; t++)
   {
-    ik_seq_frame_kernel<<<grid, 256, 0, st>>>(t < T ? tp.d + t * nk * 3 : nullptr, t < T ? vl.d + t * nk : nullptr, s->ta.tpos, s->ta.posw, nk,
-                                              s->theta, t > 0 ? th.d + (t - 1) * ntheta : nullptr, ntheta);
-    HIP_TRY(hipGetLastError());
-    if(t == T) break;
-    rc = ik_iterate_enqueue(s, t == 0 ? warmup_iters : iters_per_frame, enable_qp, -1, min_valid, st);
+    const int iters = t == 0 ? warmup_iters : iters_per_frame;
+    SeqHook hook;
+    hook.theta_record = th.d + t * ntheta;
+    if(t + 1 < T)
+    {
+      hook.next_tpos = tp.d + (t + 1) * nk * 3;
+      hook.next_valid = vl.d + (t + 1) * nk;
+    }
+    if(iters > 0)
+      rc = ik_iterate_enqueue(s, iters, enable_qp, -1, min_valid, st, &hook);
+    else // (no iteration to carry the hook)
+    {
+      ik_seq_frame_kernel<<<grid, 256, 0, st>>>(hook.next_tpos, hook.next_valid, s->ta.tpos, s->ta.posw, nk, s->theta, hook.theta_record, ntheta);
+      HIP_TRY(hipGetLastError());
+    }
     if(rc) break;
   }
   const int jrc = ik_join(s, st);
