@@ -119,6 +119,13 @@ inline hipError_t lds_opt_in(PerDeviceOnce & o, int device, const void * fn, int
   if(o.done[device & 63]) return hipSuccess;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if(e == hipSuccess) o.done[device & 63] = true;
+  else if(getenv("SMPLPP_DEBUG_LDS"))
+  {
+    hipFuncAttributes a;
+    hipError_t e2 = hipFuncGetAttributes(&a, fn);
+    fprintf(stderr, "[smplpp dbg] lds_opt_in(%d bytes) failed: %s; attributes (%s): static %zu, max dynamic %d, regs %d, max threads %d\n", bytes,
+            hipGetErrorString(e), hipGetErrorString(e2), a.sharedSizeBytes, a.maxDynamicSharedSizeBytes, a.numRegs, a.maxThreadsPerBlock);
+  }
   return e;
 }
 inline int device_cus(int device) // compute units of a device (cached per device)

@@ -215,16 +215,24 @@ constexpr int L_DR = L_T + NJ * 3;             // [72][9]
 // ancestor per depth: the table keeps, per joint, three columns per DEPTH (column slot 3 depth(joint(c)) + axis(c)) instead of
 // all 72 — 41 KB instead of 83 KB of LDS, which is what lets three tasks with a normal term share the ring buffers below.
 constexpr int DMAX = TREE_DMAX;                     // deepest kinematic tree served (SMPL: 9 levels); smplpp_ik_create checks
-constexpr int CS = 3 * DMAX;                   // column slots per joint
 constexpr int L_DAB = L_DR + 72 * 9;           // [24][CS][3][4]  per (joint, column slot): rows [dA_r | db_r] (one 16-byte LDS access per row)
-constexpr int L_DBB = L_DAB + NJ * 12 * CS;    // [24*3][10]
-constexpr int RCAP = 64;                        // ring vertices a task group can hold (one task: at most MAXRING = 40)
-constexpr int L_RV = L_DBB + NJ * 3 * NB;      // [RCAP][RVS]
 constexpr int RVS = 28;                         // floats per ring vertex: rest 3 | Ablend 9 | wsum 1 | posed 3 | weights 4 | joints 4 | their ancestor masks 4
-constexpr int L_DP = L_RV + RCAP * RVS;        // [RCAP][3][NQ]
-constexpr int NGN = 3;                          // tasks with a normal term / offset per group (their rings share L_RV / L_DP)
-constexpr int L_VN = L_DP + RCAP * 3 * NQ;     // per such task: [3][3] vertex normals + [3] their weighted sum
-constexpr int L_END = L_VN + 12 * NGN;
+// The rest of the plan depends on three sizes the kernel is instantiated for (EvalPlan below):
+//   DM   tree levels served: CS = 3 DM column slots per joint in the chain-derivative table
+//   RC   ring vertices a task group can hold (one task: at most MAXRING = 40; six tasks on a valence-6 mesh: 72)
+//   NG   tasks with a normal term / offset per group (their rings share the ring buffers)
+// <9, 76, 6> (trees of SMPL's depth: a 6-target solve with normal terms is ONE group, 158 KB of the CU's 160) and
+// <12, 64, 3> (deeper trees: the table takes 10 KB more).
+template<int DM, int RC, int NG>
+struct EvalPlan
+{
+  static constexpr int CS = 3 * DM;
+  static constexpr int L_DBB = L_DAB + NJ * 12 * CS; // [24*3][10]
+  static constexpr int L_RV = L_DBB + NJ * 3 * NB;   // [RC][RVS]
+  static constexpr int L_DP = L_RV + RC * RVS;       // [RC][3][NQ]
+  static constexpr int L_VN = L_DP + RC * 3 * NQ;    // per normal task of the group: [3][3] vertex normals + [3] their weighted sum
+  static constexpr int L_END = L_VN + 12 * NG;
+};
 constexpr int L_ANC_BYTES = NJ * 4;            // int anc[24] (ancestor bit masks; depth = popcount - 1) after the float region
 
 // workgroup barrier that orders LDS traffic only: global stores issued before it may still be in flight (__syncthreads
@@ -278,6 +286,7 @@ __device__ inline void wg_signal(unsigned * __restrict__ flag, unsigned * __rest
   }
 }
 
+template<int DMAX, int RCAP, int NGN>
 __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArrays & ta, const float * __restrict__ theta25,
                                              const float * __restrict__ verts_all, const float * __restrict__ rest_all,
                                              const float * __restrict__ Gp, const float * __restrict__ joints,
@@ -287,6 +296,8 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
                                              int * __restrict__ skip, int dbg_stop, int tsplit, const int32_t * __restrict__ roles,
                                              const float * __restrict__ vjac, double * __restrict__ Jl_out)
 {
+  typedef EvalPlan<DMAX, RCAP, NGN> Plan;
+  constexpr int CS = Plan::CS, L_DBB = Plan::L_DBB, L_RV = Plan::L_RV, L_DP = Plan::L_DP, L_VN = Plan::L_VN, L_END = Plan::L_END;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_tree[TREE_SIZE];
   __shared__ int s_par[NJ];
@@ -646,9 +657,10 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   __shared__ int s_rvert[RCAP];         // ring slot -> vertex
   __shared__ uint8_t s_map[NGN][3 * MAXADJ * 3]; // (vertex of the face, adjacent face, corner) -> slot in the task's ring, per normal task
   __shared__ int s_cnt[NGN][3];         // adjacent-face count of the face's three vertices
-  __shared__ float s_nrm[NGN][NQ * 3 * 6]; // per (column, triangle vertex): vertex normal (3) and its derivative (3)
+  __shared__ float s_dvn[NGN][NQ * 3 * 3]; // per (column, triangle vertex): derivative of the vertex normal (the normal itself, the same for every column: L_VN)
   __shared__ __attribute__((aligned(16))) float s_geo[NGN][3 * MAXADJ][12]; // per adjacent face of a triangle vertex: unit normal, |cross|, edges e1, e2
-  static_assert(EVAL_NT >= 64 + NGN * 128 + NGN * 4, "B1 hands the map / count loads to thread ranges beyond the ring threads");
+  constexpr int MAPN = 3 * MAXADJ * 3; // ring-slot map entries per normal task
+  static_assert(RCAP + NGN * 3 <= 96 && 96 + NGN * MAPN <= EVAL_NT, "B1 hands the count / map loads to thread ranges beyond the ring threads");
   for(int g = 0; g < s_ng; g++)
   {
     // group [k_lo, k_hi) from the list thread 0 made behind the ring-size scan (with 12 wavefronts, bounds every thread
@@ -700,15 +712,15 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       rv[14] = verts[v * 3 + 1];
       rv[15] = verts[v * 3 + 2];
     }
-    else if(tid >= 64 && tid < 64 + NGN * 128) // ring-slot maps of the group's normal tasks
+    else if(tid >= 96 && tid < 96 + NGN * MAPN) // ring-slot maps of the group's normal tasks
     {
-      const int gi = (tid - 64) >> 7, j = (tid - 64) & 127;
-      if(gi < ngn && j < 3 * MAXADJ * 3) s_map[gi][j] = mv.faceMap[(int64_t)ta.face[tb + k_lo + gi] * (3 * MAXADJ * 3) + j];
+      const int gi = (tid - 96) / MAPN, j = (tid - 96) % MAPN;
+      if(gi < ngn) s_map[gi][j] = mv.faceMap[(int64_t)ta.face[tb + k_lo + gi] * MAPN + j];
     }
-    else if(tid >= 64 + NGN * 128 && tid < 64 + NGN * 128 + NGN * 4)
+    else if(tid >= RCAP && tid < RCAP + NGN * 3)
     {
-      const int gi = (tid - 64 - NGN * 128) >> 2, j = (tid - 64 - NGN * 128) & 3;
-      if(gi < ngn && j < 3)
+      const int gi = (tid - RCAP) / 3, j = (tid - RCAP) % 3;
+      if(gi < ngn)
       {
         const int u = mv.faces[ta.face[tb + k_lo + gi] * 3 + j];
         s_cnt[gi][j] = mv.adjOff[u + 1] - mv.adjOff[u];
@@ -887,8 +899,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         for(int x = 0; x < 3; x++)
         {
           const float vnx = mu[x] / mn;
-          s_nrm[gi][(q * 3 + i) * 6 + x] = vnx;
-          s_nrm[gi][(q * 3 + i) * 6 + 3 + x] = dvn[x];
+          s_dvn[gi][(q * 3 + i) * 3 + x] = dvn[x];
           if(q == 0) lds[L_VN + gi * 12 + i * 3 + x] = vnx;
         }
       }
@@ -912,8 +923,8 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         for(int i = 0; i < 3; i++)
           for(int x = 0; x < 3; x++)
           {
-            msum[x] += wv[i] * s_nrm[k - k_lo][(q * 3 + i) * 6 + x];
-            dm[x] += wv[i] * s_nrm[k - k_lo][(q * 3 + i) * 6 + 3 + x];
+            msum[x] += wv[i] * lds[L_VN + (k - k_lo) * 12 + i * 3 + x];
+            dm[x] += wv[i] * s_dvn[k - k_lo][(q * 3 + i) * 3 + x];
           }
         dnormalize_dev(msum, dm, dn);
         if(q == 0)
@@ -1044,6 +1055,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   EVAL_STAMP(7);
 }
 
+template<int DMAX, int RCAP, int NGN>
 __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ theta25,
                                                       const float * __restrict__ verts_all, const float * __restrict__ rest_all,
                                                       const float * __restrict__ Gp, const float * __restrict__ joints,
@@ -1054,8 +1066,8 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
                                                       unsigned * __restrict__ sig_flag, unsigned * __restrict__ sig_counter, unsigned sig_tick,
                                                       const float * __restrict__ vjac, double * __restrict__ Jl_out)
 {
-  ik_eval_body(mv, ta, theta25, verts_all, rest_all, Gp, joints, poserot, K, optimize_beta, phi_live, min_valid, pos804, e_out, J_out, skip,
-               dbg_stop, tsplit, roles, vjac, Jl_out);
+  ik_eval_body<DMAX, RCAP, NGN>(mv, ta, theta25, verts_all, rest_all, Gp, joints, poserot, K, optimize_beta, phi_live, min_valid, pos804, e_out,
+                                J_out, skip, dbg_stop, tsplit, roles, vjac, Jl_out);
   wg_signal(sig_flag, sig_counter, sig_tick); // (every exit of the body comes through here: a waiting stream is never left behind)
 }
 
@@ -2840,21 +2852,28 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
       HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
     s->side_pending = false;
   }
-  const size_t shmem = sizeof(float) * L_END + L_ANC_BYTES;
-  static PerDeviceOnce once_eval;
-  HIP_TRY(lds_opt_in(once_eval, m->device, reinterpret_cast<const void *>(&ik_eval_kernel), (int)shmem));
-  int tsplit = (n < 256) ? (int)(256 / n) : 1; // one round of workgroups (one per CU: 83 KB of LDS each)
+  const bool deep = m->nlev > 9; // (ik_eval_kernel's two instantiations: see EvalPlan)
+  const size_t shmem = sizeof(float) * (deep ? EvalPlan<DMAX, 64, 3>::L_END : EvalPlan<9, 76, 6>::L_END) + L_ANC_BYTES;
+  static PerDeviceOnce once_eval[2];
+  const void * kfn = deep ? reinterpret_cast<const void *>(&ik_eval_kernel<DMAX, 64, 3>) : reinterpret_cast<const void *>(&ik_eval_kernel<9, 76, 6>);
+  HIP_TRY(lds_opt_in(once_eval[deep ? 1 : 0], m->device, kfn, (int)shmem));
+  int tsplit = (n < 256) ? (int)(256 / n) : 1; // one round of workgroups (one per CU: its LDS is the evaluation's)
   if(tsplit > K) tsplit = K;
   if(tsplit < 1) tsplit = 1;
   const bool fork_flag = eval_done && s->use_flags; // the side stream waits for this evaluation: flag instead of the event
   if(fork_flag) s->tick_fork++;
-  hipExtLaunchKernelGGL(ik_eval_kernel, dim3((unsigned)(n * tsplit)), dim3(EVAL_NT), shmem, st, nullptr, fork_flag ? nullptr : eval_done, 0,
-                        view_of(m), s->ta, th25,
-                        (const float *)s->verts, (const float *)s->rest, (const float *)m->ws.Gp.as<float>(), (const float *)s->joints,
-                        (const float *)s->poserot, K, optimize_beta, phi_live, (int)min_valid, s->pts, s->e,
-                        s->J, s->skip, s->dbg_stop, tsplit, s->roles, fork_flag ? s->sig : (unsigned *)nullptr,
-                        fork_flag ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork, s->vp ? (const float *)s->vjac : (const float *)nullptr,
-                        s->vp ? s->Jl : (double *)nullptr);
+#define EVAL_(DM, RC, NG)                                                                                                                  \
+  hipExtLaunchKernelGGL((ik_eval_kernel<DM, RC, NG>), dim3((unsigned)(n * tsplit)), dim3(EVAL_NT), shmem, st, nullptr,                    \
+                        fork_flag ? nullptr : eval_done, 0, view_of(m), s->ta, th25, (const float *)s->verts, (const float *)s->rest,       \
+                        (const float *)m->ws.Gp.as<float>(), (const float *)s->joints, (const float *)s->poserot, K, optimize_beta,        \
+                        phi_live, (int)min_valid, s->pts, s->e, s->J, s->skip, s->dbg_stop, tsplit, s->roles,                               \
+                        fork_flag ? s->sig : (unsigned *)nullptr, fork_flag ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork,             \
+                        s->vp ? (const float *)s->vjac : (const float *)nullptr, s->vp ? s->Jl : (double *)nullptr)
+  if(deep)
+    EVAL_(DMAX, 64, 3);
+  else
+    EVAL_(9, 76, 6);
+#undef EVAL_
   HIP_TRY(hipGetLastError());
   s->have_eval = true;
   return SMPLPP_OK;

@@ -43,6 +43,20 @@ int main()
   unsigned long long h[16];
   unsigned int rep = 0;
   const int ta = 60;
+  {
+    // reference point: A -> C back to back on one stream, no wait in between
+    std::vector<double> gaps;
+    for(int r = 0; r < 40; r++)
+    {
+      hipLaunchKernelGGL(spin, dim3(256), dim3(256), 0, s0, (long long)ta * 100, d, (unsigned int *)nullptr, 0u, (unsigned int *)nullptr);
+      hipLaunchKernelGGL(spin, dim3(256), dim3(256), 0, s0, 500LL, d + 2, (unsigned int *)nullptr, 0u, (unsigned int *)nullptr);
+      CK(hipStreamSynchronize(s0));
+      CK(hipMemcpy(h, d, 128, hipMemcpyDeviceToHost));
+      if(r >= 5) gaps.push_back(((double)h[2] - (double)h[1]) / 100.0);
+    }
+    std::sort(gaps.begin(), gaps.end());
+    printf("no wait: C starts %.2f us (median; min %.2f) after A's end\n", gaps[gaps.size() / 2], gaps[0]);
+  }
   for(int tb : {5, 30, 50, 58, 62, 70})
   {
     std::vector<double> gaps;
