@@ -589,3 +589,51 @@ def test_ik_vertex_valence_limit():
             dJ = np.abs(r["J"] - J[f]).reshape(K, 4, -1)
             scale = max(1.0, np.abs(r["J"]).max())
             assert dJ[:, :3].max() < 1e-4 * scale and dJ[:, 3].max() < 6e-4 * scale, (N, f, dJ[:, 3].max(), scale)
+
+
+def test_ik_eval_deep_tree_vs_oracle(synth_model):
+    """A kinematic tree of 12 levels (SMPL has 9): the evaluation kernel runs in its second instantiation (the
+    chain-derivative table takes 12 column slots per joint and the ring buffers hold three normal tasks per pass);
+    residual and Jacobian against the oracle, position and normal rows, beta columns included."""
+    from oracle import cpu
+    from smplpp_amd import model_io
+    from smplpp_amd.ik import IkSolver
+    from smplpp_amd.smpl import SMPL
+
+    md = dict(synth_model)
+    kt = md["kinematic_tree"].copy()
+    parent = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 0, 12, 13, 14, 0, 16, 17, 18, 3, 20, 21, 22]
+    kt[0] = np.array(parent, np.int64)
+    kt[0, 0] = 4294967295  # the root's parent as the reference's model files carry it (src/WorldTransformation.cpp: never read)
+    md["kinematic_tree"] = kt
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(md)
+    o = cpu.OracleModel(md)
+    rng = np.random.default_rng(91)
+    n, K = 2, 7
+    beta, theta = model_io.synthetic_inputs(n, seed=5)
+    theta[:, 1:] *= 0.4
+    out = s.launch(beta, theta, want=("verts",))
+    ref = o.fk(beta, theta)
+    assert np.abs(out["verts"] - ref["verts"]).max() < 1e-5
+    faces = rng.integers(0, 13776, (n, K))
+    tp = rng.normal(0, 0.4, (n, K, 3)).astype(np.float32)
+    tn = rng.normal(0, 1, (n, K, 3)).astype(np.float32)
+    tn /= np.linalg.norm(tn, axis=2, keepdims=True)
+    bary = rng.dirichlet(np.ones(3), (n, K)).astype(np.float32)
+    sol = IkSolver(s, n, K)
+    sol.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, vertex_weights=bary, phi_limit=np.full((n, K), 0.04),
+                 normal_offset=np.full((n, K), 0.015), normal_task_weight=np.full((n, K), 1.0))
+    sol.setConfig(beta, theta)
+    e, J = sol.eval(optimize_beta=True)
+    for f in range(n):
+        ts = cpu.TaskSet(faces[f], tp[f], tn[f], vertex_weights=bary[f], phi_limit=np.full(K, 0.04), normal_offset=np.full(K, 0.015))
+        ts.normal_task_weight[:] = 1.0
+        r = o.ik_eval(beta[f], theta[f], ts, True)
+        de = np.abs(r["e"] - e[f]).reshape(K, 4)
+        assert de[:, :3].max() < 5e-6 and de[:, 3].max() < 1e-4
+        dJ = np.abs(r["J"] - J[f]).reshape(K, 4, -1)
+        scale = max(1.0, np.abs(r["J"]).max())
+        assert dJ[:, :3].max() < 1e-4 * scale, f
+        assert dJ[:, 3].max() < 6e-4 * scale, f
