@@ -181,10 +181,11 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
   int dbg_item = 0;
 #endif
   f32x16 acc[3], macc[2];
-  float tt[16], o0[16], o1[16];
+  float tt[3][16]; // [coordinate][accumulator row]: sum_c M[x][c] rest[c] (+ the translation entry), unscaled; the tail applies cw
   v4f areg[HB_KS][2]; // [k-step][piece]: this wavefront's 32 frames, loaded once per frame tile
-  v4f bfr[3][2];      // [coordinate][piece]: single-buffered, a fragment is re-read right behind its last MFMA
-  v4f gfr[4];         // [2 ks + piece]: likewise
+  v4f bfr[2][3][2];   // [k-step parity][coordinate][piece]: the six fragments of k-step S + 1 are read at MFMAs 2..4 of k-step S,
+                      // so that they are seven MFMAs old at the next slot's barrier (its lgkmcnt(0) then never waits) and at their first use
+  v4f gfr[2][4];      // [entry parity][2 ks + piece]: likewise, the fragments of entry E + 1 at MFMAs 0..3 of entry E
   v4f wfr[4];         // [2 ks + piece]
   v4f trb[2];         // root translations of the tail's rows in flight
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -213,22 +214,31 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
 #endif
   };
 
-  // row R of the tail of the previous item: verts = cw (M_t + cAB M_rot . acc) + root translation
-  auto tail_row = [&](auto rtag) {
+  // row R of the tail of the previous item: verts = cw (M_t + cAB M_rot . acc) + root translation, in two halves that ride in
+  // two consecutive MFMA gaps (the arithmetic, then the store): together they are ~10 vector instructions, and a gap hides six
+  v3f ovh;
+  auto tail_prep = [&](auto rtag) {
     constexpr int R = decltype(rtag)::value;
-    constexpr int ROWC = (R & 3) + 8 * (R >> 2);
     const v4f tr = trb[R & 1];
     if constexpr(R + 1 < 16) trb[(R + 1) & 1] = *reinterpret_cast<const v4f *>(trLane + ((((R + 1) & 3) + 8 * ((R + 1) >> 2)) * 16));
-    const float u = __builtin_fmaf(tt[R], cAB, macc[1][R]);
-    v3f ov = {o0[R] + tr.x, o1[R] + tr.y, __builtin_fmaf(u, prev.cw, tr.z)};
-    // write-once output: non-temporal (aux = 2); the descriptor's range check drops frames >= n and vertex-less lanes
+    const float u = __builtin_fmaf(tt[2][R], cAB, macc[1][R]);
+    ovh = v3f{__builtin_fmaf(tt[0][R], prev.cw, tr.x), __builtin_fmaf(tt[1][R], prev.cw, tr.y), __builtin_fmaf(u, prev.cw, tr.z)};
+  };
+  auto tail_store = [&](auto rtag) {
+    constexpr int R = decltype(rtag)::value;
+    constexpr int ROWC = (R & 3) + 8 * (R >> 2);
+    // write-once output; the descriptor's range check drops frames >= n and vertex-less lanes
     if constexpr(SKINH_ABL & 32)
-      asm volatile("" ::"v"(ov));
+      asm volatile("" ::"v"(ovh));
     else
-      __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsV, prev.voff, prev.sb + ROWC * frameB, SKINH_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ovh), rsV, prev.voff, prev.sb + ROWC * frameB, SKINH_STORE_AUX);
     // HAZARD (measured on gfx950, see skin_b.hip): keep one instruction between a 96-bit buffer store and the next VALU
     // write to its data registers
     asm volatile("s_nop 1");
+  };
+  auto tail_row = [&](auto rtag) {
+    tail_prep(rtag);
+    tail_store(rtag);
   };
   auto standalone_tail = [&]() {
     hstatic_for<16>([&](auto rr) {
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
     {
       h_barrier<28 + 18>(); // behind slot 0: the A loads and slots 1..6 may stay in flight
 #pragma unroll
-      for(int q = 0; q < 6; q++) bfr[q / 2][q % 2] = *reinterpret_cast<const v4f *>(imgV[0] + q * 1024);
+      for(int q = 0; q < 6; q++) bfr[0][q / 2][q % 2] = *reinterpret_cast<const v4f *>(imgV[0] + q * 1024);
     }
     if(tid < 192) *reinterpret_cast<float *>(lds + H_LDS_TR + (tid / 3) * 16 + (tid % 3) * 4) = tval;
 #if SKINH_ABL & 512
@@ -286,10 +296,12 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
   };
 
   // ---- one work item.  HT (compile time): the tail of the previous item (its last 16 stores) rides in slots 0 and 1.
-  auto do_item = [&](int i, int inext, auto ht_tag) {
+  // (ft, vg): the item's frame tile and vertex group; vgn: the vertex group of the item after it (the same group again behind the
+  // workgroup's last item: its prefetches land in images nobody reads).  All three are carried by the caller from item to
+  // item: the two divisions and the remainder by a run-time divisor that derived them here cost ~400 cycles per item
+  auto do_item = [&](int ft_in, int vg_in, int vgn_in, auto ht_tag) {
     constexpr bool HT = decltype(ht_tag)::value;
-    const int iu = __builtin_amdgcn_readfirstlane(i), nu = __builtin_amdgcn_readfirstlane(inext);
-    const int ft = iu / nvx, vg = vg0 + iu % nvx, vgn = vg0 + nu % nvx;
+    const int ft = __builtin_amdgcn_readfirstlane(ft_in), vg = __builtin_amdgcn_readfirstlane(vg_in), vgn = __builtin_amdgcn_readfirstlane(vgn_in);
     const int Bcur = vg * (HB_SLOTS * HB_IMG), Bnext = vgn * (HB_SLOTS * HB_IMG);
     const int64_t v = (int64_t)vg * 64 + wv * 32 + l31;
     cur.voff = v < V ? (int)(v * 12 + (int64_t)(4 * half) * frameB) : 0x7fffff00;
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
       hstatic_for<9>([&](auto mm) {
         constexpr int M = decltype(mm)::value, X = M / 3, Q = M % 3; // Q: 0 hi.hi, 1 Ahi.Blo, 2 Alo.Bhi
         const v4f & a = areg[S][Q == 2 ? 1 : 0];
-        const v4f & b = bfr[X][Q == 1 ? 1 : 0];
+        const v4f & b = bfr[S & 1][X][Q == 1 ? 1 : 0];
 #if SKINH_ABL & 256
         if(blockIdx.x == 0 && tid == 0 && dbg_item < 8) g_hslot_times[dbg_item * 256 + S * 9 + M] = __builtin_readcyclecounter();
 #endif
@@ -338,15 +350,20 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr_t)(lds + (PC + wave) * 1024), 16, lane * 16,
                                                    ft * HB_G_BYTES + (PC + wave) * 1024, 0, 0);
         }
-        if constexpr(HT && (M == 5 || M == 8))
+        if constexpr(HT && (M == 5 || M == 7)) // a tail row placed at MFMA 5 / 8: arithmetic behind MFMA 5 / 7 ...
           hstatic_for<16>([&](auto kk) {
             constexpr int K = decltype(kk)::value;
-            if constexpr(h_tail_slot(K) == S && h_tail_m(K) == M) tail_row(kk);
+            if constexpr(h_tail_slot(K) == S && h_tail_m(K) == (M == 5 ? 5 : 8)) tail_prep(kk);
           });
-        if constexpr(S < HB_KS - 1 && Q == 2 && !(SKINH_ABL & 16)) // operand fragments of the next k-step
+        if constexpr(HT && (M == 6 || M == 8)) // ... store behind MFMA 6 / 8
+          hstatic_for<16>([&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            if constexpr(h_tail_slot(K) == S && h_tail_m(K) == (M == 6 ? 5 : 8)) tail_store(kk);
+          });
+        if constexpr(S < HB_KS - 1 && M >= 2 && M <= 4 && !(SKINH_ABL & 16)) // operand fragments of the next k-step, into the other register set
         {
-          bfr[X][0] = *reinterpret_cast<const v4f *>(imgV[(S + 1) % H_R] + (2 * X) * 1024);
-          bfr[X][1] = *reinterpret_cast<const v4f *>(imgV[(S + 1) % H_R] + (2 * X + 1) * 1024);
+          bfr[(S + 1) & 1][M - 2][0] = *reinterpret_cast<const v4f *>(imgV[(S + 1) % H_R] + (2 * (M - 2)) * 1024);
+          bfr[(S + 1) & 1][M - 2][1] = *reinterpret_cast<const v4f *>(imgV[(S + 1) % H_R] + (2 * (M - 2) + 1) * 1024);
         }
         if constexpr(S == HB_KS - 1)
         {
@@ -356,13 +373,13 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
           if constexpr(M == 6) cur.cw = *reinterpret_cast<const float *>(lds + imgS[HB_KS % H_R] + HB_CW_OFF + (wv * 32 + l31) * 4);
           if constexpr(M == 7)
           {
-            gfr[0] = *reinterpret_cast<const v4f *>(gLane0);
-            gfr[1] = *reinterpret_cast<const v4f *>(gLane0 + 1024);
+            gfr[0][0] = *reinterpret_cast<const v4f *>(gLane0);
+            gfr[0][1] = *reinterpret_cast<const v4f *>(gLane0 + 1024);
           }
           if constexpr(M == 8)
           {
-            gfr[2] = *reinterpret_cast<const v4f *>(gLane1);
-            gfr[3] = *reinterpret_cast<const v4f *>(gLane1 + 512);
+            gfr[0][2] = *reinterpret_cast<const v4f *>(gLane1);
+            gfr[0][3] = *reinterpret_cast<const v4f *>(gLane1 + 512);
           }
         }
         HSB();
@@ -395,44 +412,34 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
           if constexpr(B == 0) macc[MPE] = zero16;
         }
         else if constexpr(B == 0)
-          macc[MPE] = mfma(gfr[GI], wfr[WI], zero16);
+          macc[MPE] = mfma(gfr[MPE][GI], wfr[WI], zero16);
         else
-          macc[MPE] = mfma(gfr[GI], wfr[WI], macc[MPE]);
+          macc[MPE] = mfma(gfr[MPE][GI], wfr[WI], macc[MPE]);
         HSB();
         if constexpr(E == 0 && B == 0) h_barrier<h_barrier_vmcnt(HB_KS, HT, WANT_REST)>(); // slot 14: publishes slot 0 of the next item
         if constexpr(E == 0 && B >= 1 && B <= 3) dma(std::integral_constant<int, B - 1>{}, Bnext, HB_KS + 7 - HB_SLOTS, imgS[HB_KS % H_R]);
         if constexpr(E == 1) // operand fragments of the next item's first k-step (image (14 + 1) % 7)
         {
-          bfr[B / 2][B % 2] = *reinterpret_cast<const v4f *>(imgV[(HB_KS + 1) % H_R] + B * 1024);
-          if constexpr(B == 4) bfr[2][1] = *reinterpret_cast<const v4f *>(imgV[(HB_KS + 1) % H_R] + 5 * 1024);
+          bfr[0][B / 2][B % 2] = *reinterpret_cast<const v4f *>(imgV[(HB_KS + 1) % H_R] + B * 1024);
+          if constexpr(B == 4) bfr[0][2][1] = *reinterpret_cast<const v4f *>(imgV[(HB_KS + 1) % H_R] + 5 * 1024);
         }
-        if constexpr(E < 11 && B >= 1 && !(SKINH_ABL & (8 | 16))) // G' fragments of the next entry, each right behind its last MFMA of this one
+        if constexpr(E < 11 && B <= 3 && !(SKINH_ABL & (8 | 16))) // G' fragments of the next entry, in the order of their first use
         {
-          constexpr int I = B == 1 ? 0 : (B == 2 ? 2 : (B == 3 ? 1 : 3));
-          gfr[I] = *reinterpret_cast<const v4f *>((I < 2 ? gLane0 + I * 1024 : gLane1 + (I - 2) * 512) + (E + 1) * 3072);
+          constexpr int I = B == 0 ? 0 : (B == 1 ? 2 : (B == 2 ? 1 : 3));
+          gfr[MPE ^ 1][I] = *reinterpret_cast<const v4f *>((I < 2 ? gLane0 + I * 1024 : gLane1 + (I - 2) * 512) + (E + 1) * 3072);
         }
         if constexpr(E == 11 && B == 4) // root translation of the tail's first row
           trb[0] = *reinterpret_cast<const v4f *>(trLane);
-        if constexpr(E >= 1 && B >= 2 && !(SKINH_ABL & 8)) // entry F = E - 1 = (XF, CF): rows 0..5, 6..10, 11..15
-        {
-          constexpr int F = E - 1, CF = F % 4, MP = F & 1;
-          constexpr int R0 = B == 2 ? 0 : (B == 3 ? 6 : 11), R1 = B == 2 ? 6 : (B == 3 ? 11 : 16);
+        if constexpr(E >= 1 && B >= 1 && !(SKINH_ABL & 8)) // entry F = E - 1 = (XF, CF): four rows behind each of MFMAs 1..4 (its last
+        {                                                  // MFMA, issued one gap ago, has retired by then; four VALU fit a gap)
+          constexpr int F = E - 1, XF = F / 4, CF = F % 4, MP = F & 1;
 #pragma unroll
-          for(int r = R0; r < R1; r++)
+          for(int r = 4 * (B - 1); r < 4 * B; r++)
           {
-            if constexpr(CF == 0) tt[r] = macc[MP][r] * acc[0][r];
-            if constexpr(CF == 1) tt[r] = __builtin_fmaf(macc[MP][r], acc[1][r], tt[r]);
-            if constexpr(CF == 2) tt[r] = __builtin_fmaf(macc[MP][r], acc[2][r], tt[r]);
-            if constexpr(CF == 3) tt[r] = __builtin_fmaf(tt[r], cAB, macc[MP][r]);
-          }
-        }
-        if constexpr((E == 5 || E == 9) && B < 2) // coordinate (E - 5) / 4 is complete (entry E - 2 was its translation entry)
-        {
-#pragma unroll
-          for(int r = 8 * B; r < 8 * B + 8; r++)
-          {
-            if constexpr(E == 5) o0[r] = tt[r] * cur.cw;
-            if constexpr(E == 9) o1[r] = tt[r] * cur.cw;
+            if constexpr(CF == 0) tt[XF][r] = macc[MP][r] * acc[0][r];
+            if constexpr(CF == 1) tt[XF][r] = __builtin_fmaf(macc[MP][r], acc[1][r], tt[XF][r]);
+            if constexpr(CF == 2) tt[XF][r] = __builtin_fmaf(macc[MP][r], acc[2][r], tt[XF][r]);
+            if constexpr(CF == 3) tt[XF][r] = __builtin_fmaf(tt[XF][r], cAB, macc[MP][r]);
           }
         }
         if constexpr(WANT_REST && E >= 2 && E <= 9 && B < 2)
@@ -477,8 +484,16 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
     else
       load_frame_tile(ft, std::true_type{});
     // (later items find the fragments of their first k-step read by the blend phase of the item before)
-    do_item(i, i + 1 < i1 ? i + 1 : i, std::false_type{});
-    for(int k = i + 1; k < iend; k++) do_item(k, k + 1 < i1 ? k + 1 : k, std::true_type{});
+    // item k of the run: vertex group vgk; the item after it: the next group, the XCD's first one when the frame tile ends
+    // there, the same one when the workgroup's items end there
+    int vgk = vg0 + (i - ft * nvx);
+    auto next_vg = [&](int k, int vgc) { return k + 1 < i1 ? (vgc + 1 < vg1 ? vgc + 1 : vg0) : vgc; };
+    do_item(ft, vgk, next_vg(i, vgk), std::false_type{});
+    for(int k = i + 1; k < iend; k++)
+    {
+      vgk++;
+      do_item(ft, vgk, next_vg(k, vgk), std::true_type{});
+    }
     i = iend;
   }
   standalone_tail();
