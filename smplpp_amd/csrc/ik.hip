@@ -749,13 +749,24 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         const int jc = g - 1;
         const int cs0 = 3 * (__popc(sAnc[jc]) - 1), jbit = 1 << jc;
         const bool wlds = mv.maxw <= 4;
-        float acc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}; // [axis][row]
-        for(int m = 0; m < mv.maxw; m++)
+        // the 27 pose-corrective coefficients of (vertex, joint) are requested FIRST: their round trip (the item loop makes three
+        // of them, one per pass) then runs beside the chain term below, which only reads LDS
+        float Pc[3][9];
+        if(jc >= 1)
         {
-          const float wm = wlds ? rv[16 + m] : mv.wVal[(int64_t)v * mv.maxw + m];
-          if(wm == 0.0f) continue;
-          const int i = wlds ? __float_as_int(rv[20 + m]) : (int)mv.wIdx[(int64_t)v * mv.maxw + m];
-          if(!((wlds ? __float_as_int(rv[24 + m]) : sAnc[i]) & jbit)) continue; // joint jc does not move joint i: the term is exactly zero
+#pragma unroll
+          for(int x = 0; x < 3; x++)
+          {
+            const float * Pv = mv.Pvm + ((int64_t)v * 3 + x) * NP + 9 * (jc - 1);
+#pragma unroll
+            for(int e = 0; e < 9; e++) Pc[x][e] = Pv[e];
+          }
+        }
+        float acc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}; // [axis][row]
+        // (two loops, not one with `wlds ? LDS : HBM` operands: a pointer that may be either compiles to flat loads, each
+        // followed by a wait for EVERY outstanding load — the 27 requested above included)
+        const float r0 = rv[0], r1 = rv[1], r2 = rv[2];
+        auto chain_term = [&](float wm, int i) {
           const float4 * d = reinterpret_cast<const float4 *>(lds + L_DAB + (i * CS + cs0) * 12);
 #pragma unroll
           for(int a = 0; a < 3; a++)
@@ -763,26 +774,40 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
             for(int r = 0; r < 3; r++)
             {
               const float4 dr4 = d[a * 3 + r];
-              acc[a][r] += wm * (((dr4.x * rv[0] + dr4.y * rv[1]) + dr4.z * rv[2]) + dr4.w);
+              acc[a][r] += wm * (((dr4.x * r0 + dr4.y * r1) + dr4.z * r2) + dr4.w);
             }
+        };
+        if(wlds)
+        {
+#pragma unroll
+          for(int m = 0; m < 4; m++)
+          {
+            const float wm = rv[16 + m];
+            // joint jc moves joint i only when it is its ancestor (or i itself): otherwise the term is exactly zero
+            if(wm != 0.0f && (__float_as_int(rv[24 + m]) & jbit)) chain_term(wm, __float_as_int(rv[20 + m]));
+          }
         }
+        else
+          for(int m = 0; m < mv.maxw; m++)
+          {
+            const float wm = mv.wVal[(int64_t)v * mv.maxw + m];
+            if(wm == 0.0f) continue;
+            const int i = (int)mv.wIdx[(int64_t)v * mv.maxw + m];
+            if(sAnc[i] & jbit) chain_term(wm, i);
+          }
         if(jc >= 1) // pose correctives; the root joint has none (src/BlendShape.cpp:884-887)
         {
           float dr[3][3]; // [axis][coordinate x]
 #pragma unroll
           for(int x = 0; x < 3; x++)
           {
-            const float * Pv = mv.Pvm + ((int64_t)v * 3 + x) * NP + 9 * (jc - 1);
-            float Pc[9];
-#pragma unroll
-            for(int e = 0; e < 9; e++) Pc[e] = Pv[e];
 #pragma unroll
             for(int a = 0; a < 3; a++)
             {
               const float * dR = lds + L_DR + (3 * jc + a) * 9;
               float sacc = 0.f;
 #pragma unroll
-              for(int e = 0; e < 9; e++) sacc += Pc[e] * dR[e];
+              for(int e = 0; e < 9; e++) sacc += Pc[x][e] * dR[e];
               dr[a][x] = sacc;
             }
           }
