@@ -1415,13 +1415,16 @@ __device__ inline void chol_wave_lds(double * M, int r, double * w, int * bad)
 // Returns A^-1 c in xs[0..nf) like back_subst(). Needs r <= 63, r * nf doubles in Jf, nf in us/ginv, r in w.
 // pre (nullable): the first 2048 gathered entries, loaded by the caller at kernel start on the GUESS that the free set is
 // columns 0 .. pre_nf - 1 (true whenever only theta is free); used when the guess holds.
-__device__ inline void solve_dual(double * M, const double * __restrict__ J, const double * rowv, double * Jf, const double * diag,
-                                  const double * bpri, const int * idx, int nf, int D, int r, double * ginv, double * us, double * w,
-                                  double * xs, int * bad, int dbg_stop, const double * pre = nullptr, int pre_nf = 0)
+// (PRE is a template parameter and `pre` a reference to the caller's registers: as a nullable pointer the eight doubles lived
+// in scratch memory and came back through flat loads)
+template<bool PRE>
+__device__ __forceinline__ void solve_dual(double * M, const double * __restrict__ J, const double * rowv, double * Jf, const double * diag,
+                                           const double * bpri, const int * idx, int nf, int D, int r, double * ginv, double * us, double * w,
+                                           double * xs, int * bad, int dbg_stop, const double (&pre)[8], int pre_nf)
 {
   const int tid = threadIdx.x;
   const int cnt = r * nf;
-  const bool use_pre = pre && pre_nf == nf && idx[nf - 1] == nf - 1; // (ascending, distinct: then idx is the identity; uniform)
+  const bool use_pre = PRE && pre_nf == nf && idx[nf - 1] == nf - 1; // (ascending, distinct: then idx is the identity; uniform)
   for(int q0 = 0; q0 < cnt; q0 += 256 * 8)
   {
     double t[8];
@@ -1974,8 +1977,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     if(dual)
     {
       __syncthreads();
-      solve_dual(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, dinv, lraw, lraw + 192, xs, &s_bad, dbg_stop, DUAL_ONLY ? j_pre : nullptr,
-                 theta_dim);
+      solve_dual<DUAL_ONLY>(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, dinv, lraw, lraw + 192, xs, &s_bad, dbg_stop, j_pre, theta_dim);
       if(dbg_stop >= 31 && dbg_stop <= 34) return;
     }
     else if constexpr(DUAL_ONLY)
