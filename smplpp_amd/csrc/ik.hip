@@ -116,6 +116,20 @@ __device__ inline void dnormalize_dev(const float * x, const float * dx, float *
   dn[2] = (dx[2] - n2 * d) / nrm;
 }
 
+// the same derivative with ONE reciprocal (v_rcp_f32, 1 ulp) instead of six IEEE divisions (~10 instructions each): for
+// Jacobian entries only — values that enter the residual keep the reference's x / norm
+__device__ inline void dnormalize_jac(const float * x, const float * dx, float * dn)
+{
+  float nrm = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  nrm = fmaxf(nrm, 1e-12f);
+  const float inv = __builtin_amdgcn_rcpf(nrm);
+  const float n0 = x[0] * inv, n1 = x[1] * inv, n2 = x[2] * inv;
+  const float d = n0 * dx[0] + n1 * dx[1] + n2 * dx[2];
+  dn[0] = (dx[0] - n0 * d) * inv;
+  dn[1] = (dx[1] - n1 * d) * inv;
+  dn[2] = (dx[2] - n2 * d) * inv;
+}
+
 __device__ inline void actual_normal_dev(const ModelView & mv, const float * verts, int face, const float * w, float * nn)
 {
   float acc[3] = {0.f, 0.f, 0.f};
@@ -739,10 +753,11 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       const float * rv = lds + L_RV + r_ * RVS;
       float * dpv = lds + L_DP + (r_ * 3) * NQ; // row r, column q: dpv[r * NQ + q]
       const float wsum = rv[12];
+      const float iws = __builtin_amdgcn_rcpf(wsum); // (the constant homogeneous divide of SURVEY.md §9 item 4 as a reciprocal: Jacobian entries only)
       if(g == 0) // root translation: identity
       {
         for(int q = 0; q < 3; q++)
-          for(int r = 0; r < 3; r++) dpv[r * NQ + q] = ((r == q) ? wsum : 0.0f) / wsum;
+          for(int r = 0; r < 3; r++) dpv[r * NQ + q] = (r == q) ? 1.0f : 0.0f; // (wsum / wsum)
       }
       else if(g <= NJ)
       {
@@ -819,7 +834,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
 #pragma unroll
         for(int a = 0; a < 3; a++)
 #pragma unroll
-          for(int r = 0; r < 3; r++) dpv[r * NQ + 3 + 3 * jc + a] = acc[a][r] / wsum;
+          for(int r = 0; r < 3; r++) dpv[r * NQ + 3 + 3 * jc + a] = acc[a][r] * iws;
       }
       else
       {
@@ -834,7 +849,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
           const int i = mv.wIdx[(int64_t)v * mv.maxw + m];
           for(int r = 0; r < 3; r++) acc[r] += wm * lds[L_DBB + (i * 3 + r) * NB + kb];
         }
-        for(int r = 0; r < 3; r++) dpv[r * NQ + TD75 + kb] = acc[r] / wsum;
+        for(int r = 0; r < 3; r++) dpv[r * NQ + TD75 + kb] = acc[r] * iws;
       }
     }
     // the column-independent half of B3n, once per adjacent face instead of once per (face, column): edges, unit normal and
@@ -847,7 +862,22 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       if(a < cnt)
       {
         const float * rvb = lds + L_RV + s_roff[k_lo + gi] * RVS;
-        const uint8_t * mp = s_map[gi] + ia * 3;
+        // corners rotated (cyclically: same cross product) so that the first one is triangle vertex i itself — ring slot i —, which
+        // every face around it contains: B3n then reads that vertex's derivative rows once per item, not once per face
+        const uint8_t * mpb = s_map[gi] + ia * 3;
+        int mp[3] = {mpb[0], mpb[1], mpb[2]};
+        if(mp[1] == i)
+        {
+          mp[1] = mp[2];
+          mp[2] = mp[0];
+          mp[0] = i;
+        }
+        else if(mp[2] == i)
+        {
+          mp[2] = mp[1];
+          mp[1] = mp[0];
+          mp[0] = i;
+        }
         const float * p0 = rvb + mp[0] * RVS + 13;
         const float * p1 = rvb + mp[1] * RVS + 13;
         const float * p2 = rvb + mp[2] * RVS + 13;
@@ -867,6 +897,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
           ge[4 + x] = e1[x];
           ge[8 + x] = e2[x];
         }
+        ge[11] = __int_as_float(mp[0] | (mp[1] << 8) | (mp[2] << 16)); // ring slots of the face's corners (B3n)
       }
     }
     __syncthreads();
@@ -888,19 +919,24 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         const float aw = 1.0f / sum;
         if(cnt > MAXADJ) cnt = MAXADJ;
         float mu[3] = {0.f, 0.f, 0.f}, dmu[3] = {0.f, 0.f, 0.f};
+        const float * dv = dp + (i * 3) * NQ + q; // triangle vertex i (ring slot i): the first corner of every face around it
+        const float dv0 = dv[0], dv1 = dv[NQ], dv2 = dv[2 * NQ];
         for(int a = 0; a < cnt; a++)
         {
-          // the adjacent face's corners by ring slot; its geometry from s_geo (the same values every column used to recompute)
-          const uint8_t * mp = s_map[gi] + (i * MAXADJ + a) * 3;
+          // the adjacent face's geometry from s_geo (the same values every column used to recompute); its corners' ring slots
+          // ride in the record's last word (three byte reads of the map per face and column otherwise)
           const float4 * ge = reinterpret_cast<const float4 *>(s_geo[gi][i * MAXADJ + a]);
           const float4 g0 = ge[0], g1 = ge[1], g2 = ge[2];
+          const int mpw = __float_as_int(g2.w);
+          const int mp[3] = {mpw & 255, (mpw >> 8) & 255, mpw >> 16};
           const float nh[3] = {g0.x, g0.y, g0.z}, icn = g1.w;
           const float e1[3] = {g1.x, g1.y, g1.z}, e2[3] = {g2.x, g2.y, g2.z};
-          const float * d0 = dp + (mp[0] * 3) * NQ + q;
           const float * d1 = dp + (mp[1] * 3) * NQ + q;
           const float * d2 = dp + (mp[2] * 3) * NQ + q;
-          const float de1[3] = {d1[0] - d0[0], d1[NQ] - d0[NQ], d1[2 * NQ] - d0[2 * NQ]};
-          const float de2[3] = {d2[0] - d0[0], d2[NQ] - d0[NQ], d2[2 * NQ] - d0[2 * NQ]};
+          // (a face whose first corner is not slot i — a map that does not contain the vertex — cannot occur: the faces are
+          // the ones adjacent to it)
+          const float de1[3] = {d1[0] - dv0, d1[NQ] - dv1, d1[2 * NQ] - dv2};
+          const float de2[3] = {d2[0] - dv0, d2[NQ] - dv1, d2[2 * NQ] - dv2};
           float t1[3], t2[3], dnf[3];
           cross3(de1, e2, t1);
           cross3(e1, de2, t2);
@@ -919,7 +955,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
           }
         }
         float dvn[3];
-        dnormalize_dev(mu, dmu, dvn);
+        dnormalize_jac(mu, dmu, dvn);
         const float mn = fmaxf(sqrtf(mu[0] * mu[0] + mu[1] * mu[1] + mu[2] * mu[2]), 1e-12f);
         for(int x = 0; x < 3; x++)
         {
@@ -951,7 +987,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
             msum[x] += wv[i] * lds[L_VN + (k - k_lo) * 12 + i * 3 + x];
             dm[x] += wv[i] * s_dvn[k - k_lo][(q * 3 + i) * 3 + x];
           }
-        dnormalize_dev(msum, dm, dn);
+        dnormalize_jac(msum, dm, dn);
         if(q == 0)
           for(int x = 0; x < 3; x++) lds[L_VN + (k - k_lo) * 12 + 9 + x] = msum[x];
       }
@@ -1020,7 +1056,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
           float dmm[3] = {0.f, 0.f, 0.f};
           for(int i = 0; i < 3; i++)
             for(int x = 0; x < 3; x++) dmm[x] += dw[i] * lds[L_VN + (k - k_lo) * 12 + i * 3 + x];
-          dnormalize_dev(lds + L_VN + (k - k_lo) * 12 + 9, dmm, dnn);
+          dnormalize_jac(lds + L_VN + (k - k_lo) * 12 + 9, dmm, dnn);
         }
         float ndot = 0.f;
         for(int x = 0; x < 3; x++)
