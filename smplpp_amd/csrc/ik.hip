@@ -224,12 +224,13 @@ constexpr int L_R = 0;                         // [24][9]
 constexpr int L_J = L_R + NJ * 9;              // [24][3]
 constexpr int L_G = L_J + NJ * 3;              // [24][12]  relative transforms [A | b]
 constexpr int L_T = L_G + NJ * 12;             // [24][3]   local translations j_i - j_p(i)
-constexpr int L_DR = L_T + NJ * 3;             // [72][9]
+constexpr int DRS = 28;                        // (27 + one pad word: seven 16-byte reads fetch a joint's three derivative matrices)
+constexpr int L_DR = L_T + NJ * 3;             // [24][DRS]  d R_j / d theta_(j, axis a) at [j][9 a + e]
 // d[A_i | b_i]/d theta_c is non-zero only when joint(c) is an ancestor of i (or i itself), and a joint has exactly one
 // ancestor per depth: the table keeps, per joint, three columns per DEPTH (column slot 3 depth(joint(c)) + axis(c)) instead of
 // all 72 — 41 KB instead of 83 KB of LDS, which is what lets three tasks with a normal term share the ring buffers below.
 constexpr int DMAX = TREE_DMAX;                     // deepest kinematic tree served (SMPL: 9 levels); smplpp_ik_create checks
-constexpr int L_DAB = L_DR + 72 * 9;           // [24][CS][3][4]  per (joint, column slot): rows [dA_r | db_r] (one 16-byte LDS access per row)
+constexpr int L_DAB = L_DR + NJ * DRS;          // [24][CS][3][4]  per (joint, column slot): rows [dA_r | db_r] (one 16-byte LDS access per row)
 constexpr int RVS = 28;                         // floats per ring vertex: rest 3 | Ablend 9 | wsum 1 | posed 3 | weights 4 | joints 4 | their ancestor masks 4
 // The rest of the plan depends on three sizes the kernel is instantiated for (EvalPlan below):
 //   DM   tree levels served: CS = 3 DM column slots per joint in the chain-derivative table
@@ -375,7 +376,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     {
       float dR[9];
       rodrigues_grad_dev(th, tid % 3, dR);
-      for(int q = 0; q < 9; q++) lds[L_DR + tid * 9 + q] = dR[q];
+      for(int q = 0; q < 9; q++) lds[L_DR + (tid / 3) * DRS + (tid % 3) * 9 + q] = dR[q];
     }
     __syncthreads();
   }
@@ -417,7 +418,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         const bool self = (role[L] >> 18) & 1;
         const int pc = (i == 0) ? 0 : p; // (the root has no parent: any valid address, the value is not used)
         const float4 xr = *reinterpret_cast<const float4 *>(self ? lds + L_G + pc * 12 + r * 4 : lds + L_DAB + ((pc * CS + cs) * 3 + r) * 4);
-        const float * M = self ? lds + L_DR + (3 * i + cs % 3) * 9 : lds + L_R + i * 9;
+        const float * M = self ? lds + L_DR + i * DRS + (cs % 3) * 9 : lds + L_R + i * 9;
         const float m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3], m4 = M[4], m5 = M[5], m6 = M[6], m7 = M[7], m8 = M[8];
         const float t0 = lds[L_T + i * 3], t1 = lds[L_T + i * 3 + 1], t2 = lds[L_T + i * 3 + 2];
         const float jp0 = lds[L_J + pc * 3], jp1 = lds[L_J + pc * 3 + 1], jp2 = lds[L_J + pc * 3 + 2];
@@ -752,6 +753,10 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       const int v = s_rvert[r_];
       const float * rv = lds + L_RV + r_ * RVS;
       float * dpv = lds + L_DP + (r_ * 3) * NQ; // row r, column q: dpv[r * NQ + q]
+      // the ring vertex's record in 16-byte words (the LDS pipe is what this phase is pressed against: instruction count matters)
+      const float4 * rv4 = reinterpret_cast<const float4 *>(rv);
+      const float4 q0 = rv4[0], q1 = rv4[1], q2 = rv4[2], qw = rv4[4], qj = rv4[5], qa = rv4[6];
+      const float Ab[9] = {q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}; // the blended rotation, row-major
       const float wsum = rv[12];
       const float iws = __builtin_amdgcn_rcpf(wsum); // (the constant homogeneous divide of SURVEY.md §9 item 4 as a reciprocal: Jacobian entries only)
       if(g == 0) // root translation: identity
@@ -780,7 +785,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         float acc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}; // [axis][row]
         // (two loops, not one with `wlds ? LDS : HBM` operands: a pointer that may be either compiles to flat loads, each
         // followed by a wait for EVERY outstanding load — the 27 requested above included)
-        const float r0 = rv[0], r1 = rv[1], r2 = rv[2];
+        const float r0 = q0.x, r1 = q0.y, r2 = q0.z;
         auto chain_term = [&](float wm, int i) {
           const float4 * d = reinterpret_cast<const float4 *>(lds + L_DAB + (i * CS + cs0) * 12);
 #pragma unroll
@@ -794,12 +799,12 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         };
         if(wlds)
         {
+          const float wq[4] = {qw.x, qw.y, qw.z, qw.w}, jq[4] = {qj.x, qj.y, qj.z, qj.w}, aq[4] = {qa.x, qa.y, qa.z, qa.w};
 #pragma unroll
           for(int m = 0; m < 4; m++)
           {
-            const float wm = rv[16 + m];
             // joint jc moves joint i only when it is its ancestor (or i itself): otherwise the term is exactly zero
-            if(wm != 0.0f && (__float_as_int(rv[24 + m]) & jbit)) chain_term(wm, __float_as_int(rv[20 + m]));
+            if(wq[m] != 0.0f && (__float_as_int(aq[m]) & jbit)) chain_term(wq[m], __float_as_int(jq[m]));
           }
         }
         else
@@ -813,23 +818,35 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         if(jc >= 1) // pose correctives; the root joint has none (src/BlendShape.cpp:884-887)
         {
           float dr[3][3]; // [axis][coordinate x]
+          float dRj[DRS];  // the joint's three derivative matrices, [9 a + e], in seven 16-byte reads
+          {
+            const float4 * d4 = reinterpret_cast<const float4 *>(lds + L_DR + jc * DRS);
+#pragma unroll
+            for(int u = 0; u < DRS / 4; u++)
+            {
+              const float4 w4 = d4[u];
+              dRj[4 * u] = w4.x;
+              dRj[4 * u + 1] = w4.y;
+              dRj[4 * u + 2] = w4.z;
+              dRj[4 * u + 3] = w4.w;
+            }
+          }
 #pragma unroll
           for(int x = 0; x < 3; x++)
           {
 #pragma unroll
             for(int a = 0; a < 3; a++)
             {
-              const float * dR = lds + L_DR + (3 * jc + a) * 9;
               float sacc = 0.f;
 #pragma unroll
-              for(int e = 0; e < 9; e++) sacc += Pc[x][e] * dR[e];
+              for(int e = 0; e < 9; e++) sacc += Pc[x][e] * dRj[a * 9 + e];
               dr[a][x] = sacc;
             }
           }
 #pragma unroll
           for(int a = 0; a < 3; a++)
 #pragma unroll
-            for(int r = 0; r < 3; r++) acc[a][r] += (rv[3 + r * 3] * dr[a][0] + rv[3 + r * 3 + 1] * dr[a][1]) + rv[3 + r * 3 + 2] * dr[a][2];
+            for(int r = 0; r < 3; r++) acc[a][r] += (Ab[r * 3] * dr[a][0] + Ab[r * 3 + 1] * dr[a][1]) + Ab[r * 3 + 2] * dr[a][2];
         }
 #pragma unroll
         for(int a = 0; a < 3; a++)
@@ -841,7 +858,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         const int kb = g - 1 - NJ;
         float ds[3], acc[3];
         for(int x = 0; x < 3; x++) ds[x] = mv.Svm[((int64_t)v * 3 + x) * NB + kb];
-        for(int r = 0; r < 3; r++) acc[r] = (rv[3 + r * 3] * ds[0] + rv[3 + r * 3 + 1] * ds[1]) + rv[3 + r * 3 + 2] * ds[2];
+        for(int r = 0; r < 3; r++) acc[r] = (Ab[r * 3] * ds[0] + Ab[r * 3 + 1] * ds[1]) + Ab[r * 3 + 2] * ds[2];
         for(int m = 0; m < mv.maxw; m++)
         {
           const float wm = mv.wVal[(int64_t)v * mv.maxw + m];
