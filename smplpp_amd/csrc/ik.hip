@@ -338,6 +338,23 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   const int per_part = (K + tsplit - 1) / tsplit;
   const int k_begin = part * per_part, k_end = (k_begin + per_part < K) ? k_begin + per_part : K;
 
+  // ---- what phase A will read of the tasks is requested NOW: its addresses depend on nothing the kernel computes, and the
+  // dependent pair face id -> ring list (two round trips) then runs beside the set-up and the chain-derivative steps instead
+  // of in front of phase A.  (The re-projection that wrote faces, weights and targets has been waited for by the stream.)
+  const int ntask = k_end - k_begin;
+  const bool a0_live = tid < ntask * (MAXRING + 1); // A0's first pass: one (task, ring-list word) per thread
+  const int a0_t = a0_live ? tid / (MAXRING + 1) : 0, a0_q = a0_live ? tid % (MAXRING + 1) : 0;
+  const int64_t a0_k = tb + k_begin + a0_t;
+  const float a0_noff = ta.noff[a0_k], a0_nrmw = ta.nrmw[a0_k];
+  const int a0_face = ta.face[a0_k];
+  const bool a3_live = tid < ntask; // A3: one task per thread
+  const int64_t a3_k = tb + k_begin + (a3_live ? tid : 0);
+  const float a3_off = ta.noff[a3_k], a3_wp = ta.posw[a3_k], a3_wn = ta.nrmw[a3_k];
+  const float a3_w[3] = {ta.vw[a3_k * 3], ta.vw[a3_k * 3 + 1], ta.vw[a3_k * 3 + 2]};
+  const float a3_tp[3] = {ta.tpos[a3_k * 3], ta.tpos[a3_k * 3 + 1], ta.tpos[a3_k * 3 + 2]};
+  const float a3_tn[3] = {ta.tnrm[a3_k * 3], ta.tnrm[a3_k * 3 + 1], ta.tnrm[a3_k * 3 + 2]};
+  const uint16_t a0_e = mv.faceRing[(int64_t)a0_face * (MAXRING + 1) + a0_q];
+
   // ---- set-up: every global load first (one round trip), then the frame constants into LDS
   static_assert(EVAL_NT >= NJ * 12 && IK_MAXK <= 64, "one element of each frame constant per thread; validity by one ballot");
   __shared__ int s_valid;
@@ -479,14 +496,15 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   // (free until then)
   static_assert(IK_MAXK * MAXRING * 3 <= RCAP * 3 * NQ, "s_rpos must fit the L_DP region");
   float(*s_rpos)[MAXRING][3] = reinterpret_cast<float(*)[MAXRING][3]>(lds + L_DP);
-  const int ntask = k_end - k_begin;
-  // A0: ring lists from the per-face tables built with the model (topology only)
+  // A0: ring lists from the per-face tables built with the model (topology only); the first pass from the words requested at
+  // the kernel's start
   for(int item = tid; item < ntask * (MAXRING + 1); item += EVAL_NT)
   {
     const int t = item / (MAXRING + 1), q = item % (MAXRING + 1);
     const int k = k_begin + t;
-    const bool use_normal = (ta.noff[tb + k] > 0.0f) || (ta.nrmw[tb + k] > 0.0f);
-    const uint16_t e = mv.faceRing[(int64_t)ta.face[tb + k] * (MAXRING + 1) + q];
+    const bool first = item < EVAL_NT; // (item == tid)
+    const bool use_normal = first ? ((a0_noff > 0.0f) || (a0_nrmw > 0.0f)) : ((ta.noff[tb + k] > 0.0f) || (ta.nrmw[tb + k] > 0.0f));
+    const uint16_t e = first ? a0_e : mv.faceRing[(int64_t)ta.face[tb + k] * (MAXRING + 1) + q];
     // slots 0..2 = the face's own vertices; with a normal term / offset also the distinct vertices of the faces around them
     s_ringb[t][q] = (q == 0 && !use_normal) ? (uint16_t)3 : e;
     if(q == 0) s_usen[t] = use_normal ? 1 : 0;
@@ -612,10 +630,10 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     for(int i = 0; i < 3; i++)
 #pragma unroll
       for(int x = 0; x < 3; x++) tri[i * 3 + x] = s_rpos[tid][i][x]; // ring slots 0..2 are the face's own vertices
-    const float off = ta.noff[tb + k], wp = ta.posw[tb + k], wn = ta.nrmw[tb + k];
-    float w[3] = {ta.vw[(tb + k) * 3], ta.vw[(tb + k) * 3 + 1], ta.vw[(tb + k) * 3 + 2]};
-    const float tp[3] = {ta.tpos[(tb + k) * 3], ta.tpos[(tb + k) * 3 + 1], ta.tpos[(tb + k) * 3 + 2]};
-    const float tn[3] = {ta.tnrm[(tb + k) * 3], ta.tnrm[(tb + k) * 3 + 1], ta.tnrm[(tb + k) * 3 + 2]};
+    const float off = a3_off, wp = a3_wp, wn = a3_wn; // (requested at the kernel's start)
+    float w[3] = {a3_w[0], a3_w[1], a3_w[2]};
+    const float tp[3] = {a3_tp[0], a3_tp[1], a3_tp[2]};
+    const float tn[3] = {a3_tn[0], a3_tn[1], a3_tn[2]};
     // calcTangents (src/IkTask.cpp:33-47)
     float t1[3] = {tri[3] - tri[0], tri[4] - tri[1], tri[5] - tri[2]};
     float t2[3];
