@@ -492,6 +492,8 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   __shared__ float s_vn[IK_MAXK][9];
   __shared__ uint16_t s_ringb[IK_MAXK][MAXRING + 1]; // (vertex ids fit 16 bits: smplpp_ik_create checks V)
   __shared__ uint8_t s_usen[IK_MAXK];               // the task differentiates a normal (normal term or normal offset)
+  __shared__ int s_facel[IK_MAXK];                  // the task's face
+  __shared__ uint8_t s_acnt[IK_MAXK][4];            // faces around each of its three vertices (<= 255: a larger count takes the general routine either way)
   // posed positions of the ring vertices of every task of this workgroup: [task][MAXRING][3], in the dp buffer of phase B
   // (free until then)
   static_assert(IK_MAXK * MAXRING * 3 <= RCAP * 3 * NQ, "s_rpos must fit the L_DP region");
@@ -504,10 +506,15 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     const int k = k_begin + t;
     const bool first = item < EVAL_NT; // (item == tid)
     const bool use_normal = first ? ((a0_noff > 0.0f) || (a0_nrmw > 0.0f)) : ((ta.noff[tb + k] > 0.0f) || (ta.nrmw[tb + k] > 0.0f));
-    const uint16_t e = first ? a0_e : mv.faceRing[(int64_t)ta.face[tb + k] * (MAXRING + 1) + q];
+    const int face = first ? a0_face : ta.face[tb + k];
+    const uint16_t e = first ? a0_e : mv.faceRing[(int64_t)face * (MAXRING + 1) + q];
     // slots 0..2 = the face's own vertices; with a normal term / offset also the distinct vertices of the faces around them
     s_ringb[t][q] = (q == 0 && !use_normal) ? (uint16_t)3 : e;
-    if(q == 0) s_usen[t] = use_normal ? 1 : 0;
+    if(q == 0)
+    {
+      s_usen[t] = use_normal ? 1 : 0;
+      s_facel[t] = face; // (phase B's table loads start from LDS, not from another dependent HBM read)
+    }
   }
   __syncthreads();
   __shared__ int s_rcum[IK_MAXK + 1]; // ring sizes of the workgroup's tasks, cumulated (offsets of the groups' ring buffers)
@@ -574,16 +581,16 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   float(*s_fn)[3 * MAXADJ][3] = reinterpret_cast<float(*)[3 * MAXADJ][3]>(lds + L_DP + IK_MAXK * MAXRING * 3);
   for(int item = tid; item < ntask * 3 * MAXADJ; item += EVAL_NT)
   {
-    const int t = item / (3 * MAXADJ), ia = item % (3 * MAXADJ), i = ia / MAXADJ, a2 = ia % MAXADJ, k = k_begin + t;
+    const int t = item / (3 * MAXADJ), ia = item % (3 * MAXADJ), i = ia / MAXADJ, a2 = ia % MAXADJ;
     if(s_usen[t])
     {
       const int u = s_ringb[t][1 + i];
+      // (count and map entry in ONE round trip: the entry exists whether or not the vertex has that many faces)
+      const uint8_t * mp = mv.faceMap + (int64_t)s_facel[t] * (3 * MAXADJ * 3) + ia * 3;
+      const int m0 = mp[0], m1 = mp[1], m2 = mp[2];
       const int cnt = mv.adjOff[u + 1] - mv.adjOff[u];
-      if(a2 < cnt && cnt <= MAXADJ)
-      {
-        const uint8_t * mp = mv.faceMap + (int64_t)ta.face[tb + k] * (3 * MAXADJ * 3) + ia * 3;
-        face_normal_pts(s_rpos[t][mp[0]], s_rpos[t][mp[1]], s_rpos[t][mp[2]], s_fn[t][ia]);
-      }
+      if(a2 == 0) s_acnt[t][i] = (uint8_t)(cnt < 255 ? cnt : 255); // (the sum below starts from LDS, not from a second round trip; smplpp_ik_create admits at most MAXADJ)
+      if(a2 < cnt && cnt <= MAXADJ) face_normal_pts(s_rpos[t][m0], s_rpos[t][m1], s_rpos[t][m2], s_fn[t][ia]);
     }
   }
   __syncthreads();
@@ -593,7 +600,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     if(s_usen[t])
     {
       const int u = s_ringb[t][1 + i];
-      const int b0 = mv.adjOff[u], cnt = mv.adjOff[u + 1] - b0;
+      const int cnt = s_acnt[t][i];
       float vn[3];
       if(cnt > MAXADJ) // more faces than the ring map covers: the general routine
         vertex_normal_dev(verts, mv.faces, mv.adjOff, mv.adjFace, u, vn);
@@ -748,14 +755,14 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     else if(tid >= 96 && tid < 96 + NGN * MAPN) // ring-slot maps of the group's normal tasks
     {
       const int gi = (tid - 96) / MAPN, j = (tid - 96) % MAPN;
-      if(gi < ngn) s_map[gi][j] = mv.faceMap[(int64_t)ta.face[tb + k_lo + gi] * MAPN + j];
+      if(gi < ngn) s_map[gi][j] = mv.faceMap[(int64_t)s_facel[k_lo - k_begin + gi] * MAPN + j];
     }
     else if(tid >= RCAP && tid < RCAP + NGN * 3)
     {
       const int gi = (tid - RCAP) / 3, j = (tid - RCAP) % 3;
       if(gi < ngn)
       {
-        const int u = mv.faces[ta.face[tb + k_lo + gi] * 3 + j];
+        const int u = s_ringb[k_lo - k_begin + gi][1 + j]; // ring slots 0..2: the face's own vertices, in its order
         s_cnt[gi][j] = mv.adjOff[u + 1] - mv.adjOff[u];
       }
     }
