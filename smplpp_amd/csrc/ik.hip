@@ -344,11 +344,13 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   const int ntask = k_end - k_begin;
   const bool a0_live = tid < ntask * (MAXRING + 1); // A0's first pass: one (task, ring-list word) per thread
   const int a0_t = a0_live ? tid / (MAXRING + 1) : 0, a0_q = a0_live ? tid % (MAXRING + 1) : 0;
-  const int64_t a0_k = tb + k_begin + a0_t;
+  // (a workgroup whose share of the tasks is empty — more parts than tasks — or a thread without an item reads task 0 of its
+  // frame: every address requested here lies inside the task arrays)
+  const int64_t a0_k = a0_live ? tb + k_begin + a0_t : tb;
   const float a0_noff = ta.noff[a0_k], a0_nrmw = ta.nrmw[a0_k];
   const int a0_face = ta.face[a0_k];
   const bool a3_live = tid < ntask; // A3: one task per thread
-  const int64_t a3_k = tb + k_begin + (a3_live ? tid : 0);
+  const int64_t a3_k = a3_live ? tb + k_begin + tid : tb;
   const float a3_off = ta.noff[a3_k], a3_wp = ta.posw[a3_k], a3_wn = ta.nrmw[a3_k];
   const float a3_w[3] = {ta.vw[a3_k * 3], ta.vw[a3_k * 3 + 1], ta.vw[a3_k * 3 + 2]};
   const float a3_tp[3] = {ta.tpos[a3_k * 3], ta.tpos[a3_k * 3 + 1], ta.tpos[a3_k * 3 + 2]};

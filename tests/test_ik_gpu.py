@@ -639,3 +639,34 @@ def test_ik_eval_deep_tree_vs_oracle(synth_model):
         scale = max(1.0, np.abs(r["J"]).max())
         assert dJ[:, :3].max() < 1e-4 * scale, f
         assert dJ[:, 3].max() < 6e-4 * scale, f
+
+
+def test_ik_eval_more_parts_than_tasks(smpl, oracle_synth):
+    """Few frames and few tasks: the evaluation splits a frame's tasks over several workgroups (one per CU), and with 64 frames
+    x 5 tasks the split (4 parts of 2) leaves the last part of every frame WITHOUT a task.  Such a workgroup must not touch
+    anything beyond its frame's task records (its early requests once read past the end of the task arrays for the last frame);
+    first and last frame against the oracle."""
+    from oracle import cpu
+    from smplpp_amd import model_io
+    from smplpp_amd.ik import IkSolver
+
+    rng = np.random.default_rng(57)
+    n, K = 64, 5
+    beta, theta = model_io.synthetic_inputs(n, seed=21)
+    theta[:, 1:] *= 0.4
+    faces = rng.integers(0, 13776, (n, K))
+    tp = rng.normal(0, 0.4, (n, K, 3)).astype(np.float32)
+    tn = rng.normal(0, 1, (n, K, 3)).astype(np.float32)
+    tn /= np.linalg.norm(tn, axis=2, keepdims=True)
+    s = IkSolver(smpl, n, K)
+    s.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, phi_limit=np.zeros((n, K)), normal_task_weight=np.ones((n, K)))
+    s.setConfig(beta, theta)
+    e, J = s.eval(optimize_beta=False)
+    for f in (0, n - 1):
+        ts = cpu.TaskSet(faces[f], tp[f], tn[f], phi_limit=np.zeros(K))
+        ts.normal_task_weight[:] = 1.0
+        r = oracle_synth.ik_eval(beta[f], theta[f], ts, False)
+        de = np.abs(r["e"] - e[f]).reshape(K, 4)
+        assert de[:, :3].max() < 5e-6 and de[:, 3].max() < 1e-4
+        scale = max(1.0, np.abs(r["J"]).max())
+        assert np.abs(r["J"] - J[f]).max() < 6e-4 * scale
