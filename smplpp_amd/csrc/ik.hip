@@ -36,7 +36,7 @@ constexpr int TD75 = SMPLPP_THETA_DIM;        // 75
 constexpr int TD44 = SMPLPP_LATENT_POSE_DIM;  // 44
 constexpr int NQ = TD75 + NB;                 // differentiation columns handled per frame: theta(75) | beta(10)
 constexpr int IK_MAXK = 48;                   // tasks per frame supported (the reference uses at most 41: MocapBody markers)
-constexpr size_t SOLVE_LDS_MAX = 160 * 1024 - 512; // dynamic LDS the solve kernels may ask for (160 KiB per CU, minus their static LDS)
+constexpr size_t SOLVE_LDS_MAX = 160 * 1024 - 1536; // dynamic LDS the solve kernels may ask for (160 KiB per CU, minus their static LDS: 1.2 KB)
 constexpr int MAXD = TD75 + 2 * IK_MAXK + NB;  // 181: unknowns per frame supported by the in-LDS solver (every task count up to IK_MAXK, beta included)
 
 struct TaskArrays
@@ -1347,8 +1347,9 @@ __device__ inline void stage_rows(double * dst, const double * __restrict__ src,
   }
 }
 
-// the first W columns of cr rows (row stride D in HBM) packed at stride W in LDS, eight loads in flight per thread
-__device__ inline void stage_rows_cols(double * dst, const double * __restrict__ src, int cr, int W, int D)
+// the first W columns of cr rows (row stride D in HBM) packed at stride W in LDS, sixteen loads in flight per thread; rl
+// (nullable): the rows to take, by index
+__device__ inline void stage_rows_cols(double * dst, const double * __restrict__ src, int cr, int W, int D, const int * rl = nullptr)
 {
   // (the copy is a chain of HBM round trips, ~1.5 us each with a single workgroup pulling: sixteen loads in flight per thread —
   // the 164 x 75 block of a motion solve in three round trips instead of six)
@@ -1362,7 +1363,7 @@ __device__ inline void stage_rows_cols(double * dst, const double * __restrict__
     {
       const int q = q0 + u * 256 + tid, qq = q < cnt ? q : cnt - 1;
       const int rr = qq / W;
-      t[u] = src[(int64_t)rr * D + (qq - rr * W)];
+      t[u] = src[(int64_t)(rl ? rl[rr] : rr) * D + (qq - rr * W)];
     }
 #pragma unroll
     for(int u = 0; u < U; u++)
@@ -1597,7 +1598,7 @@ template<int NT>
 __device__ inline void build_and_factor_reg(double * M, const double * __restrict__ J, const double * __restrict__ rowv, double * Jc,
                                             const double * diag, const double * bpri, const int * idx, int nf, int D, int rows,
                                             int chunk_rows, double * lraw /*[2][4][16*NT]*/, double * ldiag /*[4]*/, double * dinv /*[nf]*/, int * bad,
-                                            int dbg_stop = 0)
+                                            int dbg_stop, const int * rlist /*[nlive] rows of J that are not identically zero*/, int nlive)
 {
   // thread (ty, tx): tx in the HIGH bits, so the 16 holders of a column (one tx, all ty) sit in one wavefront and the other
   // three skip the publish path (extraction, rsqrt, LDS writes) instead of executing it for four lanes each
@@ -1634,21 +1635,23 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
     // only the columns up to the last free one are staged (the free set is ascending), rows packed at that width: a motion
     // solve with its surface coordinates pinned reads 75 of its 157 columns — half the traffic, and all 164 rows in ONE chunk
     const int W = nf > 0 ? idx[nf - 1] + 1 : 1;
+    // ... and only the rows that can be non-zero (rlist): a task without a normal term has a zero fourth row, a missing marker
+    // four zero rows — a quarter of the 164 rows of a capture solve.  Zero rows add exact zeros: the sums keep their bits.
     const int crows = (int)(((int64_t)chunk_rows * D) / W);
-    for(int c0 = 0; c0 < rows; c0 += crows)
+    for(int c0 = 0; c0 < nlive; c0 += crows)
     {
-      const int cr = (rows - c0 < crows) ? rows - c0 : crows;
+      const int cr = (nlive - c0 < crows) ? nlive - c0 : crows;
       __syncthreads();
-      if(W == D)
+      if(W == D && nlive == rows)
         stage_rows(Jc, J + (int64_t)c0 * D, cr * D);
       else
-        stage_rows_cols(Jc, J + (int64_t)c0 * D, cr, W, D);
+        stage_rows_cols(Jc, J, cr, W, D, rlist + c0);
       __syncthreads();
       for(int r0 = 0; r0 < cr; r0 += 4)
       {
         const int r = r0 + lq;
         const bool rin = r < cr;
-        const double rv = rowv[c0 + (rin ? r : 0)];
+        const double rv = rowv[rlist[c0 + (rin ? r : 0)]];
         const double * Jr = Jc + (rin ? r : 0) * W;
         // (every tile's two operands are read first, then the MFMAs: a read -> wait -> MFMA pair per tile paid the LDS round
         // trip TPW times per four rows)
@@ -1875,6 +1878,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   int * state = idx + D; // 0 free, -1 at lo, +1 at hi, 2 pinned (empty box)
   double * ebuf = reinterpret_cast<double *>(state + D); // [rows] the residual, read from HBM once
   __shared__ int s_bad, s_nf, s_block, s_bside, s_done, s_anybound, s_wcnt[4];
+  __shared__ int s_rlist[DUAL_ONLY ? 1 : IK_MAXK * 4], s_nlive; // rows of J that are not identically zero (primal form: build_and_factor_reg)
   __shared__ double s_alpha, s_e2;
   // Everything the set-up reads from HBM is requested NOW, in one round trip: the skip flag, the residual, this thread's limit
   // and prior entry — and, in the dual-only instantiation, the Jacobian block the dual form will gather if only theta turns out
@@ -1889,6 +1893,18 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   const bool my_phi = my_i >= theta_dim && my_i < theta_dim + 2 * K;
   const float pl_pre = (D <= 256 && my_phi && phi_live) ? ta.philim[tb + (my_i - theta_dim) / 2] : 0.0f;
   const float th_pre = (D <= 256 && use_prior && my_i < theta_dim) ? theta[f * theta_dim + my_i] : 0.0f;
+  // primal form: the weight that decides whether a row of J can be non-zero (rows 4k .. 4k+2: the task's position weight —
+  // a missing marker has none —, row 4k+3: its normal weight), for the second wavefront's row list
+  float rl_pre[(IK_MAXK * 4 + 63) / 64];
+  if constexpr(!DUAL_ONLY)
+  {
+#pragma unroll
+    for(int c = 0; c < (IK_MAXK * 4 + 63) / 64; c++)
+    {
+      const int r = 64 * c + (tid & 63), k = (r < rows ? r : 0) >> 2;
+      rl_pre[c] = ((r & 3) == 3) ? ta.nrmw[tb + k] : ta.posw[tb + k];
+    }
+  }
   double j_pre[8];
   if constexpr(DUAL_ONLY)
   {
@@ -1943,6 +1959,21 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       s_done = 0;
       if(e2_out) e2_out[f] = s;
     }
+  }
+  else if(!DUAL_ONLY && tid < 128) // beside the sum: the rows of J that can be non-zero, ascending
+  {
+    const int l = tid - 64;
+    int base = 0;
+#pragma unroll
+    for(int c = 0; c < (IK_MAXK * 4 + 63) / 64; c++)
+    {
+      const int r = 64 * c + l;
+      const bool lv = r < rows && (((r & 3) == 3) ? (rl_pre[c] > 0.0f) : (rl_pre[c] != 0.0f));
+      const unsigned long long m = __ballot(lv);
+      if(lv) s_rlist[base + __popcll(m & ((1ull << l) - 1ull))] = r;
+      base += __popcll(m);
+    }
+    if(l == 0) s_nlive = base;
   }
   __syncthreads();
   for(int i = tid; i < D; i += 256)
@@ -2067,7 +2098,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     {
       // registers, one barrier per column
       __syncthreads();
-      build_and_factor_reg<NTR>(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, chunk_rows, lraw, ldiag, dinv, &s_bad, dbg_stop);
+      build_and_factor_reg<NTR>(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, chunk_rows, lraw, ldiag, dinv, &s_bad, dbg_stop, s_rlist, s_nlive);
       if(dbg_stop == 4) return;
     }
     else
