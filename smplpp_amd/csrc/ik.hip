@@ -1647,6 +1647,7 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
       else
         stage_rows_cols(Jc, J, cr, W, D, rlist + c0);
       __syncthreads();
+      if(dbg_stop == 41) return; // (timing experiments only)
       for(int r0 = 0; r0 < cr; r0 += 4)
       {
         const int r = r0 + lq;
@@ -1673,6 +1674,7 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
       }
     }
     __syncthreads();
+    if(dbg_stop == 42) return;
 #pragma unroll
     for(int u = 0; u < TPW; u++)
     {
@@ -2099,7 +2101,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       // registers, one barrier per column
       __syncthreads();
       build_and_factor_reg<NTR>(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, chunk_rows, lraw, ldiag, dinv, &s_bad, dbg_stop, s_rlist, s_nlive);
-      if(dbg_stop == 4) return;
+      if(dbg_stop == 4 || dbg_stop == 41 || dbg_stop == 42) return;
     }
     else
     {
