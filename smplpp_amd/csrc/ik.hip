@@ -1857,11 +1857,25 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
                                                        int K, int theta_dim, int beta_dim, int phi_live, int enable_qp, int use_prior,
                                                        int chunk_rows, const int * __restrict__ skip, double * __restrict__ e2_out,
                                                        int * __restrict__ status, int * __restrict__ sticky, double * __restrict__ x_out, int dbg_stop, int m_dim,
-                                                       float * __restrict__ theta25, float * __restrict__ theta_copy)
+                                                       float * __restrict__ theta25, float * __restrict__ theta_copy,
+                                                       unsigned * __restrict__ go_flag, unsigned * __restrict__ go_counter, unsigned go_tick)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int64_t f = blockIdx.x;
   const int tid = threadIdx.x;
+  // "Every workgroup of this kernel is on its CU": the re-projection on the side stream waits for THIS, not for the end of the
+  // evaluation.  Both kernels become ready at the same instant, and when the face scan's 1536 workgroups were dispatched first
+  // the solve's (one per frame, a whole SIMD's registers per wavefront, 150 KB of LDS) waited for them to drain: 77 us became
+  // 105-118 us in most frames of a capture fit, on the critical path.  Nothing is published here (what the scan reads was
+  // written by the kernel before this one), so no drain: a counter and, from the last workgroup to arrive, the flag.
+  if(go_flag && tid == 0)
+  {
+    if(__hip_atomic_fetch_add(go_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+    {
+      __hip_atomic_store(go_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(go_flag, go_tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   const int D = theta_dim + 2 * K + beta_dim, rows = 4 * K;
   const int64_t tb = f * K;
   double * M = sm;
@@ -2826,7 +2840,19 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   S_TRY(hipMemset(s->status, 0, sizeof(int) * n));
   S_TRY(hipMemset(s->sticky, 0, sizeof(int) * n));
   s->verts = s->vbuf[0];
-  S_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+  {
+    // The side stream carries the re-projection, which becomes ready at the same instant as the solve on the caller's stream (both
+    // wait for the evaluation).  Whichever kernel the hardware dispatches first takes the CUs: when the face scan's 1536 workgroups
+    // went first, the solve's workgroups (one per frame, 150 KB of LDS, a whole SIMD's registers) waited for them to drain — 77 us
+    // became 105-118 us in most frames of a capture fit, on the critical path.  Lowest priority for the side stream
+    // (SMPLPP_IK_SIDE_PRIORITY=0: default priority).
+    int lo = 0, hi = 0;
+    const char * pe = getenv("SMPLPP_IK_SIDE_PRIORITY");
+    if((!pe || pe[0] != '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+      S_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, lo)); // (lo: the numerically greatest = least priority)
+    else
+      S_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+  }
   S_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   S_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   {
@@ -3000,8 +3026,8 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   int tsplit = (n < 256) ? (int)(256 / n) : 1; // one round of workgroups (one per CU: its LDS is the evaluation's)
   if(tsplit > K) tsplit = K;
   if(tsplit < 1) tsplit = 1;
-  const bool fork_flag = eval_done && s->use_flags; // the side stream waits for this evaluation: flag instead of the event
-  if(fork_flag) s->tick_fork++;
+  const bool fork_flag = false; // (flags mode: the fork is signalled by the SOLVE kernel's start, see ik_solve_kernel; the evaluation signals only in events mode)
+  if(s->use_flags) eval_done = nullptr;
 #define EVAL_(DM, RC, NG)                                                                                                                  \
   hipExtLaunchKernelGGL((ik_eval_kernel<DM, RC, NG>), dim3((unsigned)(n * tsplit)), dim3(EVAL_NT), shmem, st, nullptr,                    \
                         fork_flag ? nullptr : eval_done, 0, view_of(m), s->ta, th25, (const float *)s->verts, (const float *)s->rest,       \
@@ -3105,12 +3131,16 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
     const bool dual_only = rows < s->theta_dim && rows <= 63 && chunk_rows >= rows && D <= 192 && dbg_stop != 9;
     const bool last = hook && it == iters - 1;
     float * theta_record = last ? hook->theta_record : nullptr;
+    const bool go = beside && s->use_flags; // the side stream's fork: raised by the solve kernel once all its workgroups run
+    if(go) s->tick_fork++;
 #define SOLVE_(DO) ik_solve_kernel<DO><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
     s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
-    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr, theta_record)
+    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr, theta_record, \
+    go ? s->sig : (unsigned *)nullptr, go ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork)
 #define SOLVE11_() ik_solve_kernel<false, 11><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
     s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
-    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr, theta_record)
+    s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr, theta_record, \
+    go ? s->sig : (unsigned *)nullptr, go ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork)
     {
       TraceRange tr_solve("solve IK"); // node.cpp:907-943
       if(dual_only)
