@@ -1292,24 +1292,52 @@ __device__ inline void back_subst(const double * M, int nf, double * xs, const d
   __syncthreads(); // M and dinv are complete
   if(tid < 64)
   {
+    // One wavefront, lane i keeps x_i (+64, +128).  The loop is a chain of nf steps whose cost is its instruction count (a
+    // step used to be ~60 instructions, ~280 cycles): lane j's entry is never touched after step j (the row entries of lanes
+    // >= j are read as zero), so nobody "owns" a finished entry inside the loop — entries stay unscaled and take their
+    // 1/L_jj once, at the end; rows are read without exec masks (a lane beyond the row reads the zero word instead).
+    __shared__ double s_zero;
+    if(tid == 0) s_zero = 0.0;
     double x[3];
 #pragma unroll
     for(int a = 0; a < 3; a++) x[a] = (tid + 64 * a < nf) ? M[tri_idx(nf, tid + 64 * a)] : 0.0;
-    for(int j = nf - 1; j >= 0; j--)
-    {
-      const int ja = __builtin_amdgcn_readfirstlane(j >> 6), jl = __builtin_amdgcn_readfirstlane(j & 63);
-      const double * Lj = M + tri_idx(j, 0);
-      double l[3];
+    __builtin_amdgcn_wave_barrier();
+    // three segments by the number of accumulators a row still reaches (rows 128.., 64..127, 0..63), each a loop without
+    // branches whose next row and pivot are requested one step ahead (two steps: rows[2])
+    auto segment = [&](auto na_tag, int jhi, int jlo) {
+      constexpr int NA = decltype(na_tag)::value;
+      if(jhi < jlo) return;
+      auto fetch = [&](int j, double (&l)[NA], double & d) {
+        const double * Lj = M + tri_idx(j, 0);
 #pragma unroll
-      for(int a = 0; a < 3; a++) l[a] = (tid + 64 * a < j) ? Lj[tid + 64 * a] : 0.0;
-      const double xv = ja == 0 ? x[0] : (ja == 1 ? x[1] : x[2]);
-      const double xj = readlane_f64(xv, jl) * dinv[j];
+        for(int a = 0; a < NA - 1; a++) l[a] = Lj[tid + 64 * a];
+        l[NA - 1] = *((tid + 64 * (NA - 1) < j) ? Lj + tid + 64 * (NA - 1) : &s_zero);
+        d = dinv[j];
+      };
+      double l0[NA], l1[NA], d0, d1;
+      fetch(jhi, l0, d0);
+      fetch(jhi - 1 >= jlo ? jhi - 1 : jlo, l1, d1);
+      for(int j = jhi; j >= jlo; j--)
+      {
+        double lc[NA];
 #pragma unroll
-      for(int a = 0; a < 3; a++) x[a] = (tid + 64 * a == j) ? xj : x[a] - l[a] * xj;
-    }
+        for(int a = 0; a < NA; a++) lc[a] = l0[a];
+        const double dc = d0;
+#pragma unroll
+        for(int a = 0; a < NA; a++) l0[a] = l1[a];
+        d0 = d1;
+        fetch(j - 2 >= jlo ? j - 2 : jlo, l1, d1);
+        const double xj = readlane_f64(x[NA - 1], j - 64 * (NA - 1)) * dc;
+#pragma unroll
+        for(int a = 0; a < NA; a++) x[a] = fma(-lc[a], xj, x[a]);
+      }
+    };
+    segment(std::integral_constant<int, 3>{}, nf - 1, 128);
+    segment(std::integral_constant<int, 2>{}, nf - 1 < 127 ? nf - 1 : 127, 64);
+    segment(std::integral_constant<int, 1>{}, nf - 1 < 63 ? nf - 1 : 63, 0);
 #pragma unroll
     for(int a = 0; a < 3; a++)
-      if(tid + 64 * a < nf) xs[tid + 64 * a] = x[a];
+      if(tid + 64 * a < nf) xs[tid + 64 * a] = x[a] * dinv[tid + 64 * a];
   }
   __syncthreads();
 }
