@@ -2868,19 +2868,10 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   S_TRY(hipMemset(s->status, 0, sizeof(int) * n));
   S_TRY(hipMemset(s->sticky, 0, sizeof(int) * n));
   s->verts = s->vbuf[0];
-  {
-    // The side stream carries the re-projection, which becomes ready at the same instant as the solve on the caller's stream (both
-    // wait for the evaluation).  Whichever kernel the hardware dispatches first takes the CUs: when the face scan's 1536 workgroups
-    // went first, the solve's workgroups (one per frame, 150 KB of LDS, a whole SIMD's registers) waited for them to drain — 77 us
-    // became 105-118 us in most frames of a capture fit, on the critical path.  Lowest priority for the side stream
-    // (SMPLPP_IK_SIDE_PRIORITY=0: default priority).
-    int lo = 0, hi = 0;
-    const char * pe = getenv("SMPLPP_IK_SIDE_PRIORITY");
-    if((!pe || pe[0] != '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-      S_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, lo)); // (lo: the numerically greatest = least priority)
-    else
-      S_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
-  }
+  // (default priority: a lowest-priority side stream — tried against the scan being dispatched ahead of the solve — halved the
+  // latent-IK leg of bench.py, where several solvers' streams exist; what fixes that order is the solve kernel's own "all my
+  // workgroups run" flag, see ik_solve_kernel)
+  S_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
   S_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   S_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   {
