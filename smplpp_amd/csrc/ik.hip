@@ -228,7 +228,7 @@ constexpr int DRS = 28;                        // (27 + one pad word: seven 16-b
 constexpr int L_DR = L_T + NJ * 3;             // [24][DRS]  d R_j / d theta_(j, axis a) at [j][9 a + e]
 // d[A_i | b_i]/d theta_c is non-zero only when joint(c) is an ancestor of i (or i itself), and a joint has exactly one
 // ancestor per depth: the table keeps, per joint, three columns per DEPTH (column slot 3 depth(joint(c)) + axis(c)) instead of
-// all 72 — 41 KB instead of 83 KB of LDS, which is what lets three tasks with a normal term share the ring buffers below.
+// all 72 — 31 KB (nine levels) instead of 83 KB of LDS, which is what lets six tasks with a normal term share the ring buffers below.
 constexpr int DMAX = TREE_DMAX;                     // deepest kinematic tree served (SMPL: 9 levels); smplpp_ik_create checks
 constexpr int L_DAB = L_DR + NJ * DRS;          // [24][CS][3][4]  per (joint, column slot): rows [dA_r | db_r] (one 16-byte LDS access per row)
 constexpr int RVS = 28;                         // floats per ring vertex: rest 3 | Ablend 9 | wsum 1 | posed 3 | weights 4 | joints 4 | their ancestor masks 4
@@ -260,7 +260,7 @@ __device__ inline void lds_barrier()
 #ifndef SMPLPP_EVAL_NT
 #define SMPLPP_EVAL_NT 768
 #endif
-// threads per workgroup of ik_eval_kernel: one workgroup per frame owns a CU (152 KB of LDS), and its phases are bound by
+// threads per workgroup of ik_eval_kernel: one workgroup per frame owns a CU (158 KB of LDS), and its phases are bound by
 // memory latency and per-item instruction count, so more wavefronts per SIMD both hide latency and shorten the item loops —
 // but every instruction all threads execute alike (phase set-up, loop control) costs one issue slot per wavefront: 12
 // wavefronts (170 registers each, nothing spilled) beat 16 by 5 % and 8 by 1 % on the 6-target solve
@@ -946,7 +946,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     }
     __syncthreads();
     if(k_lo == k_begin) EVAL_STAMP(10);
-    // B3n (a task with a normal term / offset is alone in its group): the derivative of each of the three vertex normals,
+    // B3n (tasks with a normal term / offset, up to NGN to a group): the derivative of each of the three vertex normals,
     // one thread per (column, triangle vertex) — the chain n_f -> vn over ~6 adjacent faces is the long part of the
     // kernel for such tasks, and only nq of the 256 threads worked when a column's thread walked all three vertices
     if(ngn > 0) // d vertexNormal_i / dq  

@@ -494,7 +494,7 @@ def test_ik_paired_normal_task_groups_are_bit_identical(smpl, golden_ik_synth, m
 
 def test_ik_eval_mixed_task_kinds_vs_oracle(smpl, oracle_synth):
     """13 tasks per frame, every third one position-only (no normal term, no offset): the evaluation kernel groups the two
-    kinds separately (three normal tasks or any number of position-only ones per pass) in task order."""
+    kinds separately (up to six normal tasks or any number of position-only ones per pass) in task order."""
     from oracle import cpu
     from smplpp_amd import model_io
     from smplpp_amd.ik import IkSolver
