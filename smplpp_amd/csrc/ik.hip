@@ -1168,12 +1168,11 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
                                                       int phi_live, int min_valid, float * __restrict__ pos804,
                                                       double * __restrict__ e_out, double * __restrict__ J_out,
                                                       int * __restrict__ skip, int dbg_stop, int tsplit, const int32_t * __restrict__ roles,
-                                                      unsigned * __restrict__ sig_flag, unsigned * __restrict__ sig_counter, unsigned sig_tick,
                                                       const float * __restrict__ vjac, double * __restrict__ Jl_out)
 {
+  // (the side stream's fork is not raised here but by the solve kernel that follows, once its workgroups run: ik_solve_kernel)
   ik_eval_body<DMAX, RCAP, NGN>(mv, ta, theta25, verts_all, rest_all, Gp, joints, poserot, K, optimize_beta, phi_live, min_valid, pos804, e_out,
                                 J_out, skip, dbg_stop, tsplit, roles, vjac, Jl_out);
-  wg_signal(sig_flag, sig_counter, sig_tick); // (every exit of the body comes through here: a waiting stream is never left behind)
 }
 
 __global__ void ik_actual_normals_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all, int K, int64_t nk)
@@ -3045,15 +3044,13 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   int tsplit = (n < 256) ? (int)(256 / n) : 1; // one round of workgroups (one per CU: its LDS is the evaluation's)
   if(tsplit > K) tsplit = K;
   if(tsplit < 1) tsplit = 1;
-  const bool fork_flag = false; // (flags mode: the fork is signalled by the SOLVE kernel's start, see ik_solve_kernel; the evaluation signals only in events mode)
-  if(s->use_flags) eval_done = nullptr;
+  if(s->use_flags) eval_done = nullptr; // (flags mode: the fork is the solve kernel's start flag; the evaluation's end is signalled in events mode only)
 #define EVAL_(DM, RC, NG)                                                                                                                  \
-  hipExtLaunchKernelGGL((ik_eval_kernel<DM, RC, NG>), dim3((unsigned)(n * tsplit)), dim3(EVAL_NT), shmem, st, nullptr,                    \
-                        fork_flag ? nullptr : eval_done, 0, view_of(m), s->ta, th25, (const float *)s->verts, (const float *)s->rest,       \
-                        (const float *)m->ws.Gp.as<float>(), (const float *)s->joints, (const float *)s->poserot, K, optimize_beta,        \
-                        phi_live, (int)min_valid, s->pts, s->e, s->J, s->skip, s->dbg_stop, tsplit, s->roles,                               \
-                        fork_flag ? s->sig : (unsigned *)nullptr, fork_flag ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork,             \
-                        s->vp ? (const float *)s->vjac : (const float *)nullptr, s->vp ? s->Jl : (double *)nullptr)
+  hipExtLaunchKernelGGL((ik_eval_kernel<DM, RC, NG>), dim3((unsigned)(n * tsplit)), dim3(EVAL_NT), shmem, st, nullptr, eval_done, 0,     \
+                        view_of(m), s->ta, th25, (const float *)s->verts, (const float *)s->rest, (const float *)m->ws.Gp.as<float>(),     \
+                        (const float *)s->joints, (const float *)s->poserot, K, optimize_beta, phi_live, (int)min_valid, s->pts, s->e,     \
+                        s->J, s->skip, s->dbg_stop, tsplit, s->roles, s->vp ? (const float *)s->vjac : (const float *)nullptr,             \
+                        s->vp ? s->Jl : (double *)nullptr)
   if(deep)
     EVAL_(DMAX, 64, 3);
   else
