@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
 #if SKINH_ABL & (256 | 512)
   int dbg_item = 0;
 #endif
-  f32x16 acc[3], macc[2];
+  f32x16 acc[3], macc[3]; // (macc: entry E accumulates in macc[E % 3]; its rows are consumed until the first gap of entry E + 2)
   float tt[3][16]; // [coordinate][accumulator row]: sum_c M[x][c] rest[c] (+ the translation entry), unscaled; the tail applies cw
   v4f areg[HB_KS][2]; // [k-step][piece]: this wavefront's 32 frames, loaded once per frame tile
   v4f bfr[2][3][2];   // [k-step parity][coordinate][piece]: the six fragments of k-step S + 1 are read at MFMAs 2..4 of k-step S,
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
     constexpr int R = decltype(rtag)::value;
     const v4f tr = trb[R & 1];
     if constexpr(R + 1 < 16) trb[(R + 1) & 1] = *reinterpret_cast<const v4f *>(trLane + ((((R + 1) & 3) + 8 * ((R + 1) >> 2)) * 16));
-    const float u = __builtin_fmaf(tt[2][R], cAB, macc[1][R]);
+    const float u = __builtin_fmaf(tt[2][R], cAB, macc[2][R]); // (entry 11: macc[11 % 3])
     ovh = v3f{__builtin_fmaf(tt[0][R], prev.cw, tr.x), __builtin_fmaf(tt[1][R], prev.cw, tr.y), __builtin_fmaf(u, prev.cw, tr.z)};
   };
   auto tail_store = [&](auto rtag) {
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
     // k-step 0 (joints 0..15) takes the three piece products; of k-step 1 only eight k are live (joints 16..23) and both lane
     // halves read the same G' piece, so Ghi1.Whi1 + Ghi1.Wlo1 is ONE MFMA against the weight fragment [Whi1 | Wlo1]
     hstatic_for<12>([&](auto ee) {
-      constexpr int E = decltype(ee)::value, MPE = E & 1;
+      constexpr int E = decltype(ee)::value, MPE = E & 1, ME = E % 3;
       hstatic_for<5>([&](auto bb) {
         constexpr int B = decltype(bb)::value;
         // B: 0 Ghi0.Whi0, 1 Ghi0.Wlo0, 2 Ghi1.[Whi1 | Wlo1], 3 Glo0.Whi0, 4 Glo1.[Whi1 | 0]
@@ -409,12 +409,12 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
 #endif
         if constexpr(SKINH_ABL & 8)
         {
-          if constexpr(B == 0) macc[MPE] = zero16;
+          if constexpr(B == 0) macc[ME] = zero16;
         }
         else if constexpr(B == 0)
-          macc[MPE] = mfma(gfr[MPE][GI], wfr[WI], zero16);
+          macc[ME] = mfma(gfr[MPE][GI], wfr[WI], zero16);
         else
-          macc[MPE] = mfma(gfr[MPE][GI], wfr[WI], macc[MPE]);
+          macc[ME] = mfma(gfr[MPE][GI], wfr[WI], macc[ME]);
         HSB();
         if constexpr(E == 0 && B == 0) h_barrier<h_barrier_vmcnt(HB_KS, HT, WANT_REST)>(); // slot 14: publishes slot 0 of the next item
         if constexpr(E == 0 && B >= 1 && B <= 3) dma(std::integral_constant<int, B - 1>{}, Bnext, HB_KS + 7 - HB_SLOTS, imgS[HB_KS % H_R]);
@@ -430,17 +430,29 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
         }
         if constexpr(E == 11 && B == 4) // root translation of the tail's first row
           trb[0] = *reinterpret_cast<const v4f *>(trLane);
-        if constexpr(E >= 1 && B >= 1 && !(SKINH_ABL & 8)) // entry F = E - 1 = (XF, CF): four rows behind each of MFMAs 1..4 (its last
-        {                                                  // MFMA, issued one gap ago, has retired by then; four VALU fit a gap)
-          constexpr int F = E - 1, XF = F / 4, CF = F % 4, MP = F & 1;
+        // The VALU rows of entry F = (XF, CF) ride behind MFMAs 1..4 of entry F + 1 (three rows each: its last MFMA, issued one gap
+        // before MFMA 1, has retired by then) and behind MFMA 0 of entry F + 2 (the last four): at most four vector instructions
+        // and a fragment read per gap — six FMAs (6/5/5 rows over three gaps) ran ~8 cycles over each gap.  Three accumulators
+        // in rotation, so that entry F + 2's own MFMAs do not touch the one still being read.
+        auto blend_rows = [&](auto ftag, auto r0tag, auto r1tag) {
+          constexpr int F = decltype(ftag)::value, XF = F / 4, CF = F % 4, MF = F % 3, R0 = decltype(r0tag)::value, R1 = decltype(r1tag)::value;
 #pragma unroll
-          for(int r = 4 * (B - 1); r < 4 * B; r++)
+          for(int r = R0; r < R1; r++)
           {
-            if constexpr(CF == 0) tt[XF][r] = macc[MP][r] * acc[0][r];
-            if constexpr(CF == 1) tt[XF][r] = __builtin_fmaf(macc[MP][r], acc[1][r], tt[XF][r]);
-            if constexpr(CF == 2) tt[XF][r] = __builtin_fmaf(macc[MP][r], acc[2][r], tt[XF][r]);
-            if constexpr(CF == 3) tt[XF][r] = __builtin_fmaf(tt[XF][r], cAB, macc[MP][r]);
+            if constexpr(CF == 0) tt[XF][r] = macc[MF][r] * acc[0][r];
+            if constexpr(CF == 1) tt[XF][r] = __builtin_fmaf(macc[MF][r], acc[1][r], tt[XF][r]);
+            if constexpr(CF == 2) tt[XF][r] = __builtin_fmaf(macc[MF][r], acc[2][r], tt[XF][r]);
+            if constexpr(CF == 3) tt[XF][r] = __builtin_fmaf(tt[XF][r], cAB, macc[MF][r]);
           }
+        };
+        if constexpr(!(SKINH_ABL & 8))
+        {
+          if constexpr(E >= 1 && B >= 1)
+            blend_rows(std::integral_constant<int, E - 1>{}, std::integral_constant<int, 3 * (B - 1)>{}, std::integral_constant<int, 3 * B>{});
+          if constexpr(E >= 2 && B == 0)
+            blend_rows(std::integral_constant<int, E - 2>{}, std::integral_constant<int, 12>{}, std::integral_constant<int, 16>{});
+          if constexpr(E == 11 && B == 4) // (entry 10 has no entry 12 behind it; entry 11's rows are the tail's)
+            blend_rows(std::integral_constant<int, 10>{}, std::integral_constant<int, 12>{}, std::integral_constant<int, 16>{});
         }
         if constexpr(WANT_REST && E >= 2 && E <= 9 && B < 2)
         {
