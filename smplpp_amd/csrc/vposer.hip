@@ -33,112 +33,129 @@ constexpr int LAT = SMPLPP_LATENT_DIM; // 32
 constexpr int HID = 512;               // VPoser.h hiddenDim_
 constexpr int OUT6 = 126;              // 6 * 21
 
-struct D6
+// dual number: a value and ND directional derivatives (ND = 6: all six inputs of a joint at once; ND = 1: one direction per
+// thread — the components never mix, so both give the same bits)
+template<int ND>
+struct DN
 {
   float v;
-  float d[6];
+  float d[ND];
 };
-__device__ inline D6 mk(float v)
+typedef DN<6> D6;
+template<int ND>
+__device__ inline DN<ND> mk(float v)
 {
-  D6 r;
+  DN<ND> r;
   r.v = v;
-  for(int i = 0; i < 6; i++) r.d[i] = 0.f;
+  for(int i = 0; i < ND; i++) r.d[i] = 0.f;
   return r;
 }
-__device__ inline D6 operator+(const D6 & a, const D6 & b)
+template<int ND>
+__device__ inline DN<ND> operator+(const DN<ND> & a, const DN<ND> & b)
 {
-  D6 r;
+  DN<ND> r;
   r.v = a.v + b.v;
-  for(int i = 0; i < 6; i++) r.d[i] = a.d[i] + b.d[i];
+  for(int i = 0; i < ND; i++) r.d[i] = a.d[i] + b.d[i];
   return r;
 }
-__device__ inline D6 operator-(const D6 & a, const D6 & b)
+template<int ND>
+__device__ inline DN<ND> operator-(const DN<ND> & a, const DN<ND> & b)
 {
-  D6 r;
+  DN<ND> r;
   r.v = a.v - b.v;
-  for(int i = 0; i < 6; i++) r.d[i] = a.d[i] - b.d[i];
+  for(int i = 0; i < ND; i++) r.d[i] = a.d[i] - b.d[i];
   return r;
 }
-__device__ inline D6 operator*(const D6 & a, const D6 & b)
+template<int ND>
+__device__ inline DN<ND> operator*(const DN<ND> & a, const DN<ND> & b)
 {
-  D6 r;
+  DN<ND> r;
   r.v = a.v * b.v;
-  for(int i = 0; i < 6; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+  for(int i = 0; i < ND; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
   return r;
 }
-__device__ inline D6 operator/(const D6 & a, const D6 & b)
+template<int ND>
+__device__ inline DN<ND> operator/(const DN<ND> & a, const DN<ND> & b)
 {
-  D6 r;
+  DN<ND> r;
   r.v = a.v / b.v;
-  for(int i = 0; i < 6; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
+  for(int i = 0; i < ND; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
   return r;
 }
-__device__ inline D6 operator*(float s, const D6 & a)
+template<int ND>
+__device__ inline DN<ND> operator*(float s, const DN<ND> & a)
 {
-  D6 r;
+  DN<ND> r;
   r.v = s * a.v;
-  for(int i = 0; i < 6; i++) r.d[i] = s * a.d[i];
+  for(int i = 0; i < ND; i++) r.d[i] = s * a.d[i];
   return r;
 }
-__device__ inline D6 operator+(const D6 & a, float s)
+template<int ND>
+__device__ inline DN<ND> operator+(const DN<ND> & a, float s)
 {
-  D6 r = a;
+  DN<ND> r = a;
   r.v += s;
   return r;
 }
-__device__ inline D6 neg(const D6 & a)
+template<int ND>
+__device__ inline DN<ND> neg(const DN<ND> & a)
 {
   return -1.0f * a;
 }
-__device__ inline D6 dsqrt(const D6 & a)
+template<int ND>
+__device__ inline DN<ND> dsqrt(const DN<ND> & a)
 {
-  D6 r;
+  DN<ND> r;
   r.v = sqrtf(a.v);
-  for(int i = 0; i < 6; i++) r.d[i] = a.d[i] / (2.0f * r.v);
+  for(int i = 0; i < ND; i++) r.d[i] = a.d[i] / (2.0f * r.v);
   return r;
 }
-__device__ inline D6 dacos(const D6 & a)
+template<int ND>
+__device__ inline DN<ND> dacos(const DN<ND> & a)
 {
-  D6 r;
+  DN<ND> r;
   r.v = acosf(a.v);
   const float g = -1.0f / sqrtf(1.0f - a.v * a.v);
-  for(int i = 0; i < 6; i++) r.d[i] = g * a.d[i];
+  for(int i = 0; i < ND; i++) r.d[i] = g * a.d[i];
   return r;
 }
-__device__ inline D6 dsin(const D6 & a)
+template<int ND>
+__device__ inline DN<ND> dsin(const DN<ND> & a)
 {
-  D6 r;
+  DN<ND> r;
   r.v = sinf(a.v);
   const float c = cosf(a.v);
-  for(int i = 0; i < 6; i++) r.d[i] = c * a.d[i];
+  for(int i = 0; i < ND; i++) r.d[i] = c * a.d[i];
   return r;
 }
 // torch::nn::functional::normalize of a 3-vector: x / max(||x||, 1e-12) (clamp_min passes no gradient when active)
-__device__ inline void dnormalize3(const D6 * x, D6 * o)
+template<int ND>
+__device__ inline void dnormalize3(const DN<ND> * x, DN<ND> * o)
 {
-  D6 n2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
-  D6 n = dsqrt(n2);
-  if(n.v < 1e-12f) n = mk(1e-12f);
+  DN<ND> n2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+  DN<ND> n = dsqrt(n2);
+  if(n.v < 1e-12f) n = mk<ND>(1e-12f);
   for(int i = 0; i < 3; i++) o[i] = x[i] / n;
 }
 
 // convertRotMatToAxisAngle (src/VPoser.cpp:25-120) on one matrix, value + derivative
-__device__ inline void rotmat_to_aa(const D6 R[3][3], D6 aa[3])
+template<int ND>
+__device__ inline void rotmat_to_aa(const DN<ND> R[3][3], DN<ND> aa[3])
 {
   const float eps = FLT_EPSILON;
   const float epsSqrt = sqrtf(eps);
   const float epsSqrt2 = sqrtf(epsSqrt);
   const float kPi = 3.14159265358979323846f;
-  D6 trace = R[0][0] + R[1][1] + R[2][2];
-  D6 theta = dacos((float)((1.0 - (double)eps) * 0.5) * (trace + (-1.0f))); // :41
-  D6 w[3] = {R[2][1] - R[1][2], R[0][2] - R[2][0], R[1][0] - R[0][1]};      // :43-49
+  DN<ND> trace = R[0][0] + R[1][1] + R[2][2];
+  DN<ND> theta = dacos((float)((1.0 - (double)eps) * 0.5) * (trace + (-1.0f))); // :41
+  DN<ND> w[3] = {R[2][1] - R[1][2], R[0][2] - R[2][0], R[1][0] - R[0][1]};      // :43-49
   if(1.0f + trace.v < epsSqrt2) // near pi (:53-103)
   {
-    D6 tn2[3];
-    D6 one_m_tr = neg(trace) + 1.0f, three_m_tr = neg(trace) + 3.0f;
+    DN<ND> tn2[3];
+    DN<ND> one_m_tr = neg(trace) + 1.0f, three_m_tr = neg(trace) + 3.0f;
     for(int i = 0; i < 3; i++)
     {
-      D6 s = (2.0f * R[i][i] + one_m_tr) / three_m_tr; // :54-56
+      DN<ND> s = (2.0f * R[i][i] + one_m_tr) / three_m_tr; // :54-56
       tn2[i] = dsqrt(s + eps) * theta;                   // :60
     }
     if(theta.v > kPi - 1e-4f) // :62-94
@@ -162,49 +179,63 @@ __device__ inline void rotmat_to_aa(const D6 R[3][3], D6 aa[3])
   }
   else if(fabsf(3.0f - trace.v) < epsSqrt) // near zero: Taylor (:105-111)
   {
-    D6 t2 = theta * theta;
-    D6 f = (1.0f / 6.0f) * t2 + (7.0f / 360.0f) * (t2 * t2) + 1.0f;
+    DN<ND> t2 = theta * theta;
+    DN<ND> f = (1.0f / 6.0f) * t2 + (7.0f / 360.0f) * (t2 * t2) + 1.0f;
     for(int i = 0; i < 3; i++) aa[i] = 0.5f * (w[i] * f);
   }
   else // :112-116
   {
-    D6 f = theta / (2.0f * dsin(theta));
+    DN<ND> f = theta / (2.0f * dsin(theta));
     for(int i = 0; i < 3; i++) aa[i] = w[i] * f;
   }
 }
 
-// ContinousRotReprDecoderImpl::forward (:129-141) on one joint's 6 numbers (view [3,2]) then -> axis-angle
-__device__ inline void sixd_to_aa(const float * o6, float * aa_out, float * jac36 /*[3][6]*/)
+// ContinousRotReprDecoderImpl::forward (:129-141) on one joint's 6 numbers (view [3,2]) then -> axis-angle.  ND = 6: all six
+// derivative directions (jac36 [3][6]); ND = 1: direction `dir` only (jac36 [3]: d aa / d o6[dir])
+template<int ND>
+__device__ inline void sixd_to_aa_dir(const float * o6, int dir, float * aa_out, float * jac)
 {
-  D6 c1[3], c2[3];
+  DN<ND> c1[3], c2[3];
   for(int r = 0; r < 3; r++)
   {
-    c1[r] = mk(o6[2 * r]);
-    c1[r].d[2 * r] = 1.0f;
-    c2[r] = mk(o6[2 * r + 1]);
-    c2[r].d[2 * r + 1] = 1.0f;
+    c1[r] = mk<ND>(o6[2 * r]);
+    c2[r] = mk<ND>(o6[2 * r + 1]);
+    if(ND == 6)
+    {
+      c1[r].d[(2 * r) % ND] = 1.0f;
+      c2[r].d[(2 * r + 1) % ND] = 1.0f;
+    }
+    else
+    {
+      c1[r].d[0] = (2 * r == dir) ? 1.0f : 0.0f;
+      c2[r].d[0] = (2 * r + 1 == dir) ? 1.0f : 0.0f;
+    }
   }
-  D6 a1[3], a2[3], t[3];
+  DN<ND> a1[3], a2[3], t[3];
   dnormalize3(c1, a1);
-  D6 dot = a1[0] * c2[0] + a1[1] * c2[1] + a1[2] * c2[2];
+  DN<ND> dot = a1[0] * c2[0] + a1[1] * c2[1] + a1[2] * c2[2];
   for(int r = 0; r < 3; r++) t[r] = c2[r] - dot * a1[r];
   dnormalize3(t, a2);
-  D6 a3[3] = {a1[1] * a2[2] - a1[2] * a2[1], a1[2] * a2[0] - a1[0] * a2[2], a1[0] * a2[1] - a1[1] * a2[0]};
-  D6 R[3][3];
+  DN<ND> a3[3] = {a1[1] * a2[2] - a1[2] * a2[1], a1[2] * a2[0] - a1[0] * a2[2], a1[0] * a2[1] - a1[1] * a2[0]};
+  DN<ND> R[3][3];
   for(int r = 0; r < 3; r++)
   {
     R[r][0] = a1[r];
     R[r][1] = a2[r];
     R[r][2] = a3[r];
   }
-  D6 aa[3];
+  DN<ND> aa[3];
   rotmat_to_aa(R, aa);
   for(int i = 0; i < 3; i++)
   {
     aa_out[i] = aa[i].v;
-    if(jac36)
-      for(int q = 0; q < 6; q++) jac36[i * 6 + q] = aa[i].d[q];
+    if(jac)
+      for(int q = 0; q < ND; q++) jac[i * ND + q] = aa[i].d[q];
   }
+}
+__device__ inline void sixd_to_aa(const float * o6, float * aa_out, float * jac36 /*[3][6]*/)
+{
+  sixd_to_aa_dir<6>(o6, 0, aa_out, jac36);
 }
 
 // Value-only forward (no Jacobian: decoding a stored latent, node/node.cpp:1376-1391): grid = n frames, block = 256, exact
@@ -639,22 +670,33 @@ __global__ __launch_bounds__(256) void vposer_jac_kernel(const float * __restric
   VPJ_T(4);
   // ---- rotation tail: 6D -> axis-angle and its 3 x 6 Jacobian, one thread per joint; the chain rule into the 32 latent columns
   float * sj = reinterpret_cast<float *>(D2f); // [21][18]
-  if(tid < 21)
+  if(tid < 21 * 6) // one thread per (joint, input direction): the value path six times over, one derivative column each
   {
-    float o6[6], aa[3], j36[18];
-    for(int q = 0; q < 6; q++) o6[q] = so[(tid * 6 + q) * 33 + 32];
-    sixd_to_aa(o6, aa, j36);
-    for(int i = 0; i < 3; i++) out[f * out_stride + tid * 3 + i] = aa[i];
-    for(int q = 0; q < 18; q++) sj[tid * 18 + q] = j36[q];
+    const int j = tid / 6, dir = tid % 6;
+    float o6[6], aa[3], jc[3];
+    for(int q = 0; q < 6; q++) o6[q] = so[(j * 6 + q) * 33 + 32];
+    sixd_to_aa_dir<1>(o6, dir, aa, jc);
+    if(dir == 0)
+      for(int i = 0; i < 3; i++) out[f * out_stride + j * 3 + i] = aa[i];
+    for(int i = 0; i < 3; i++) sj[j * 18 + i * 6 + dir] = jc[i];
   }
   __syncthreads();
   VPJ_T(5);
-  for(int item = tid; item < 63 * LAT; item += 256)
+  // one thread per (joint, latent column): the six tangent entries of the column once for the joint's three output rows
+  for(int item = tid; item < 21 * LAT; item += 256)
   {
-    const int row = item / LAT, c = item % LAT, j = row / 3, i = row % 3;
-    float s = 0.f;
-    for(int q = 0; q < 6; q++) s += sj[j * 18 + i * 6 + q] * so[(j * 6 + q) * 33 + c];
-    jac[(f * 63 + row) * LAT + c] = s;
+    const int j = item / LAT, c = item % LAT;
+    float t6[6];
+#pragma unroll
+    for(int q = 0; q < 6; q++) t6[q] = so[(j * 6 + q) * 33 + c];
+#pragma unroll
+    for(int i = 0; i < 3; i++)
+    {
+      float s = 0.f;
+#pragma unroll
+      for(int q = 0; q < 6; q++) s += sj[j * 18 + i * 6 + q] * t6[q];
+      jac[(f * 63 + j * 3 + i) * LAT + c] = s;
+    }
   }
   VPJ_T(6);
 }
@@ -974,30 +1016,40 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
   VPJ_T(4);
   // ---- rotation tail: 6D -> axis-angle and its 3 x 6 Jacobian, one thread per (frame, joint); the chain rule into the 32 latent
   // columns by all threads
-  if(tid < 21 * NF)
+  static_assert(21 * 6 * NF <= 256, "one thread per (frame, joint, direction)");
+  if(tid < 21 * 6 * NF) // one thread per (frame, joint, input direction): the value path six times over, one derivative column each
   {
-    const int q = tid / 21, j = tid % 21;
+    const int q = tid / (21 * 6), jd = tid % (21 * 6), j = jd / 6, dir = jd % 6;
     const float * so = reinterpret_cast<const float *>(vl + L::D2 + q * VJ_DF);
     float * sj = reinterpret_cast<float *>(vl + L::D2 + q * VJ_DF + 126 * 33 * 4); // [21][18] behind so
-    float o6[6], aa[3], j36[18];
+    float o6[6], aa[3], jc[3];
     for(int i = 0; i < 6; i++) o6[i] = so[(j * 6 + i) * 33 + 32];
-    sixd_to_aa(o6, aa, j36);
-    if(f0 + q < n)
+    sixd_to_aa_dir<1>(o6, dir, aa, jc);
+    if(dir == 0 && f0 + q < n)
       for(int i = 0; i < 3; i++) out[(f0 + q) * out_stride + j * 3 + i] = aa[i];
-    for(int i = 0; i < 18; i++) sj[j * 18 + i] = j36[i];
+    for(int i = 0; i < 3; i++) sj[j * 18 + i * 6 + dir] = jc[i];
   }
   __syncthreads();
   VPJ_T(5);
-  for(int item = tid; item < NF * 63 * LAT; item += 256)
+  // one thread per (frame, joint, latent column): the six tangent entries of the column once for the joint's three output rows
+  for(int item = tid; item < NF * 21 * LAT; item += 256)
   {
-    const int q = item / (63 * LAT), it = item % (63 * LAT);
+    const int q = item / (21 * LAT), it = item % (21 * LAT);
     if(f0 + q >= n) continue;
     const float * so = reinterpret_cast<const float *>(vl + L::D2 + q * VJ_DF);
     const float * sj = reinterpret_cast<const float *>(vl + L::D2 + q * VJ_DF + 126 * 33 * 4);
-    const int row = it / LAT, c = it % LAT, j = row / 3, i = row % 3;
-    float s = 0.f;
-    for(int k = 0; k < 6; k++) s += sj[j * 18 + i * 6 + k] * so[(j * 6 + k) * 33 + c];
-    jac[((f0 + q) * 63 + row) * LAT + c] = s;
+    const int j = it / LAT, c = it % LAT;
+    float t6[6];
+#pragma unroll
+    for(int k = 0; k < 6; k++) t6[k] = so[(j * 6 + k) * 33 + c];
+#pragma unroll
+    for(int i = 0; i < 3; i++)
+    {
+      float s = 0.f;
+#pragma unroll
+      for(int k = 0; k < 6; k++) s += sj[j * 18 + i * 6 + k] * t6[k];
+      jac[((f0 + q) * 63 + j * 3 + i) * LAT + c] = s;
+    }
   }
   VPJ_T(6);
 }
@@ -1031,7 +1083,7 @@ __global__ void rotmat_to_aa_kernel(const float * __restrict__ rot, float * __re
   if(i >= n) return;
   D6 R[3][3], aa[3];
   for(int r = 0; r < 3; r++)
-    for(int c = 0; c < 3; c++) R[r][c] = mk(rot[i * 9 + r * 3 + c]);
+    for(int c = 0; c < 3; c++) R[r][c] = mk<6>(rot[i * 9 + r * 3 + c]);
   rotmat_to_aa(R, aa);
   for(int q = 0; q < 3; q++) aa_out[i * 3 + q] = aa[q].v;
 }
