@@ -1,0 +1,62 @@
+"""Development aid: IK evaluation / iteration over many (frames, tasks, mode) combinations — every shape the evaluation's task
+split, grouping and the solve's forms (dual, primal 6/11 tiles, LDS fall-back) can take — checked against the oracle on one
+frame per combination and for finiteness on all.  usage: python tools/ik_stress.py [seed]"""
+import os, sys, itertools, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from smplpp_amd import model_io
+from smplpp_amd.smpl import SMPL
+from smplpp_amd.ik import IkSolver
+from oracle import cpu
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+rng = np.random.default_rng(seed)
+model = model_io.synthetic_model()
+s = SMPL(); s.setDevice("cuda:0"); s.init(model)
+o = cpu.OracleModel(model)
+ns = [1, 2, 3, 7, 8, 33, 64, 65, 127, 256, 257, 512]
+Ks = [1, 2, 5, 6, 7, 12, 13, 24, 41, 48]
+modes = ["plain", "normal", "offset", "phi", "beta", "mixed"]
+bad = 0; t0 = time.time(); cnt = 0
+for n, K in itertools.product(ns, Ks):
+    if n * K > 512 * 13: continue
+    for mode in modes:
+        beta, theta = model_io.synthetic_inputs(n, seed=int(rng.integers(1 << 30)))
+        theta[:, 1:] *= 0.4
+        faces = rng.integers(0, 13776, (n, K))
+        tp = rng.normal(0, 0.4, (n, K, 3)).astype(np.float32)
+        tn = rng.normal(0, 1, (n, K, 3)).astype(np.float32); tn /= np.linalg.norm(tn, axis=2, keepdims=True)
+        nw = np.zeros((n, K)); noff = np.zeros((n, K)); pl = np.zeros((n, K)); pw = np.ones((n, K)); ob = False
+        if mode == "normal": nw[:] = 1.0
+        if mode == "offset": noff[:] = 0.015
+        if mode == "phi": pl[:] = 0.04; nw[:] = 0.7
+        if mode == "beta": ob = True; nw[:] = 1.0; pl[:] = 0.04
+        if mode == "mixed":
+            nw[:, ::3] = 1.3; noff[:, 1::3] = 0.015; pw[:, ::4] = 0.0; pl[:, ::2] = 0.04
+        sol = IkSolver(s, n, K)
+        sol.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, phi_limit=pl, normal_offset=noff, normal_task_weight=nw, pos_task_weight=pw)
+        sol.setConfig(beta, theta)
+        e, J = sol.eval(optimize_beta=ob)
+        f = int(rng.integers(n))
+        ts = cpu.TaskSet(faces[f], tp[f], tn[f], phi_limit=pl[f], normal_offset=noff[f])
+        ts.normal_task_weight[:] = nw[f]; ts.pos_task_weight[:] = pw[f]
+        r = o.ik_eval(beta[f], theta[f], ts, ob)
+        de = np.abs(r["e"] - e[f]).max(); scale = max(1.0, np.abs(r["J"]).max()); dJ = np.abs(r["J"] - J[f]).max() / scale
+        dJp = np.abs(r["J"] - J[f]).reshape(K, 4, -1)[:, :3].max() / scale
+        # position rows to fp32 rounding; normal rows carry 1 / edge-length amplification (random faces, random normals: entries
+        # of a few hundred with 1e-3 relative noise in fp32 — the same numbers before and after round 3's kernel work)
+        ok = np.isfinite(e).all() and np.isfinite(J).all() and de < 5e-4 and dJp < 1e-5 and dJ < 3e-3
+        e2 = sol.iterate(3, enable_qp=(mode in ("phi", "beta", "mixed")), optimize_beta_from=(1 if ob else -1))
+        _, th = sol.getConfig()
+        ok = ok and np.isfinite(e2).all() and np.isfinite(th).all()
+        cnt += 1
+        if not ok:
+            bad += 1
+            dJr = np.abs(r["J"] - J[f]).reshape(K, 4, -1)
+            k_w, r_w, c_w = np.unravel_index(np.argmax(dJr), dJr.shape)
+            print("FAIL n=%d K=%d mode=%s frame %d: de %.3g dJ %.3g finite %s | worst entry task %d row %d col %d: oracle %.6g engine %.6g; position rows %.3g normal rows %.3g (scale %.3g)"
+                  % (n, K, mode, f, de, dJ, np.isfinite(e2).all(), k_w, r_w, c_w, r["J"].reshape(K, 4, -1)[k_w, r_w, c_w], J[f].reshape(K, 4, -1)[k_w, r_w, c_w],
+                     dJr[:, :3].max() / scale, dJr[:, 3].max() / scale, scale))
+        del sol
+print("%d combinations, %d failures, %.0f s" % (cnt, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
