@@ -43,9 +43,9 @@ for n, K in itertools.product(ns, Ks):
         r = o.ik_eval(beta[f], theta[f], ts, ob)
         de = np.abs(r["e"] - e[f]).max(); scale = max(1.0, np.abs(r["J"]).max()); dJ = np.abs(r["J"] - J[f]).max() / scale
         dJp = np.abs(r["J"] - J[f]).reshape(K, 4, -1)[:, :3].max() / scale
-        # position rows to fp32 rounding; normal rows carry 1 / edge-length amplification (random faces, random normals: entries
+        # position rows to the tests' 1e-4 (the offset term brings a little of the normal rows' noise in); normal rows carry 1 / edge-length amplification (random faces, random normals: entries
         # of a few hundred with 1e-3 relative noise in fp32 — the same numbers before and after round 3's kernel work)
-        ok = np.isfinite(e).all() and np.isfinite(J).all() and de < 5e-4 and dJp < 1e-5 and dJ < 3e-3
+        ok = np.isfinite(e).all() and np.isfinite(J).all() and de < 5e-4 and dJp < 1e-4 and dJ < 3e-3
         e2 = sol.iterate(3, enable_qp=(mode in ("phi", "beta", "mixed")), optimize_beta_from=(1 if ob else -1))
         _, th = sol.getConfig()
         ok = ok and np.isfinite(e2).all() and np.isfinite(th).all()
