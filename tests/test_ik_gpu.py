@@ -670,3 +670,47 @@ def test_ik_eval_more_parts_than_tasks(smpl, oracle_synth):
         assert de[:, :3].max() < 5e-6 and de[:, 3].max() < 1e-4
         scale = max(1.0, np.abs(r["J"]).max())
         assert np.abs(r["J"] - J[f]).max() < 6e-4 * scale
+
+
+def test_ik_primal_solve_with_zero_rows_vs_oracle(smpl, oracle_synth):
+    """A capture-shaped solve in miniature: 24 markers (96 residual rows >= 75 unknowns: the primal, register-tiled form), no
+    normal term on most of them (their fourth row of J is identically zero), a normal offset, and every fifth marker missing
+    (weight 0: four zero rows).  The solve stages and multiplies only the rows that can be non-zero; one step from the same
+    state lands within 1e-4 rad of the oracle's step, for the LLT and for the box-QP form, and again after three iterations."""
+    from oracle import cpu
+    from smplpp_amd import model_io
+    from smplpp_amd.ik import IkSolver
+
+    rng = np.random.default_rng(77)
+    n, K = 5, 24
+    beta, theta = model_io.synthetic_inputs(n, seed=31)
+    theta[:, 1:] *= 0.3
+    hidden = theta.copy()
+    hidden[:, 1:] += rng.normal(0, 0.1, (n, 24, 3)).astype(np.float32)
+    faces = rng.integers(0, 13776, K)
+    f0 = smpl.getFaceIndex()[faces] - 1
+    hv = smpl.launch(beta, hidden, want=("verts",))["verts"]
+    tp = hv[:, f0].mean(axis=2).astype(np.float32)
+    tn = np.tile(np.array([0, 0, 1], np.float32), (n, K, 1))
+    pw = np.ones((n, K)); pw[:, ::5] = 0.0
+    nw = np.zeros((n, K)); nw[:, 3::7] = 0.8
+    for qp in (False, True):
+        s = IkSolver(smpl, n, K)
+        s.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, phi_limit=np.zeros(K), normal_offset=np.full(K, 0.015),
+                   pos_task_weight=pw, normal_task_weight=nw)
+        s.setConfig(beta, theta)
+        for it in (1, 3):
+            _, th_before = s.getConfig()
+            t_before = s.getTasks()
+            e2 = s.iterate(1, enable_qp=qp)
+            _, th_after = s.getConfig()
+            for f in range(n):
+                ts = cpu.TaskSet(t_before["face_idx"][f], tp[f], tn[f], phi_limit=np.zeros(K), normal_offset=np.full(K, 0.015),
+                                 vertex_weights=t_before["vertex_weights"][f])
+                ts.pos_task_weight[:] = pw[f]
+                ts.normal_task_weight[:] = nw[f]
+                _, tho, e2o = oracle_synth.ik_solve(beta[f], th_before[f].reshape(25, 3), ts, 1, enable_qp=qp)
+                assert np.abs(tho - th_after[f].reshape(25, 3)).max() < 1e-4, (qp, it, f)
+                assert abs(e2o - e2[f]) < 5e-5 * max(1.0, e2o), (qp, it, f)
+            if it == 1:
+                s.iterate(1, enable_qp=qp)
