@@ -18,6 +18,19 @@
 // given to one XCD, consecutively, so each 338 KB slice of Bm is pulled into that XCD's L2 once per launch.
 #include "common.h"
 #include "pose_math.h"
+#ifdef POSE_STAMP
+namespace smplpp_hip
+{
+__device__ unsigned long long g_pose_stamps[16];
+}
+#define PST(i) if(blockIdx.x == 512 && threadIdx.x == 0) smplpp_hip::g_pose_stamps[i] = __builtin_amdgcn_s_memtime()
+#define PSTC(i) if(blockIdx.x == 512 && threadIdx.x == 192) smplpp_hip::g_pose_stamps[i] = __builtin_amdgcn_s_memtime()
+extern "C" int smplpp_debug_pose_stamps(unsigned long long * out)
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(smplpp_hip::g_pose_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
+#include "pose_body.h"
 #include "trace.h"
 
 namespace smplpp_hip
@@ -26,346 +39,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------------------------------------- pose kernel
-// LDS traffic of one wavefront is executed in order, so the phases of a single-wavefront section only need the compiler
-// to keep that order (no s_barrier, and no vmcnt(0) drain of outstanding global stores as __syncthreads() would add).
-__device__ __forceinline__ void wave_sync()
-{
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
-// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for every global store
-// issued so far (A operand, rotations, joints) to reach L2 — microseconds per phase in a kernel that is pure latency.
-__device__ __forceinline__ void block_sync_lds()
-{
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// grid = n frames, block = 256 (four wavefronts per frame: the kernel is a chain of dependent latencies, so the work of a
-// frame is spread over as many lanes as it has independent pieces).
-// Trees with at most CT_LEV levels of at most 5 joints (SMPL: 9 levels; ctab != null) take the fast path:
-//   phase 0  theta in, Rodrigues x24 (threads 0..23) BESIDE the 72 joint coordinates (threads 64..135: they need beta and the
-//            folded regressor only); the chain wavefront fetches its table row
-//   barrier 1
-//   phase 1  220 pose/shape coefficients (threads 0..191) BESIDE the kinematic chain (wavefront 3): one tree LEVEL at a time,
-//            lane = (joint of the level, entry of its 3x4 transform), operands from host-built LDS addresses in one batch,
-//            the parent's row by ds_bpermute from the lanes that computed it
-//   barrier 2
-//   phase 2  the fragment chunks of the A operand (A2h / A3), relative transforms G', G2h fragments, 4x4 outputs
-// Other trees: joints in phase 1, the chain in phase 2 with its look-ups in LDS, a third barrier, then the outputs.
-// levels: [nlev + 1] offsets into lvl_joint, then the joints sorted by depth (built at model creation).
-#ifdef POSE_STAMP
-__device__ unsigned long long g_pose_stamps[16];
-#define PST(i) if(blockIdx.x == 512 && threadIdx.x == 0) g_pose_stamps[i] = __builtin_amdgcn_s_memtime()
-#define PSTC(i) if(blockIdx.x == 512 && threadIdx.x == 192) g_pose_stamps[i] = __builtin_amdgcn_s_memtime()
-extern "C" int smplpp_debug_pose_stamps(unsigned long long * out)
-{
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pose_stamps), sizeof(unsigned long long) * 16);
-}
-#else
-#define PST(i)
-#define PSTC(i)
-#endif
-__global__ __launch_bounds__(256) void pose_kernel(const float * __restrict__ beta, const float * __restrict__ theta,
-                                                   const float * __restrict__ J0, const float * __restrict__ JS, const float * __restrict__ JSp,
-                                                   const int32_t * __restrict__ parent, const int32_t * __restrict__ lvl_off,
-                                                   const int32_t * __restrict__ lvl_joint, int nlev, float * __restrict__ AT, int64_t ldA,
-                                                   float * __restrict__ Gp, float * __restrict__ joints_out,
-                                                   float * __restrict__ rot_out, float * __restrict__ xf44_out, int64_t n,
-                                                   uint16_t * __restrict__ A3, _Float16 * __restrict__ A2h,
-                                                   _Float16 * __restrict__ G2h, float gscale, const int32_t * __restrict__ ctab,
-                                                   int * __restrict__ range_flag)
+// (the body: pose_body.h)
+__global__ __launch_bounds__(256) void pose_kernel(PoseArgs a)
 {
   const int64_t f = blockIdx.x;
-  const int tid = threadIdx.x;
-  // rotations [24][9] | joints [24][3] | zero[4] in ONE array: the chain's operand addresses are indices into it (CT_* below)
-  __shared__ float sP[CT_P_SIZE];
-  float(*sR)[9] = reinterpret_cast<float(*)[9]>(sP + CT_P_R);
-  float(*sJ)[3] = reinterpret_cast<float(*)[3]>(sP + CT_P_J);
-  float * const sZero = sP + CT_P_ZERO;
-  __shared__ __attribute__((aligned(16))) float sG[NJ + 1][12]; // global transforms [A | g], 3x4 row-major (+ a spare row: dead chain lanes store there)
-  __shared__ float sBeta[NB];
-  __shared__ float sCoef[224]; // the A operand row of this frame: [c(207) | beta(10) | 1 | 0...]
-  __shared__ int sPar[NJ];
-  __shared__ int sLvl[NJ + 1 + NJ];
-  if(f >= n) return;
-  PST(0);
-  // ---- phase 0 (the folded-regressor rows are fetched now, so their latency overlaps Rodrigues and the first barrier)
-  // fast path (ctab): the joints do not depend on the rotations — threads 64..135 compute them NOW, beside Rodrigues (beta
-  // straight from global memory: a uniform address), so that the chain wavefront can start at the first barrier
-  const int jt = ctab ? ((tid >= 64 && tid < 64 + NJ * 3) ? tid - 64 : -1) : (tid < NJ * 3 ? tid : -1);
-  float j0v = 0.0f, jsv[NB];
-#pragma unroll
-  for(int k = 0; k < NB; k++) jsv[k] = 0.0f;
-  if(jt >= 0)
-  {
-    if(JSp) // [JS row | J0 | 0] in one 48-byte row: three loads instead of eleven
-    {
-      const float4 * row = reinterpret_cast<const float4 *>(JSp + jt * 12);
-      const float4 a = row[0], b = row[1], c = row[2];
-      jsv[0] = a.x; jsv[1] = a.y; jsv[2] = a.z; jsv[3] = a.w;
-      jsv[4] = b.x; jsv[5] = b.y; jsv[6] = b.z; jsv[7] = b.w;
-      jsv[8] = c.x; jsv[9] = c.y;
-      j0v = c.z;
-    }
-    else
-    {
-      j0v = J0[jt];
-#pragma unroll
-      for(int k = 0; k < NB; k++) jsv[k] = JS[jt * NB + k];
-    }
-  }
-  // chain wavefront: this lane's row of the chain table (model.hip, CT_*): per level the joint of its slot, the parent, the
-  // parent's slot, and WHERE its operand lies in sP — in registers
-  int cti[CT_LEV], ctp[CT_LEV], cts[CT_LEV], cta[CT_LEV];
-#pragma unroll
-  for(int L = 0; L < CT_LEV; L++)
-  {
-    cti[L] = ctp[L] = -1;
-    cts[L] = 0;
-    cta[L] = CT_P_ZERO | (CT_P_ZERO << 10) | (1 << 20);
-  }
-  if(ctab && tid >= 192 && tid < 192 + 60)
-  {
-    const int4 * row = reinterpret_cast<const int4 *>(ctab + (tid - 192) * (2 * CT_LEV));
-    int w[2 * CT_LEV];
-#pragma unroll
-    for(int q = 0; q < 2 * CT_LEV / 4; q++)
-    {
-      const int4 v = row[q];
-      w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-    }
-#pragma unroll
-    for(int L = 0; L < CT_LEV; L++)
-    {
-      const int i = w[2 * L] & 0xff, p = (w[2 * L] >> 8) & 0xff;
-      cti[L] = i == 0xff ? -1 : i;
-      ctp[L] = p == 0xff ? -1 : p;
-      cts[L] = (w[2 * L] >> 16) & 0xff;
-      cta[L] = w[2 * L + 1];
-    }
-  }
-  if(tid >= 160 && tid < 160 + NB) sBeta[tid - 160] = beta ? beta[f * NB + (tid - 160)] : 0.0f;
-  if(tid < 4) sZero[tid] = 0.0f;
-  if(!ctab) // (the tree tables in LDS serve the generic chain only)
-  {
-    if(tid >= 128 && tid < 128 + NJ) sPar[tid - 128] = parent[tid - 128];
-    if(tid >= 192 && tid < 192 + nlev + 1) sLvl[tid - 192] = lvl_off[tid - 192];
-    if(tid >= 224 && tid < 224 + NJ) sLvl[NJ + 1 + tid - 224] = lvl_joint[tid - 224];
-  }
-  if(tid < NJ)
-  {
-    float R[9];
-    const float * th = theta + (f * (NJ + 1) + 1 + tid) * 3; // theta[:,1:,:] (src/SMPL.cpp:685-686)
-    rodrigues9(th[0], th[1], th[2], R);
-#pragma unroll
-    for(int q = 0; q < 9; q++) sR[tid][q] = R[q];
-    if(rot_out)
-#pragma unroll
-      for(int q = 0; q < 9; q++) rot_out[(f * NJ + tid) * 9 + q] = R[q];
-  }
-  if(ctab && jt >= 0) // joints (src/JointRegression.cpp:588-590 through the folded regressor)
-  {
-    float be[NB];
-#pragma unroll
-    for(int k = 0; k < NB; k++) be[k] = beta ? beta[f * NB + k] : 0.0f;
-    const float s = joint_coord(j0v, jsv, be);
-    sJ[jt / 3][jt % 3] = s;
-    if(joints_out) joints_out[f * NJ * 3 + jt] = s;
-  }
-  PST(1);
-  block_sync_lds();
-  PST(2);
-  // ---- phase 1: coefficient k = tid (root joint has no pose corrective: src/BlendShape.cpp:884-887) and joint coordinate tid
-  // (fast path: the chain wavefront has its own work in this phase; threads 0..31 take its 32 coefficients too)
-  for(int k = tid; k < 224 && (!ctab || tid < 192); k += ctab ? 192 : 256)
-  {
-    float a = 0.0f;
-    if(k < NP)
-    {
-      const int q = k % 9;
-      a = sR[1 + k / 9][q] - ((q == 0 || q == 4 || q == 8) ? 1.0f : 0.0f);
-    }
-    else if(k < NP + NB)
-      a = sBeta[k - NP];
-    else if(k == K_ONE)
-      a = 1.0f;
-    sCoef[k] = a;
-    if(AT && k < KP) AT[(int64_t)k * ldA + f] = a;
-  }
-  if(!ctab && tid < NJ * 3) // joints (src/JointRegression.cpp:588-590 through the folded regressor)
-  {
-    const float s = joint_coord(j0v, jsv, sBeta);
-    sJ[tid / 3][tid % 3] = s;
-    if(joints_out) joints_out[f * NJ * 3 + tid] = s;
-  }
-  if(tid >= 192 && ctab)
-  {
-    // chain: G_0 = L_0, G_i = G_p(i) . L_i with L_i = [R_i | j_i - j_p(i)] (src/WorldTransformation.cpp:508-610), level by
-    // level; within a level the joints are independent (their parents are one level up).  Rotations and joints are both
-    // complete at the first barrier, so the chain runs beside the coefficient phase.  The lane's operand of every level (a
-    // column of R_i, or the offset j_i - j_p) does not depend on the chain: fetched up front, from addresses the host put
-    // into the table (no per-level address arithmetic: that was half of this wavefront's time).
-    PSTC(8);
-    const int lane = tid - 192, e = lane % 12, r = e / 4, c = e % 4;
-    float * const sGflat = &sG[0][0];
-    float x0[CT_LEV], x1[CT_LEV], x2[CT_LEV];
-#pragma unroll
-    for(int L = 0; L < CT_LEV; L++)
-    {
-      // (every level of the table, live or not — dead ones point at the zero words: one batch of loads, one wait)
-      const float * a = sP + (cta[L] & 0x3ff);
-      const float * b = sP + ((cta[L] >> 10) & 0x3ff);
-      const int st = cta[L] >> 20; // 3: a column of R_i, 1: j_i
-      const float a0 = a[0], a1 = a[st], a2 = a[2 * st], b0 = b[0], b1 = b[1], b2 = b[2];
-      x0[L] = a0 - b0;
-      x1[L] = a1 - b1;
-      x2[L] = a2 - b2;
-      if(ctp[L] < 0) x0[L] = (r == 0) ? x0[L] : (r == 1 ? x1[L] : x2[L]); // root: L_0 = [R_0 | j_0], entry (r, c) itself
-    }
-    PSTC(9);
-    // The parent's row comes out of the REGISTERS of the lanes that computed it one level earlier (ds_bpermute through
-    // __shfl: no LDS write -> wait -> read turn-around per level); the LDS copy is written on the side for phase 3.
-    float vprev = 0.0f;
-#pragma unroll
-    for(int L = 0; L < CT_LEV; L++)
-    {
-      if(L < nlev) // (wave-uniform)
-      {
-        const int i = cti[L], p = ctp[L], src = 12 * cts[L] + r * 4;
-        const float g0 = __shfl(vprev, src + 0, 64), g1 = __shfl(vprev, src + 1, 64), g2 = __shfl(vprev, src + 2, 64),
-                    g3 = __shfl(vprev, src + 3, 64);
-        const float vc = chain_entry(g0, g1, g2, g3, x0[L], x1[L], x2[L], c == 3);
-        const float v = p >= 0 ? vc : x0[L];
-        // (selects instead of a divergent branch: lanes without a joint at this level keep their value and store to a spare word)
-        const bool live = lane < 60 && i >= 0;
-        vprev = live ? v : vprev;
-        sGflat[live ? i * 12 + e : NJ * 12 + (lane & 3)] = v;
-      }
-    }
-    PSTC(10);
-  }
-  block_sync_lds();
-  PST(3);
-  // ---- phase 2
-  if(A3 && tid < 84)
-  {
-    // bf16x3 pieces in MFMA fragment order (layout: common.h): chunk c = k / 8 is element block j of MFMA lane 32 h + r in
-    // k-step ks = c / 2, h = c % 2; thread (c, s) writes the 16 bytes of piece s
-    const int c = tid % 28, sp = tid / 28, ks = c >> 1, h = c & 1;
-    const int64_t ftp = f >> 6;
-    const int fh = (int)((f >> 5) & 1), r = (int)(f & 31);
-    uint16_t pc[8];
-#pragma unroll
-    for(int j = 0; j < 8; j++)
-    {
-      uint16_t p0, p1, p2;
-      split_bf16x3(sCoef[8 * c + j], p0, p1, p2);
-      pc[j] = sp == 0 ? p0 : (sp == 1 ? p1 : p2);
-    }
-    uint16_t * dst = A3 + ((((ftp * BB_KS + ks) * 2 + fh) * 3 + sp) * 64 + (32 * h + r)) * 8;
-    uint4 w;
-    w.x = pc[0] | ((uint32_t)pc[1] << 16);
-    w.y = pc[2] | ((uint32_t)pc[3] << 16);
-    w.z = pc[4] | ((uint32_t)pc[5] << 16);
-    w.w = pc[6] | ((uint32_t)pc[7] << 16);
-    *reinterpret_cast<uint4 *>(dst) = w;
-  }
-  if(A2h && tid >= 96 && tid < 96 + 28)
-  {
-    // fp16x2 pieces in MFMA fragment order (layout: common.h): chunk c = k / 8 is element block j of MFMA lane 32 h + r in
-    // k-step ks = c / 2, h = c % 2; both pieces of the chunk by one thread
-    const int c = tid - 96, ks = c >> 1, h = c & 1;
-    const int64_t ft = f >> 6;
-    const int fh = (int)((f >> 5) & 1), r = (int)(f & 31);
-    f16x8 hi, lo;
-#pragma unroll
-    for(int j = 0; j < 8; j++)
-    {
-      _Float16 a, b;
-      const float xs = sCoef[8 * c + j] * HB_SA;
-      if(!(__builtin_fabsf(xs) <= 65504.0f)) atomicOr(range_flag, 1); // outside fp16's range (|beta| >= 1023) or not finite
-      split_f16x2(xs, a, b);
-      hi[j] = a;
-      lo[j] = b;
-    }
-    _Float16 * dst = A2h + ((((ft * HB_KS + ks) * 2 + fh) * 2) * 64 + (32 * h + r)) * 8;
-    *reinterpret_cast<f16x8 *>(dst) = hi;
-    *reinterpret_cast<f16x8 *>(dst + 64 * 8) = lo;
-  }
-  if(tid >= 192 && !ctab)
-  {
-    // generic trees (deeper than CT_LEV levels or wider than 5 joints per level): the same chain with its look-ups in LDS
-    const int lane = tid - 192, slot = lane / 12, e = lane % 12, r = e / 4, c = e % 4;
-    for(int L = 0; L < nlev; L++)
-    {
-      const int lo = sLvl[L], hi = sLvl[L + 1];
-      for(int q0 = lo; q0 < hi; q0 += 5)
-      {
-        if(slot < 5 && q0 + slot < hi)
-        {
-          const int i = sLvl[NJ + 1 + q0 + slot], p = sPar[i];
-          float v;
-          if(p < 0)
-            v = (c < 3) ? sR[i][r * 3 + c] : sJ[i][r];
-          else if(c < 3)
-            v = chain_entry(sG[p][r * 4 + 0], sG[p][r * 4 + 1], sG[p][r * 4 + 2], 0.0f, sR[i][0 * 3 + c], sR[i][1 * 3 + c], sR[i][2 * 3 + c], false);
-          else
-          {
-            const float t0 = sJ[i][0] - sJ[p][0], t1 = sJ[i][1] - sJ[p][1], t2 = sJ[i][2] - sJ[p][2];
-            v = chain_entry(sG[p][r * 4 + 0], sG[p][r * 4 + 1], sG[p][r * 4 + 2], sG[p][r * 4 + 3], t0, t1, t2, true);
-          }
-          sG[i][e] = v;
-        }
-      }
-      wave_sync();
-    }
-  }
-  PST(4);
-  if(!ctab) block_sync_lds(); // (fast path: the chain finished before the second barrier)
-  PST(5);
-  // ---- phase 3: relative transforms: translation -= A_i . j_i (src/WorldTransformation.cpp:657-677)
-  for(int e = tid; e < NJ * 12; e += 256)
-  {
-    const int i = e / 12, q = e % 12, r = q / 4, c = q % 4;
-    float v = sG[i][q];
-    if(c == 3) v = relative_t(v, sG[i][r * 4 + 0], sG[i][r * 4 + 1], sG[i][r * 4 + 2], sJ[i][0], sJ[i][1], sJ[i][2]);
-    if(Gp) Gp[(f * NJ + i) * 12 + q] = v;
-    if(xf44_out) xf44_out[(f * NJ + i) * 16 + q] = v;
-  }
-  if(xf44_out && tid < NJ * 4) xf44_out[(f * NJ + tid / 4) * 16 + 12 + tid % 4] = (tid % 4 == 3) ? 1.0f : 0.0f;
-  if(G2h && tid >= 64 && tid < 64 + 36)
-  {
-    // the relative transforms once more as the A operand of the blend MFMAs of skin_h.hip (rows = frames, k = joint):
-    // thread (entry e, chunk c) writes both fp16x2 pieces of joints 8 c .. 8 c + 7 of entry e (layout: common.h)
-    const int e = (tid - 64) / 3, c = (tid - 64) % 3, r4 = e / 4, cc = e % 4;
-    const int64_t ft = f >> 6;
-    const int fh = (int)((f >> 5) & 1), r = (int)(f & 31);
-    f16x8 hi, lo;
-#pragma unroll
-    for(int j = 0; j < 8; j++)
-    {
-      const int i = 8 * c + j;
-      float v = sG[i][e];
-      if(cc == 3) v = relative_t(v, sG[i][r4 * 4 + 0], sG[i][r4 * 4 + 1], sG[i][r4 * 4 + 2], sJ[i][0], sJ[i][1], sJ[i][2]);
-      _Float16 a, b;
-      if(!(__builtin_fabsf(v * gscale) <= 65504.0f)) atomicOr(range_flag, 1); // a transform outside 16 x the template's extent
-      split_f16x2(v * gscale, a, b);
-      hi[j] = a;
-      lo[j] = b;
-    }
-    _Float16 * blk = G2h + (((ft * 2 + fh) * 12 + e) * 3072) / 2;
-    if(c < 2)
-    {
-      *reinterpret_cast<f16x8 *>(blk + (32 * c + r) * 8) = hi;
-      *reinterpret_cast<f16x8 *>(blk + 512 + (32 * c + r) * 8) = lo;
-    }
-    else
-    {
-      *reinterpret_cast<f16x8 *>(blk + 1024 + r * 8) = hi;
-      *reinterpret_cast<f16x8 *>(blk + 1024 + 256 + r * 8) = lo;
-    }
-  }
-  PST(6);
+  if(f >= a.n) return;
+  pose_body(a, f, (int)threadIdx.x, a.theta + f * ((NJ + 1) * 3));
 }
 
 // rows [n, ldA) of AT are padding for the last 32-frame tile: keep them zero (re-zeroed whenever n changes)
@@ -567,8 +246,42 @@ hipError_t launch_skin_bf16x3(const smplpp_model * m, int64_t n, const float * t
 hipError_t launch_skin_f16x2(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st);  // skin_h.hip
 
 // Device-pointer FK (enqueue only).  Used by smplpp_fk and by the IK solver.
+// The pose step's arguments for the model's workspace (form h: with_ops adds the fused kernel's operand images; the other forms
+// fill in their own operand).  The workspace buffers must have been reserved (fk_device does, before anything reads the result).
+PoseArgs fk_pose_args(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * joints, float * poserot, float * xforms44,
+                      bool with_ops)
+{
+  Workspace & ws = m->ws;
+  PoseArgs pa;
+  pa.beta = beta;
+  pa.theta = theta;
+  pa.J0 = m->J0;
+  pa.JS = m->JS;
+  pa.JSp = m->JSp;
+  pa.parent = m->parent;
+  pa.lvl_off = m->lvl;
+  pa.lvl_joint = m->lvl + NJ + 1;
+  pa.nlev = m->nlev;
+  pa.AT = nullptr;
+  pa.ldA = 0;
+  pa.Gp = ws.Gp.as<float>();
+  pa.joints_out = joints;
+  pa.rot_out = poserot;
+  pa.xf44_out = xforms44;
+  pa.n = n;
+  pa.A3 = nullptr;
+  pa.A2h = with_ops ? ws.A2h.as<_Float16>() : nullptr;
+  pa.G2h = with_ops ? ws.G2h.as<_Float16>() : nullptr;
+  pa.gscale = m->sG;
+  pa.ctab = m->chain_fast ? m->lvl + CT_OFF : nullptr;
+  pa.range_flag = m->range_flag;
+  return pa;
+}
+
+// pose_done: the pose step's outputs for exactly these inputs are already in the workspace (written by the IK solve kernel at
+// its end: ik.hip) — only the fused kernel is launched
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
-              float * xforms44, float * rest, float * poserot, hipStream_t st)
+              float * xforms44, float * rest, float * poserot, hipStream_t st, bool pose_done)
 {
   Workspace & ws = m->ws;
   // Form of the fused kernel (m->form, from SMPLPP_SKIN at model creation): h (default,
@@ -583,16 +296,17 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
   {
     HIP_TRY(ws.A2h.reserve((size_t)(n64 / 64) * HB_KS * HB_A_BYTES));
     HIP_TRY(ws.G2h.reserve((size_t)(n64 / 64) * HB_G_BYTES));
-    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->JSp, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
-                                                         ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr,
-                                                         (verts || rest) ? ws.A2h.as<_Float16>() : nullptr,
-                                                         (verts || rest) ? ws.G2h.as<_Float16>() : nullptr, m->sG, m->chain_fast ? m->lvl + CT_OFF : nullptr, m->range_flag);
+    if(!pose_done)
+      pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(fk_pose_args(m, n, beta, theta, joints, poserot, xforms44, verts || rest));
   }
   else if(form == 'b')
   {
     HIP_TRY(ws.A3.reserve((size_t)(n64 / 64) * BB_KS * BB_A_BYTES));
-    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->JSp, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, nullptr, 0,
-                                                         ws.Gp.as<float>(), joints, poserot, xforms44, n, ws.A3.as<uint16_t>(), nullptr, nullptr, 1.0f, m->chain_fast ? m->lvl + CT_OFF : nullptr, nullptr);
+    PoseArgs pa = fk_pose_args(m, n, beta, theta, joints, poserot, xforms44, false);
+    pa.A3 = ws.A3.as<uint16_t>();
+    pa.gscale = 1.0f;
+    pa.range_flag = nullptr;
+    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(pa);
   }
   else
   {
@@ -605,8 +319,12 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
       int64_t cnt = (int64_t)KP * (ldA - n);
       zero_pad_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(ws.AT.as<float>(), ldA, n);
     }
-    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(beta, theta, m->J0, m->JS, m->JSp, m->parent, m->lvl, m->lvl + NJ + 1, m->nlev, ws.AT.as<float>(),
-                                                         ldA, ws.Gp.as<float>(), joints, poserot, xforms44, n, nullptr, nullptr, nullptr, 1.0f, m->chain_fast ? m->lvl + CT_OFF : nullptr, nullptr);
+    PoseArgs pa = fk_pose_args(m, n, beta, theta, joints, poserot, xforms44, false);
+    pa.AT = ws.AT.as<float>();
+    pa.ldA = ldA;
+    pa.gscale = 1.0f;
+    pa.range_flag = nullptr;
+    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(pa);
   }
   HIP_TRY(hipGetLastError());
   if(verts || rest)
@@ -703,7 +421,7 @@ extern "C" int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const 
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   TraceRange tr_fwd("forward SMPL"); // the reference's span around SMPL::launch (node/node.cpp:752-781)
-  if(space == SMPLPP_DEVICE) return fk_device(m, n, beta, theta, verts, joints, xforms, rest, nullptr, st);
+  if(space == SMPLPP_DEVICE) return fk_device(m, n, beta, theta, verts, joints, xforms, rest, nullptr, st, false);
 
   Workspace & ws = m->ws;
   const size_t nb = sizeof(float) * (size_t)n * NB, nt = sizeof(float) * (size_t)n * (NJ + 1) * 3;
@@ -718,7 +436,7 @@ extern "C" int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const 
   HIP_TRY(hipMemcpyAsync(ws.theta.p, theta, nt, hipMemcpyHostToDevice, st));
   int rc = fk_device(m, n, ws.beta.as<float>(), ws.theta.as<float>(), verts ? ws.verts.as<float>() : nullptr,
                      joints ? ws.joints.as<float>() : nullptr, xforms ? ws.xf44.as<float>() : nullptr,
-                     rest ? ws.rest.as<float>() : nullptr, nullptr, st);
+                     rest ? ws.rest.as<float>() : nullptr, nullptr, st, false);
   if(rc) return rc;
   if(verts) HIP_TRY(hipMemcpyAsync(verts, ws.verts.p, nv, hipMemcpyDeviceToHost, st));
   if(rest) HIP_TRY(hipMemcpyAsync(rest, ws.rest.p, nv, hipMemcpyDeviceToHost, st));

@@ -28,7 +28,7 @@ struct smplpp_vposer;
 namespace smplpp_hip
 {
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
-              float * xforms44, float * rest, float * poserot, hipStream_t st);
+              float * xforms44, float * rest, float * poserot, hipStream_t st, bool pose_done = false);
 int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
                           float * jac, hipStream_t st);
 
