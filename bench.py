@@ -225,15 +225,20 @@ def main():
                     help="rehearsal on a 1-GPU box: every rank uses GPU 0 (use with --backend gloo)")
     args = ap.parse_args()
 
+    from smplpp_amd import dist as D
+
+    # `python bench.py --gpus N` with no launcher in front starts its own N ranks: fresh child processes, before anything in THIS
+    # process touches the GPU (no torch import yet), rank 0's line forwarded, non-zero exit if any rank fails.  Under
+    # torch.distributed.run (RANK / WORLD_SIZE set) this process is one of the ranks.  A WORLD_SIZE that contradicts --gpus is refused.
+    if D.launch_plan(args.gpus) == "spawn":
+        raise SystemExit(D.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
     import torch
 
-    from smplpp_amd import dist as D
     from smplpp_amd import model_io
     from smplpp_amd.smpl import SMPL
 
     rank, world, local = D.env_rank_world()
-    if world != args.gpus and world != 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     if args.all_ranks_on_device0:
@@ -341,12 +346,20 @@ def main():
         T = int(args.mocap_frames) if args.mocap_frames > 0 else g["points"].shape[0]
         pts = (g["points"][:T] - g["points"][0][g["valid"][0]].mean(axis=0) + np.array([0, -0.3, 0], np.float32)).astype(np.float32)
         mvalid = g["valid"][:T]
-        R = D.shard_sizes(args.mocap_restarts, world)[rank]
-        rng = np.random.default_rng(200 + rank)
+        # the job is defined by its GLOBAL inputs (seeded alike on every rank); a rank takes its contiguous slice, so restart r /
+        # latent frame f is the same problem — and, chain_base / frame_base given, the same bits — on 1, 2, 4 or 8 GPUs
+        rlo, rhi = D.shard_range(args.mocap_restarts, rank, world)
+        R = rhi - rlo
+        rng = np.random.default_rng(200)
+        th0_all = np.zeros((args.mocap_restarts, 25, 3), np.float32)
+        th0_all[:, 1:] = rng.normal(0, 0.03, (args.mocap_restarts, 24, 3))  # the restarts differ in their initial pose
+        gv0_all = np.zeros((args.mocap_restarts, 44), np.float32)
+        gv0_all[:, 6:38] = rng.normal(0, 0.05, (args.mocap_restarts, 32))
+        hidv_all = np.zeros((args.vposer_frames, 25, 3), np.float32)
+        hidv_all[:, 1:22] = rng.normal(0, 0.15, (args.vposer_frames, 21, 3))
         if R > 0:
-            th0 = np.zeros((R, 25, 3), np.float32)
-            th0[:, 1:] = rng.normal(0, 0.03, (R, 24, 3))  # the restarts differ in their initial pose
-            ms = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R)
+            th0 = np.ascontiguousarray(th0_all[rlo:rhi])
+            ms = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R, chain_base=rlo)
             ms.solve(pts, mvalid, np.zeros(10, np.float32), th0, max_frames=2)  # warm-up of the code path
         torch.cuda.synchronize()
         D.barrier()
@@ -371,9 +384,8 @@ def main():
         vp = VPoserDecoder(VPoserDecoder.synthetic_params(seed=3), device=local)
         # the reference's own capture setting (node.cpp:316-322 forces VPoser + QP on): 44-d layout, D = 44 + 2 * 41
         if R > 0:
-            msv = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R, vposer=vp)
-            gv0 = np.zeros((R, 44), np.float32)
-            gv0[:, 6:38] = rng.normal(0, 0.05, (R, 32))
+            msv = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R, vposer=vp, chain_base=rlo)
+            gv0 = np.ascontiguousarray(gv0_all[rlo:rhi])
             msv.solve(pts, mvalid, np.zeros(10, np.float32), gv0, max_frames=2)
         torch.cuda.synchronize()
         D.barrier()
@@ -390,15 +402,15 @@ def main():
         }
 
         Kv = 6
-        nv = D.shard_sizes(args.vposer_frames, world)[rank]
+        vlo, vhi = D.shard_range(args.vposer_frames, rank, world)
+        nv = vhi - vlo
         _, vfaces = reference_task_faces(Kv)
         vt, ev = 0.0, np.zeros(1)
         if nv > 0:
-            hidv = np.zeros((nv, 25, 3), np.float32)
-            hidv[:, 1:22] = rng.normal(0, 0.15, (nv, 21, 3))
+            hidv = np.ascontiguousarray(hidv_all[vlo:vhi])
             hvv = smpl.launch(np.zeros((nv, 10), np.float32), hidv, want=("verts",))["verts"]
             tpv = hvv[:, model["face_indices"][vfaces] - 1].mean(axis=2)
-            vs = IkSolver(smpl, nv, Kv, vposer=vp)
+            vs = IkSolver(smpl, nv, Kv, vposer=vp, frame_base=vlo)
             vs.setTasks(face_idx=vfaces, target_pos=tpv, phi_limit=np.zeros(Kv), normal_task_weight=np.zeros(Kv))
             g0 = np.zeros((nv, vs.theta_dim), np.float32)
         for rep in range(3):

@@ -144,6 +144,11 @@ int smplpp_adjacent_faces(const smplpp_model * m, int64_t vertex, int64_t cap, i
  * Unknown layout per frame: [theta (75, or 44 with a VPoser) | phi (2K) | beta (10 when optimised)] (:787-791). */
 int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_vposer * vposer /*nullable*/, smplpp_ik ** out);
 int smplpp_ik_destroy(smplpp_ik * s);
+/* This solver holds frames [frame_base, frame_base + n) of a larger job (contiguous shards per GPU).  Everything a
+ * frame computes is independent of the frames beside it; the one kernel that orders its fp32 sums by frame position (the VPoser
+ * decoder's Jacobian) takes the position from the GLOBAL index, so a frame's trajectory has the same bits on 1, 2, 4 or 8 GPUs.
+ * Default 0.  No reference counterpart (single device, node/node.cpp:372). */
+int smplpp_ik_set_frame_base(smplpp_ik * s, int64_t frame_base);
 /* IkTask public fields (IkTask.h:54-84), struct-of-arrays over [n,K]; any pointer may be NULL = keep current.
  * Defaults match the header: weights 1, phiLimit 0.04, normalOffset 0, vertexWeights 1/3, targetNormal +Z. */
 int smplpp_ik_set_tasks(smplpp_ik * s, const int64_t * face_idx /*[n,K]*/, const float * vertex_weights /*[n,K,3]*/,
@@ -220,6 +225,12 @@ int smplpp_vposer_destroy(smplpp_vposer * v);
  * jac (nullable) [n,63,32] = d(out)/dz, the quantity autograd supplies in node/node.cpp:761-772. */
 int smplpp_vposer_forward(smplpp_vposer * v, int64_t n, const float * z, float * out, float * jac, int space,
                           void * stream);
+/* The same for a SHARD of a larger job: frame_base = the global index of this call's frame 0.  The Jacobian kernel orders its
+ * fp32 sums by the frame's global index, so a latent decodes to the same bits whether the job runs on 1 GPU or is cut over
+ * 2, 4 or 8 (smplpp_vposer_forward is frame_base = 0).  No reference counterpart: the reference is single-device
+ * (node/node.cpp:372); SURVEY 8(e). */
+int smplpp_vposer_forward_at(smplpp_vposer * v, int64_t n, int64_t frame_base, const float * z, float * out, float * jac, int space,
+                             void * stream);
 /* convertRotMatToAxisAngle (src/VPoser.cpp:25-120): rot [n,3,3] -> aa [n,3]. */
 int smplpp_rotmat_to_axis_angle(int device, int64_t n, const float * rot, float * aa, int space, void * stream);
 

@@ -72,6 +72,7 @@ def load():
         "smplpp_adjacent_faces": [vp, C.c_int64, C.c_int64, i64p, f32p, i64p],
         "smplpp_ik_create": [vp, C.c_int64, C.c_int64, vp, C.POINTER(vp)],
         "smplpp_ik_destroy": [vp],
+        "smplpp_ik_set_frame_base": [vp, C.c_int64],
         "smplpp_ik_set_tasks": [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int],
         "smplpp_ik_set_config": [vp, vp, vp, C.c_int],
         "smplpp_ik_get_config": [vp, vp, vp, C.c_int],
@@ -87,6 +88,7 @@ def load():
         "smplpp_vposer_create": [C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(vp)],
         "smplpp_vposer_destroy": [vp],
         "smplpp_vposer_forward": [vp, C.c_int64, vp, vp, vp, C.c_int, vp],
+        "smplpp_vposer_forward_at": [vp, C.c_int64, C.c_int64, vp, vp, vp, C.c_int, vp],
         "smplpp_rotmat_to_axis_angle": [C.c_int, C.c_int64, vp, vp, C.c_int, vp],
     }
     for name, argtypes in sig.items():

@@ -30,7 +30,7 @@ namespace smplpp_hip
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
               float * xforms44, float * rest, float * poserot, hipStream_t st, bool pose_done = false);
 int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
-                          float * jac, hipStream_t st);
+                          float * jac, hipStream_t st, int64_t frame_base);
 
 constexpr int TD75 = SMPLPP_THETA_DIM;        // 75
 constexpr int TD44 = SMPLPP_LATENT_POSE_DIM;  // 44
@@ -53,6 +53,9 @@ struct TaskArrays
   float * apos;    // [n,K,3]
   float * anrm;    // [n,K,3]
   float * hint;    // [n,K] squared distance of the actual position to the task's own face (cull radius of the re-projection)
+  float * roww;    // [n,K,2] the (position, normal) task weights the LAST evaluation used: what decides which rows of J can be
+                   // non-zero.  Written by ik_eval_kernel, read by ik_solve_kernel on the same stream — posw itself may already
+                   // hold the NEXT frame's validity by then (the sequence driver's switch rides on the side stream's finish kernel)
 };
 
 struct ModelView
@@ -682,6 +685,8 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       e_out[(f * K + k) * 4 + x] = (double)(wp * (ap[x] - tp[x])); // node.cpp:807
     }
     e_out[(f * K + k) * 4 + 3] = e3;
+    ta.roww[(tb + k) * 2] = wp;
+    ta.roww[(tb + k) * 2 + 1] = wn;
     // the re-projection's cull radius when the query point is the actual position (no surface coordinate can move): the
     // exact distance to the task's own face, from the vertices already in registers (same evaluation as the scan's)
     st_agent(&ta.hint[tb + k], tri_sqdist_vals(tri[0], tri[1], tri[2], tri[3], tri[4], tri[5], tri[6], tri[7], tri[8], ap[0], ap[1], ap[2]).x);
@@ -1945,7 +1950,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     for(int c = 0; c < (IK_MAXK * 4 + 63) / 64; c++)
     {
       const int r = 64 * c + (tid & 63), k = (r < rows ? r : 0) >> 2;
-      rl_pre[c] = ((r & 3) == 3) ? ta.nrmw[tb + k] : ta.posw[tb + k];
+      rl_pre[c] = ta.roww[(tb + k) * 2 + (((r & 3) == 3) ? 1 : 0)]; // (the evaluation's copy: see TaskArrays::roww)
     }
   }
   double j_pre[8];
@@ -2602,7 +2607,8 @@ __global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArra
                                                            unsigned * __restrict__ sig_counter, unsigned sig_tick,
                                                            const float * __restrict__ next_tpos, const uint8_t * __restrict__ next_valid)
 {
-  if(next_tpos) // the sequence driver's frame switch (SeqHook): the evaluation that read the old targets is over, the next one waits for this kernel
+  if(next_tpos) // the sequence driver's frame switch (SeqHook): the evaluation that read the old targets is over, the next one
+                // waits for this kernel; the solve running beside it takes its row list from ta.roww, not from posw
   {
     const int64_t f = blockIdx.x / tsplit;
     const int part = (int)(blockIdx.x % tsplit), per_part = (K + tsplit - 1) / tsplit;
@@ -2611,8 +2617,10 @@ __global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArra
     {
       const int64_t i = f * K + k;
       const bool v = next_valid[i] != 0;
-      ta.posw[i] = v ? 1.0f : 0.0f;
-      for(int x = 0; x < 3; x++) ta.tpos[i * 3 + x] = v ? next_tpos[i * 3 + x] : 0.0f;
+      // write-through like everything else a kernel of the other stream reads behind the flag (wg_signal drains this
+      // workgroup's stores to its XCD's L2, not to memory; the next evaluation's workgroups sit on other XCDs)
+      st_agent(&ta.posw[i], v ? 1.0f : 0.0f);
+      for(int x = 0; x < 3; x++) st_agent(&ta.tpos[i * 3 + x], v ? next_tpos[i * 3 + x] : 0.0f);
     }
   }
   proj_finish_body(mv, ta, verts_all, pts, F, K, skip, list_cnt, list_d, list_f, dbg, tsplit);
@@ -2653,6 +2661,7 @@ struct smplpp_ik
   smplpp_model * m = nullptr;
   smplpp_vposer * vp = nullptr;
   int64_t n = 0, K = 0;
+  int64_t frame_base = 0; // global index of frame 0 when this solver holds a shard of a larger job (smplpp_ik_set_frame_base)
   int theta_dim = TD75;
   TaskArrays ta{};
   float *theta = nullptr, *beta = nullptr, *theta25 = nullptr, *vjac = nullptr;
@@ -2729,6 +2738,13 @@ extern "C" int smplpp_ik_destroy(smplpp_ik * s)
   if(s->side) (void)hipStreamDestroy(s->side);
   for(void * p : s->owned) (void)hipFree(p);
   delete s;
+  return SMPLPP_OK;
+}
+
+extern "C" int smplpp_ik_set_frame_base(smplpp_ik * s, int64_t frame_base)
+{
+  if(!s || frame_base < 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_set_frame_base: bad argument");
+  s->frame_base = frame_base;
   return SMPLPP_OK;
 }
 
@@ -2809,6 +2825,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   A_(ta.apos, nk * 3);
   A_(ta.anrm, nk * 3);
   A_(ta.hint, nk);
+  A_(ta.roww, nk * 2);
   A_(theta, (size_t)n * s->theta_dim);
   A_(beta, (size_t)n * NB);
   A_(theta25, (size_t)n * 75);
@@ -3018,7 +3035,7 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
     {
       // the decoder writes its 63 angles straight into theta25[:, 6:69]; the pass-through entries (root translation / rotation,
       // joints 22-23) are kept current by whoever changes the configuration: smplpp_ik_set_config and the solve kernel's update
-      int rc = vposer_forward_device(s->vp, n, s->theta + 6, TD44, s->theta25 + 6, 75, s->vjac, st);
+      int rc = vposer_forward_device(s->vp, n, s->theta + 6, TD44, s->theta25 + 6, 75, s->vjac, st, s->frame_base);
       if(rc) return rc;
       th25 = s->theta25;
     }

@@ -711,6 +711,7 @@ __global__ __launch_bounds__(256) void vposer_jac_kernel(const float * __restric
 // — the B operand of layer 1 is ONE W0 fragment stream (w0h, shared by all frames and workgroups, from L2 like the weights),
 // masked per frame in registers (a 1 KiB mask image per frame in LDS), and C10 = W1 . W0 is a constant of the model added in
 // fp32.  LDS then only holds the layer-1 tangent blocks (64 KiB per frame): NF = 2 fits.
+constexpr int VJ_GROUP = 2; // frames per k-loop rotation group (= the frames per workgroup of the many-frames instantiation)
 template<int NF>
 struct VJ2
 {
@@ -730,12 +731,19 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
                                                           const float * __restrict__ b2, const uint8_t * __restrict__ w1h,
                                                           const uint8_t * __restrict__ w2h, const uint8_t * __restrict__ w0h,
                                                           const float * __restrict__ c10, float sD1, float sD2, float iW1, float iW2,
-                                                          float * __restrict__ out, int64_t out_stride, float * __restrict__ jac, int64_t n)
+                                                          float * __restrict__ out, int64_t out_stride, float * __restrict__ jac, int64_t n,
+                                                          int64_t frame_base)
 {
   typedef VJ2<NF> L;
   extern __shared__ __attribute__((aligned(16))) unsigned char vl[];
   float * red = reinterpret_cast<float *>(vl + L::RED);
-  const int64_t f0 = (int64_t)blockIdx.x * NF;
+  // A frame's bits must not depend on where its shard starts or how many frames run beside it (a job sharded over 1, 4 or 8 GPUs
+  // decodes every latent to the same bits): workgroups are aligned to GROUPS of the GLOBAL frame index (frame_base = the global
+  // index of this launch's frame 0), the k-loop rotation below is a function of the group, and a frame's arithmetic is the same in
+  // every instantiation (its columns of the MFMA tiles never mix with its neighbour's).  f0 = this launch's index of the
+  // workgroup's slot 0: negative in the first workgroup of a shard that starts inside a group.
+  const int64_t group = frame_base / VJ_GROUP + (NF == VJ_GROUP ? (int64_t)blockIdx.x : 0);
+  const int64_t f0 = (NF == VJ_GROUP) ? group * NF - frame_base : (int64_t)blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, l31 = l & 31, lh = l >> 5;
   VPJ_T(0);
   // ---- layer 0 (+ LeakyReLU 0.01), rows tid and tid + 256 of every frame: the 64 weights of the two rows are loaded once
@@ -749,7 +757,8 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
   if(tid >= 128 && tid < 144) reinterpret_cast<float *>(vl + L::RED + 64)[tid - 128] = 0.0f;
   if(tid < NF * LAT)
   {
-    const int64_t f = f0 + tid / LAT < n ? f0 + tid / LAT : n - 1; // (a workgroup's spare frame repeats the last one; never stored)
+    int64_t f = f0 + tid / LAT; // (a workgroup's spare slot repeats a frame of the launch; never stored)
+    f = f < 0 ? 0 : (f < n ? f : n - 1);
     reinterpret_cast<float *>(vl + L::SZ)[tid] = z[f * z_stride + tid % LAT];
   }
   __syncthreads();
@@ -810,7 +819,8 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
       sb[sidx][0] = *reinterpret_cast<const v4fv *>(bp + ks * 2048);
       sb[sidx][1] = *reinterpret_cast<const v4fv *>(bp + ks * 2048 + 1024);
     };
-    const int rot = (int)((blockIdx.x * 5u) & 31u); // (every workgroup starts its k loop elsewhere: see vposer_jac_kernel)
+    // (every workgroup starts its k loop elsewhere: see vposer_jac_kernel; by the GLOBAL group, so that sharding moves no bit)
+    const int rot = (int)(((unsigned long long)(NF == VJ_GROUP ? group : (frame_base + f0) / VJ_GROUP) * 5ull) & 31ull);
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     // LDS operands of a k-step (value tile pieces, one row mask per frame), read one k-step ahead into a second register set
     v4fv vah[2], val[2];
@@ -1025,7 +1035,7 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
     float o6[6], aa[3], jc[3];
     for(int i = 0; i < 6; i++) o6[i] = so[(j * 6 + i) * 33 + 32];
     sixd_to_aa_dir<1>(o6, dir, aa, jc);
-    if(dir == 0 && f0 + q < n)
+    if(dir == 0 && f0 + q >= 0 && f0 + q < n)
       for(int i = 0; i < 3; i++) out[(f0 + q) * out_stride + j * 3 + i] = aa[i];
     for(int i = 0; i < 3; i++) sj[j * 18 + i * 6 + dir] = jc[i];
   }
@@ -1035,7 +1045,7 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
   for(int item = tid; item < NF * 21 * LAT; item += 256)
   {
     const int q = item / (21 * LAT), it = item % (21 * LAT);
-    if(f0 + q >= n) continue;
+    if(f0 + q < 0 || f0 + q >= n) continue;
     const float * so = reinterpret_cast<const float *>(vl + L::D2 + q * VJ_DF);
     const float * sj = reinterpret_cast<const float *>(vl + L::D2 + q * VJ_DF + 126 * 33 * 4);
     const int j = it / LAT, c = it % LAT;
@@ -1089,16 +1099,30 @@ __global__ void rotmat_to_aa_kernel(const float * __restrict__ rot, float * __re
 }
 
 int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
-                          float * jac, hipStream_t st)
+                          float * jac, hipStream_t st, int64_t frame_base)
 {
-  if(jac && v->jac_form == 2 && v->w0h && v->c10 && n > device_cus(v->device))
+  if(jac && v->jac_form == 2 && v->w0h && v->c10)
   {
-    // more frames than CUs: two frames per workgroup share every weight fragment (vposer_jac2_kernel)
-    static PerDeviceOnce once2;
-    HIP_TRY(lds_opt_in(once2, v->device, reinterpret_cast<const void *>(&vposer_jac2_kernel<2>), VJ2<2>::TOTAL));
-    vposer_jac2_kernel<2><<<dim3((unsigned)((n + 1) / 2)), dim3(256), VJ2<2>::TOTAL, st>>>(z, z_stride, v->w0t, v->b0, v->b1, v->b2, v->w1h, v->w2h,
-                                                                                         v->w0h, v->c10, v->sD1, v->sD2, 1.0f / v->sW1,
-                                                                                         1.0f / v->sW2, out, out_stride, jac, n);
+    // One kernel, two instantiations with the SAME arithmetic per frame: more frames than CUs -> two frames per workgroup share
+    // every weight fragment; fewer -> one frame per workgroup.  Either way a frame's bits are a function of the frame and of its
+    // GLOBAL index's group (frame_base + local index) / 2 alone: not of the batch size, not of the shard it travels in.
+    if(n > device_cus(v->device))
+    {
+      static PerDeviceOnce once2;
+      HIP_TRY(lds_opt_in(once2, v->device, reinterpret_cast<const void *>(&vposer_jac2_kernel<2>), VJ2<2>::TOTAL));
+      const int64_t groups = (frame_base % VJ_GROUP + n + VJ_GROUP - 1) / VJ_GROUP;
+      vposer_jac2_kernel<2><<<dim3((unsigned)groups), dim3(256), VJ2<2>::TOTAL, st>>>(z, z_stride, v->w0t, v->b0, v->b1, v->b2, v->w1h, v->w2h,
+                                                                                    v->w0h, v->c10, v->sD1, v->sD2, 1.0f / v->sW1,
+                                                                                    1.0f / v->sW2, out, out_stride, jac, n, frame_base);
+    }
+    else
+    {
+      static PerDeviceOnce once1;
+      HIP_TRY(lds_opt_in(once1, v->device, reinterpret_cast<const void *>(&vposer_jac2_kernel<1>), VJ2<1>::TOTAL));
+      vposer_jac2_kernel<1><<<dim3((unsigned)n), dim3(256), VJ2<1>::TOTAL, st>>>(z, z_stride, v->w0t, v->b0, v->b1, v->b2, v->w1h, v->w2h,
+                                                                               v->w0h, v->c10, v->sD1, v->sD2, 1.0f / v->sW1,
+                                                                               1.0f / v->sW2, out, out_stride, jac, n, frame_base);
+    }
     HIP_TRY(hipGetLastError());
     return SMPLPP_OK;
   }
@@ -1231,7 +1255,13 @@ extern "C" int smplpp_vposer_create(int device, const float * w0, const float * 
 extern "C" int smplpp_vposer_forward(smplpp_vposer * v, int64_t n, const float * z, float * out, float * jac, int space,
                                      void * stream)
 {
-  if(!v || n <= 0 || !z || !out) return fail(SMPLPP_ERR_INVALID, "smplpp_vposer_forward: bad argument");
+  return smplpp_vposer_forward_at(v, n, 0, z, out, jac, space, stream);
+}
+
+extern "C" int smplpp_vposer_forward_at(smplpp_vposer * v, int64_t n, int64_t frame_base, const float * z, float * out, float * jac,
+                                        int space, void * stream)
+{
+  if(!v || n <= 0 || frame_base < 0 || !z || !out) return fail(SMPLPP_ERR_INVALID, "smplpp_vposer_forward: bad argument");
   int rc = check_space(space, "smplpp_vposer_forward");
   if(rc) return rc;
   HIP_TRY(hipSetDevice(v->device));
@@ -1241,7 +1271,7 @@ extern "C" int smplpp_vposer_forward(smplpp_vposer * v, int64_t n, const float *
   HIP_TRY(zi.init(z, (size_t)n * LAT, space, st));
   HIP_TRY(oo.init(out, (size_t)n * 63, space));
   HIP_TRY(jo.init(jac, (size_t)n * 63 * LAT, space));
-  rc = vposer_forward_device(v, n, zi.d, LAT, oo.d, 63, jo.d, st);
+  rc = vposer_forward_device(v, n, zi.d, LAT, oo.d, 63, jo.d, st, frame_base);
   if(rc) return rc;
   hipError_t e = oo.finish(st);
   if(e == hipSuccess) e = jo.finish(st);

@@ -7,7 +7,12 @@ The reference has no counterpart (single process, device index 0: node/node.cpp:
 from __future__ import annotations
 
 import os
-from typing import List, Tuple
+import socket
+import subprocess
+import sys
+import threading
+import time
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -15,6 +20,93 @@ import numpy as np
 def env_rank_world() -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from the torchrun environment; (0, 1, 0) when not launched distributed."""
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def launch_plan(gpus: int, environ=None) -> str:
+    """What a program asked for `gpus` ranks has to do, from its environment alone (no GPU call): "single" (one rank, not
+    launched distributed), "rank" (it IS one rank of a launched job: torchrun or launch_ranks set RANK / WORLD_SIZE), or
+    "spawn" (gpus > 1 and nobody launched the ranks: the program starts them itself, launch_ranks).  A WORLD_SIZE set by
+    someone else that contradicts `gpus` is refused — never silently measured as a smaller job."""
+    environ = os.environ if environ is None else environ
+    if gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    ws = environ.get("WORLD_SIZE")
+    if ws is None:
+        return "single" if gpus == 1 else "spawn"
+    if int(ws) != gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s in the environment: launch %d ranks, or unset WORLD_SIZE and let the "
+                         "program start its own" % (gpus, ws, gpus))
+    return "single" if gpus == 1 else "rank"
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(argv: Sequence[str], world: int, extra_env: Optional[dict] = None, timeout: Optional[float] = None,
+                 stdout=None, stderr=None) -> int:
+    """Start `world` FRESH child processes of `argv` — one per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT in their environment, rendezvous on 127.0.0.1 — wait for them, forward rank 0's stdout (the ranks' stderr
+    goes to ours, prefixed by nothing: they are few) and return 0 only if every rank exited 0.  The caller must not have
+    touched the GPU: children are new processes (fork + exec of the interpreter), never a re-exec of this one.  When a rank
+    fails the others are terminated (their own process handles only), so a dead peer cannot leave the job hanging in a
+    barrier; the first non-zero exit code is returned."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    stdout = sys.stdout if stdout is None else stdout
+    stderr = sys.stderr if stderr is None else stderr
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+
+    def pump(src, dst):
+        for ln in src:
+            dst.write(ln)
+            dst.flush()
+
+    threads = [threading.Thread(target=pump, args=(procs[0].stdout, stdout), daemon=True)]
+    threads += [threading.Thread(target=pump, args=(p.stderr, stderr), daemon=True) for p in procs]
+    for t in threads:
+        t.start()
+    t0 = time.monotonic()
+    rc = 0
+    live = set(range(world))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0 and rc == 0:
+                rc = c
+                stderr.write("launch_ranks: rank %d exited with %d; stopping the other ranks\n" % (r, c))
+        timed_out = timeout is not None and time.monotonic() - t0 > timeout
+        if (rc != 0 or timed_out) and live:
+            if timed_out and rc == 0:
+                rc = 124
+                stderr.write("launch_ranks: timeout after %.0f s\n" % timeout)
+            for r in live:
+                procs[r].terminate()
+            for r in sorted(live):
+                try:
+                    procs[r].wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            live.clear()
+        if live:
+            time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
+    return rc
 
 
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:

@@ -121,12 +121,13 @@ class VPoserDecoder:
                                      + np.tile(np.array([1, 0, 0, 1, 0, 0], np.float32), 21)).astype(np.float32)
         return out
 
-    def forward(self, latent, want_jac=False):
+    def forward(self, latent, want_jac=False, frame_base=0):
+        """`frame_base`: global index of latent[0] when the call decodes a shard of a larger job (same bits as the unsharded call)."""
         z = _np32(latent).reshape(-1, 32)
         n = z.shape[0]
         out = np.empty((n, 21, 3), np.float32)
         jac = np.empty((n, 63, 32), np.float32) if want_jac else None
-        check(_lib.load().smplpp_vposer_forward(self._h, n, _ptr(z), _ptr(out), _ptr(jac), HOST, None))
+        check(_lib.load().smplpp_vposer_forward_at(self._h, n, int(frame_base), _ptr(z), _ptr(out), _ptr(jac), HOST, None))
         return (out, jac) if want_jac else out
 
     def __del__(self):
@@ -149,12 +150,15 @@ def convertRotMatToAxisAngle(rotMat, device=0):
 class IkSolver:
     """The loop body of node/node.cpp:645-1002 for `n` independent frames with `K` tasks each."""
 
-    def __init__(self, smpl: SMPL, n: int, K: int, vposer: Optional[VPoserDecoder] = None):
+    def __init__(self, smpl: SMPL, n: int, K: int, vposer: Optional[VPoserDecoder] = None, frame_base: int = 0):
+        """`frame_base`: global index of this solver's frame 0 when it holds one shard of a larger job (dist.shard_range)."""
         self.smpl, self.n, self.K, self.vposer = smpl, int(n), int(K), vposer
         self.theta_dim = LATENT_POSE_DIM if vposer is not None else 75
         h = C.c_void_p()
         check(_lib.load().smplpp_ik_create(smpl.handle, self.n, self.K, vposer._h if vposer is not None else None, C.byref(h)))
         self._h = h
+        if frame_base:
+            check(_lib.load().smplpp_ik_set_frame_base(self._h, int(frame_base)))
         self.task_names: Optional[List[str]] = None
 
     def __del__(self):

@@ -185,12 +185,14 @@ class MocapMotionSolver:
 
     WARMUP_ITERS = 32  # frame 0 is solved in passes ikIter = 0..31: the store block (ikIter > 30, node/node.cpp:1369) follows the solve
 
-    def __init__(self, smpl, face_idx, vertex_weights, restarts: int, vposer=None, marker_thickness=0.015):
+    def __init__(self, smpl, face_idx, vertex_weights, restarts: int, vposer=None, marker_thickness=0.015, chain_base: int = 0):
+        """`chain_base`: global index of this solver's chain 0 when it holds one GPU's share of the chains (dist.shard_range):
+        a chain's trajectory has the same bits whichever shard it runs in."""
         from .ik import IkSolver
 
         self.K = len(face_idx)
         self.R = restarts
-        self.solver = IkSolver(smpl, restarts, self.K, vposer=vposer)
+        self.solver = IkSolver(smpl, restarts, self.K, vposer=vposer, frame_base=chain_base)
         self.vposer = vposer
         K = self.K
         self.solver.setTasks(face_idx=np.asarray(face_idx, np.int64), vertex_weights=np.asarray(vertex_weights, np.float32),
@@ -254,14 +256,14 @@ class MocapBodySolver:
     BETA_FROM = 25   # optimizeBeta = ikIter >= 25 (:655); phiLimit_ = ikIter < 25 ? 0 : 0.04 (:695)
     PHI_LIMIT = 0.04
 
-    def __init__(self, smpl, names: Sequence[str], restarts: int = 1, vposer=None, marker_thickness=0.015):
+    def __init__(self, smpl, names: Sequence[str], restarts: int = 1, vposer=None, marker_thickness=0.015, chain_base: int = 0):
         from .ik import IkSolver
 
         self.names = sorted(names)  # std::map<std::string, IkTask> order (node.cpp:47, 798)
         self.faces = np.array([BASELINE41[n] for n in self.names], np.int64)
         self.K = len(self.names)
         self.R = restarts
-        self.solver = IkSolver(smpl, restarts, self.K, vposer=vposer)
+        self.solver = IkSolver(smpl, restarts, self.K, vposer=vposer, frame_base=chain_base)
         K = self.K
         self.solver.setTasks(face_idx=self.faces, vertex_weights=np.full((K, 3), 1 / 3, np.float32),
                              normal_task_weight=np.zeros(K), normal_offset=np.full(K, marker_thickness),

@@ -36,3 +36,21 @@ def test_bench_prints_one_contract_line():
     ex = d["exact_form"]
     assert "bf16x3" in ex["dtype"] and ex["value"] > 1e4 and ex["kernel_ms"] > 0 and ex["ms_per_step"] >= ex["kernel_ms"]
     assert ex["roofline"]["bound"] in ("hbm", "mfma") and ex["roofline"]["hbm"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher in front (the way the driver starts --gpus 1): bench.py spawns two fresh rank
+    processes before touching the GPU and forwards rank 0's line.  On a one-GPU box both ranks share GPU 0 and the control
+    plane is gloo (the rehearsal switches); on an 8-GPU node the same command without them runs RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3", "--ik-iters", "5",
+                        "--no-cpu-baseline", "--sustained-steps", "100", "--mocap-frames", "60", "--no-exact-form", "--backend", "gloo",
+                        "--all-ranks-on-device0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_reported_by_rccl"] == 2 and d["final_gather_ms"] > 0
+    assert d["mocap"]["restarts_this_rank"] == 32 and d["vposer_ik"]["frames_this_rank"] == 256
+    assert d["value"] > 1e4

@@ -97,3 +97,73 @@ def test_gather_offsets_host_arithmetic():
     assert L.smplpp_gather_offsets(bad, 2, 4, offs) != 0
     huge = (C.c_int64 * 2)(2**40, 2**40)
     assert L.smplpp_gather_offsets(huge, 2, 2**30, offs) != 0  # overflow is refused, not wrapped
+
+
+# ---- the launcher a program asked for `--gpus N` uses when nobody started its ranks (bench.py)
+def test_launch_plan():
+    assert D.launch_plan(1, {}) == "single"
+    assert D.launch_plan(8, {}) == "spawn"
+    assert D.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3"}) == "rank"
+    assert D.launch_plan(1, {"WORLD_SIZE": "1"}) == "single"
+    for gpus, ws in [(8, "1"), (2, "4"), (1, "2")]:  # someone else's WORLD_SIZE contradicts --gpus: refused, never measured as a smaller job
+        with pytest.raises(SystemExit):
+            D.launch_plan(gpus, {"WORLD_SIZE": ws})
+    with pytest.raises(SystemExit):
+        D.launch_plan(0, {})
+
+
+LAUNCHED = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch
+from smplpp_amd import dist as D
+d = D.init_process_group("gloo")
+rank, world, local = D.env_rank_world()
+assert world == 2 and local == rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
+if {fail!r} and rank == 1:
+    sys.exit(3)
+full = D.gather_rows(torch.full((1, 2), float(rank)), 2)
+m = D.max_over_ranks(float(rank))
+print("not the line: rank", rank, file=sys.stderr)
+if rank == 0:
+    print('{{"n_gpus": %d, "sum": %g, "max": %g}}' % (world, float(full.sum()), m))
+else:
+    print("a rank other than 0 printed to stdout: must not be forwarded")
+D.barrier()
+d.destroy_process_group()
+"""
+
+
+def test_launch_ranks_two_gloo_ranks(tmp_path):
+    import io
+
+    script = tmp_path / "launched.py"
+    script.write_text(LAUNCHED.format(root=ROOT, fail=False))
+    out, err = io.StringIO(), io.StringIO()
+    rc = D.launch_ranks([sys.executable, str(script)], 2, timeout=120, stdout=out, stderr=err)
+    assert rc == 0, err.getvalue()
+    lines = [ln for ln in out.getvalue().splitlines() if ln.strip() and not ln.startswith("[Gloo]")]  # (gloo's own chatter goes to stdout)
+    assert lines == ['{"n_gpus": 2, "sum": 2, "max": 1}'], (lines, err.getvalue())
+
+
+def test_launch_ranks_a_failing_rank_stops_the_job(tmp_path):
+    import io
+
+    script = tmp_path / "launched.py"
+    script.write_text(LAUNCHED.format(root=ROOT, fail=True))  # rank 1 exits 3 while rank 0 waits in the gather
+    out, err = io.StringIO(), io.StringIO()
+    rc = D.launch_ranks([sys.executable, str(script)], 2, timeout=120, stdout=out, stderr=err)
+    assert rc == 3 and "rank 1 exited with 3" in err.getvalue()
+    assert "n_gpus" not in out.getvalue()
+
+
+def test_bench_starts_its_own_ranks_and_refuses_a_contradicting_world_size():
+    """No GPU here: each rank bench.py starts fails loudly ("needs an MI355X"), and the parent — which must not have touched the
+    GPU or torch.distributed itself — reports it and exits non-zero; WORLD_SIZE=1 with --gpus 2 is refused outright."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-ik"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert r.stderr.count("bench.py needs an MI355X") >= 1 and "launch_ranks: rank" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

@@ -208,3 +208,58 @@ def test_latent_ik_config4_size_512_frames_50_iterations(decoders, synth_model, 
     # (with random decoder weights the targets — poses drawn in joint-angle space — lie outside the decoder's range: the solves
     # settle at residuals of 3e-3..6e-2 instead of converging, which is what makes their last steps worth checking above)
     assert (e2 < e2_first).mean() > 0.9
+
+
+def test_decoder_bits_do_not_depend_on_the_shard(decoders):
+    """a latent must decode — value AND Jacobian — to the same bits whether the job runs as one 512-frame
+    batch or cut into shards (BASELINE configs[4]: 512 frames over 4 GPUs).  The Jacobian kernel rotates its k loop by the frame's
+    GLOBAL group (frame_base + local index) / 2, and the one-frame-per-workgroup instantiation (shards of fewer frames than CUs)
+    does the same arithmetic per frame as the two-frame one.  Shards starting on even AND odd global indices, and a one-frame shard."""
+    gpu, _ = decoders
+    rng = np.random.default_rng(31)
+    n = 512
+    z = rng.normal(0, 1.0, (n, 32)).astype(np.float32)
+    out, jac = gpu.forward(z, want_jac=True)
+    for lo, hi in [(128, 256), (0, 128), (129, 256), (255, 512), (300, 301), (1, 512)]:
+        o, j = gpu.forward(z[lo:hi], want_jac=True, frame_base=lo)
+        assert np.array_equal(o, out[lo:hi]), (lo, hi)
+        assert np.array_equal(j, jac[lo:hi]), (lo, hi)
+    # (the guard that makes the test meaningful: WITHOUT the base the rotation differs and so do the last bits somewhere)
+    o0, j0 = gpu.forward(z[128:256], want_jac=True, frame_base=0)
+    assert np.abs(j0 - jac[128:256]).max() < 1e-4
+
+
+def test_latent_ik_trajectory_does_not_depend_on_the_shard(decoders, synth_model):
+    """The same property through the whole latent IK loop (decoder -> FK -> evaluation -> solve -> re-projection), 8 iterations:
+    frames 256..383 of a 512-frame job == the same frames as a 128-frame shard with frame_base = 256, bit for bit."""
+    from smplpp_amd.ik import IkSolver, reference_task_faces
+    from smplpp_amd.smpl import SMPL
+
+    gpu, _ = decoders
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(synth_model)
+    K, n = 6, 512
+    _, faces = reference_task_faces(K)
+    rng = np.random.default_rng(33)
+    hid = np.zeros((n, 25, 3), np.float32)
+    hid[:, 1:22] = rng.normal(0, 0.15, (n, 21, 3))
+    hv = s.launch(np.zeros((n, 10), np.float32), hid, want=("verts",))["verts"]
+    tp = hv[:, synth_model["face_indices"][faces] - 1].mean(axis=2)
+    g0 = np.zeros((n, 44), np.float32)
+    g0[:, 6:38] = rng.normal(0, 0.3, (n, 32))
+
+    def run(lo, hi):
+        sol = IkSolver(s, hi - lo, K, vposer=gpu, frame_base=lo)
+        sol.setTasks(face_idx=faces, target_pos=np.ascontiguousarray(tp[lo:hi]), phi_limit=np.zeros(K), normal_task_weight=np.zeros(K))
+        sol.setConfig(np.zeros((hi - lo, 10), np.float32), np.ascontiguousarray(g0[lo:hi]))
+        e2 = sol.iterate(8)
+        _, th = sol.getConfig()
+        t = sol.getTasks()
+        return e2, th, t["face_idx"], t["vertex_weights"]
+
+    full = run(0, n)
+    for lo, hi in [(256, 384), (383, 512)]:
+        part = run(lo, hi)
+        for a, b in zip(part, full):
+            assert np.array_equal(a, b[lo:hi]), (lo, hi)
