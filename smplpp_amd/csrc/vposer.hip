@@ -13,6 +13,12 @@
 #include <cmath>
 #include <vector>
 
+// Contraction decided by the SOURCE, not by the back end: a * b + c inside one expression is an fma, across statements it is not.
+// (Under hipcc's default, fp-contract=fast, the instruction selector fuses wherever a product has a single use — and the one- and
+// two-frame instantiations of vposer_jac2_kernel, whose products have different use counts, then rounded the SAME frame
+// differently: a frame's bits must not depend on the batch it travels in.)
+#pragma clang fp contract(on)
+
 struct smplpp_vposer
 {
   int device = 0;

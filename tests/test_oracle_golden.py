@@ -202,3 +202,27 @@ def test_closest_points_and_weights_roundtrip(oracle_synth, synth_model):
     # a point off the surface projects onto the mesh
     face, closest, sq = oracle_synth.closest_points(v, pts + np.float32(0.01) * np.array([[0, 0, 1.0]], np.float32))
     assert (sq > 0).all() and (sq <= 1.0001e-4).all()
+
+
+def test_oracle_vs_reference_autograd_on_the_sweep_outliers(synth_model):
+    """The IK sweep's named outliers (tests/ik_stress_cases.py: KNOWN_OUTLIERS — task faces with a sliver among the faces around
+    them): the fp64 oracle against the reference's OWN fp32 autograd residual and Jacobian on exactly those frames
+    (tests/golden/ik_outliers.npz, generated in the build container by oracle/gen_outliers.py through oracle/_ref).  The oracle's
+    deviation is the reference's fp32 rounding: position-class rows 1e-6, rows through a vertex normal 1e-3, residual 1e-4."""
+    import ik_stress_cases as S
+
+    g = np.load(os.path.join(GOLDEN, "ik_outliers.npz"))
+    assert sorted(g["keys"]) == sorted(S.KNOWN_OUTLIERS)
+    o = cpu.OracleModel(synth_model)
+    adj = np.load(os.path.join(GOLDEN, "ik_synth.npz"))["adjacency"]
+    for v in range(o.V):
+        o.set_adjacency(v, adj[v][adj[v] >= 0])
+    for k in g["keys"]:
+        c = S.make_case(*S.parse_key(k))
+        assert c["f"] == int(g[k + "/frame"])
+        r = S.oracle_eval(o, c)
+        rJ = g[k + "/ref_J"].astype(np.float64)
+        de = float(np.abs(g[k + "/ref_e"] - r["e"]).max())
+        dp, dn = S.deviations(rJ, r["J"], c)
+        assert de < 1e-4 and dp < 1e-6 and dn < 1e-3, (k, de, dp, dn)
+        assert np.allclose([de, dp, dn], g[k + "/oracle_dev"], rtol=1e-3, atol=1e-9)  # the yardstick the GPU test reads
