@@ -184,8 +184,12 @@ int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * target_pos,
 int smplpp_ik_get_vertices(smplpp_ik * s, float * verts, int space, void * stream);
 /* Outcome of the solves so far, per frame: bit 0 = the LAST solve failed with the reference's "LLT has numerical issue!"
  * (node/node.cpp:934-937; that frame's update was skipped), bit 1 = some solve failed since the configuration was set /
- * the sequence started.  Host-space iterate / solve_sequence calls return SMPLPP_ERR_NUMERIC themselves; enqueue-only
- * (SMPLPP_DEVICE) callers have no return value to inspect and read it here (waits for `stream` first). flags [n]. */
+ * the sequence started, bit 2 = an evaluation since then met a task WITH A NORMAL TERM (normal weight or normal offset) on a
+ * vertex of more than 12 adjacent faces: the analytic Jacobian differentiates vertex normals through tables of 12 faces per vertex
+ * (src/SMPL.cpp:527-535 puts no bound on it), so those rows are unsupported; position-only tasks are unaffected and any model gets
+ * its solver.  Host-space eval / iterate / solve_sequence calls return SMPLPP_ERR_NUMERIC (bits 0, 1) or SMPLPP_ERR_INVALID
+ * (bit 2) themselves; enqueue-only (SMPLPP_DEVICE) callers have no return value to inspect and read it here (waits for `stream`
+ * first). flags [n]. */
 int smplpp_ik_get_status(smplpp_ik * s, int32_t * flags, int space, void * stream);
 
 /* Streams and sharing.  A model owns ONE workspace (pose coefficients, relative transforms of the last forward pass) that

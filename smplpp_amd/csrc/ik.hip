@@ -53,6 +53,8 @@ struct TaskArrays
   float * apos;    // [n,K,3]
   float * anrm;    // [n,K,3]
   float * hint;    // [n,K] squared distance of the actual position to the task's own face (cull radius of the re-projection)
+  int * flags;     // [n] sticky per-frame status word (smplpp_ik_get_status): bit 0 a solve failed, bit 2 a task with a normal term
+                   // touches a vertex with more than MAXADJ adjacent faces (its Jacobian rows are not supported)
   float * roww;    // [n,K,2] the (position, normal) task weights the LAST evaluation used: what decides which rows of J can be
                    // non-zero.  Written by ik_eval_kernel, read by ik_solve_kernel on the same stream — posw itself may already
                    // hold the NEXT frame's validity by then (the sequence driver's switch rides on the side stream's finish kernel)
@@ -607,8 +609,11 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       const int u = s_ringb[t][1 + i];
       const int cnt = s_acnt[t][i];
       float vn[3];
-      if(cnt > MAXADJ) // more faces than the ring map covers: the general routine
+      if(cnt > MAXADJ) // more faces than the ring map covers: the general routine for the VALUE; the derivative tables of phase
+      {                // B hold MAXADJ faces per vertex, so the frame is flagged and host-space callers get an error
         vertex_normal_dev(verts, mv.faces, mv.adjOff, mv.adjFace, u, vn);
+        atomicOr(&ta.flags[f], 4);
+      }
       else
       {
         float sum = 0.0f;
@@ -2346,7 +2351,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   if(tid == 0)
   {
     status[f] = s_bad ? 1 : ((enable_qp && !s_done) ? 2 : 0);
-    if(s_bad) sticky[f] = 1; // survives later solves (sequence driver)
+    if(s_bad) sticky[f] = sticky[f] | 1; // survives later solves (sequence driver); bit 2 is the evaluation's (TaskArrays::flags)
   }
   const bool ok = !s_bad;
   // config update (node.cpp:945-968), fp32
@@ -2782,9 +2787,8 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   if(K > PROJ_MAXK) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: at most 48 tasks per frame are supported");
   if(TD75 + 2 * K + NB > MAXD)
     return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: too many tasks for the in-LDS solver (75 + 2K + 10 must be <= 181)");
-  int maxadj = 0;
-  for(int64_t v = 0; v < m->V; v++) maxadj = std::max(maxadj, (int)(m->h_adjOff[v + 1] - m->h_adjOff[v]));
-  if(maxadj > MAXADJ) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: a vertex has more than 12 adjacent faces");
+  // (a vertex with more than MAXADJ = 12 adjacent faces does not stop the solver from being created: position-only tasks anywhere and
+  // normal-term tasks away from such a vertex are unaffected; a normal-term task that touches one is reported when it is evaluated)
   HIP_TRY(hipSetDevice(m->device));
   smplpp_ik * s = new smplpp_ik();
   s->m = m;
@@ -2846,6 +2850,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   A_(skip, (size_t)n);
   A_(status, (size_t)n);
   A_(sticky, (size_t)n);
+  s->ta.flags = s->sticky;
   if(vposer)
   {
     A_(Jl, nk * 4 * Dmax);
@@ -3078,6 +3083,8 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   return SMPLPP_OK;
 }
 
+static int ik_check_valence(smplpp_ik * s);
+
 extern "C" int smplpp_ik_eval(smplpp_ik * s, int optimize_beta, double * e, double * J, int space, void * stream)
 {
   if(!s) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_eval: null solver");
@@ -3091,7 +3098,11 @@ extern "C" int smplpp_ik_eval(smplpp_ik * s, int optimize_beta, double * e, doub
   hipMemcpyKind kind = space == SMPLPP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   if(e) HIP_TRY(hipMemcpyAsync(e, s->e, sizeof(double) * s->n * s->K * 4, kind, st));
   if(J) HIP_TRY(hipMemcpyAsync(J, s->vp ? s->Jl : s->J, sizeof(double) * s->n * s->K * 4 * D, kind, st));
-  if(space == SMPLPP_HOST) HIP_TRY(hipStreamSynchronize(st));
+  if(space == SMPLPP_HOST)
+  {
+    HIP_TRY(hipStreamSynchronize(st));
+    if((rc = ik_check_valence(s))) return rc;
+  }
   return SMPLPP_OK;
 }
 
@@ -3257,7 +3268,19 @@ static int ik_check_status(smplpp_ik * s, const int * flags)
   std::vector<int> h((size_t)s->n);
   HIP_TRY(hipMemcpy(h.data(), flags, sizeof(int) * s->n, hipMemcpyDeviceToHost));
   for(int64_t f = 0; f < s->n; f++)
-    if(h[f] == 1) return fail(SMPLPP_ERR_NUMERIC, "LLT has numerical issue!"); // node.cpp:934-937
+    if(h[f] & 1) return fail(SMPLPP_ERR_NUMERIC, "LLT has numerical issue!"); // node.cpp:934-937
+  return SMPLPP_OK;
+}
+
+// bit 2 of the sticky word: raised by the evaluation (see TaskArrays::flags)
+static int ik_check_valence(smplpp_ik * s)
+{
+  std::vector<int> h((size_t)s->n);
+  HIP_TRY(hipMemcpy(h.data(), s->sticky, sizeof(int) * s->n, hipMemcpyDeviceToHost));
+  for(int64_t f = 0; f < s->n; f++)
+    if(h[f] & 4)
+      return fail(SMPLPP_ERR_INVALID, "a task with a normal term (normal weight or normal offset) touches a vertex with more than 12 adjacent "
+                                      "faces: the Jacobian of such a term is not supported");
   return SMPLPP_OK;
 }
 
@@ -3285,6 +3308,7 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
   {
     HIP_TRY(hipStreamSynchronize(st));
     if((rc = ik_check_status(s, s->status))) return rc;
+    if((rc = ik_check_valence(s))) return rc;
   }
   return SMPLPP_OK;
 }
@@ -3356,13 +3380,15 @@ extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * 
   {
     HIP_TRY(hipStreamSynchronize(st));
     if((rc = ik_check_status(s, s->sticky))) return rc;
+    if((rc = ik_check_valence(s))) return rc;
   }
   return SMPLPP_OK;
 }
 
 // Per-frame outcome of the solves so far: flags[f] bit 0 = the last solve of frame f failed ("LLT has numerical issue!",
 // node/node.cpp:934-937: the update of that frame was skipped), bit 1 = some solve since the last set_config /
-// solve_sequence start failed.  SMPLPP_HOST calls of iterate / solve_sequence report the same condition as an error; a
+// solve_sequence start failed, bit 2 = an evaluation since then met a task with a normal term on a vertex of more than 12
+// adjacent faces (its Jacobian rows are not supported).  SMPLPP_HOST calls of iterate / solve_sequence report the same condition as an error; a
 // SMPLPP_DEVICE (enqueue-only) caller reads it here once its stream has reached the point of interest.
 extern "C" int smplpp_ik_get_status(smplpp_ik * s, int32_t * flags, int space, void * stream)
 {
@@ -3376,7 +3402,7 @@ extern "C" int smplpp_ik_get_status(smplpp_ik * s, int32_t * flags, int space, v
   HIP_TRY(hipMemcpy(a.data(), s->status, sizeof(int) * s->n, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(b.data(), s->sticky, sizeof(int) * s->n, hipMemcpyDeviceToHost));
   std::vector<int32_t> h((size_t)s->n);
-  for(int64_t f = 0; f < s->n; f++) h[(size_t)f] = (a[(size_t)f] == 1 ? 1 : 0) | (b[(size_t)f] ? 2 : 0);
+  for(int64_t f = 0; f < s->n; f++) h[(size_t)f] = (a[(size_t)f] == 1 ? 1 : 0) | ((b[(size_t)f] & 1) ? 2 : 0) | (b[(size_t)f] & 4);
   if(space == SMPLPP_HOST)
     memcpy(flags, h.data(), sizeof(int32_t) * (size_t)s->n);
   else

@@ -30,7 +30,6 @@ struct smplpp_vposer
   // scale sD1, no slopes) and the constant product C10 = W1 . W0 [512][32] (fp32, from an fp64 sum on the host)
   uint8_t * w0h = nullptr;
   float * c10 = nullptr;
-  int jac_form = 2; // SMPLPP_VPOSER_JAC=1: the one-frame-per-workgroup kernel for every batch size
 };
 
 namespace smplpp_hip
@@ -364,13 +363,10 @@ __global__ __launch_bounds__(256) void vposer_kernel(const float * __restrict__ 
 //              (lane 32 h + r holds W[32 tile + r][16 ks + 8 h + j], j = 0..7), straight from L2 to registers;
 //   B operand: the tangent block of the previous layer, written to LDS in fragment order by its producer:
 //              Df [32 k-steps][piece 2][64 lanes (32 h + column)][8 fp16].
-// The VALUE path (activations) rides on the same weight fragments: the lane that feeds W[row][8 k's] to the MFMA also
-// takes their dot product with the previous layer's activations (fp16x2 pieces too, per-frame power-of-two scale) by
-// v_dot2_f32_f16, three products per pair like the MFMAs, fp32 accumulate — no second (fp32) stream of the weights, which
-// at 1 MB per layer and frame was what the kernel waited for.  Values carry 22-bit operands: 1e-6 relative to the fp32
-// VALU form of the value-only kernel.
-// LDS: D1f 64 KiB | D2f 64 KiB | a2, slope1 [512 each] fp32 | activation fragments Af [32 k-steps][piece 2][h 2][8 fp16] | z, scratch;
-// the layer-2 output so [126][33] reuses D1f, the rotation tail's 3 x 6 blocks reuse D2f.
+// The VALUE path (activations) rides on the same weight fragments, as one more B tile whose columns are the frames' activation
+// vectors (fp16x2 pieces too, per-frame power-of-two scale) — no second (fp32) stream of the weights, which at 1 MB per layer and
+// frame was what the first form of the kernel waited for.  Values carry 22-bit operands: 1e-6 relative to the fp32 VALU form of the
+// value-only kernel.  LDS plan: struct VJ2 below.
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 typedef float v4fv __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
@@ -378,40 +374,10 @@ typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 constexpr int VJ_DF = 32 * 2 * 1024; // bytes of one tangent block in fragment order
 constexpr int VJ_AF = 32 * 2 * 2 * 16; // bytes of one activation vector in fragment order
-constexpr int VJ_LDS = 2 * VJ_DF + 2 * HID * 4 + VJ_AF + (LAT + 16) * 4;
 
 __device__ __forceinline__ f32x16v vmfma(const v4fv & a, const v4fv & b, const f32x16v & c)
 {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, a), __builtin_bit_cast(f16x8v, b), c, 0, 0, 0);
-}
-// dot product of 8 fp16 pairs (one MFMA fragment against the matching activation fragment), fp32 accumulate
-__device__ __forceinline__ float vdot8(const v4fv & w, const v4fv & a, float c)
-{
-  // (explicit element pairs: hipcc folded `bit_cast<half2>(w[q])` inside an unrolled loop over q to element 0 for every q)
-  const f16x8v wv = __builtin_bit_cast(f16x8v, w), av = __builtin_bit_cast(f16x8v, a);
-  c = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 0, 1), __builtin_shufflevector(av, av, 0, 1), c, false);
-  c = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 2, 3), __builtin_shufflevector(av, av, 2, 3), c, false);
-  c = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 4, 5), __builtin_shufflevector(av, av, 4, 5), c, false);
-  c = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 6, 7), __builtin_shufflevector(av, av, 6, 7), c, false);
-  return c;
-}
-// the same with FOUR independent accumulators (one per element pair): back-to-back v_dot2 into ONE register wait for each other
-// (a dependent v_dot2c issues every ~16 cycles: four of them outlast the 32-cycle MFMA they were meant to hide behind)
-struct Dot4
-{
-  float c[4];
-};
-__device__ __forceinline__ void vdot8x4(const v4fv & w, const v4fv & a, Dot4 & d)
-{
-  const f16x8v wv = __builtin_bit_cast(f16x8v, w), av = __builtin_bit_cast(f16x8v, a);
-  d.c[0] = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 0, 1), __builtin_shufflevector(av, av, 0, 1), d.c[0], false);
-  d.c[1] = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 2, 3), __builtin_shufflevector(av, av, 2, 3), d.c[1], false);
-  d.c[2] = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 4, 5), __builtin_shufflevector(av, av, 4, 5), d.c[2], false);
-  d.c[3] = __builtin_amdgcn_fdot2(__builtin_shufflevector(wv, wv, 6, 7), __builtin_shufflevector(av, av, 6, 7), d.c[3], false);
-}
-__device__ __forceinline__ float dot4_sum(const Dot4 & d)
-{
-  return (d.c[0] + d.c[1]) + (d.c[2] + d.c[3]);
 }
 // per-frame power-of-two scale that puts max|v| of a 512-vector (two entries per thread) just under 2^14; red: [5] floats of LDS
 __device__ __forceinline__ float vscale512(float v0, float v1, float * red)
@@ -444,275 +410,12 @@ extern "C" int smplpp_debug_vpj_stamps(unsigned long long * out)
 #else
 #define VPJ_T(i)
 #endif
-__global__ __launch_bounds__(256) void vposer_jac_kernel(const float * __restrict__ z, int64_t z_stride, const float * __restrict__ w0t,
-                                                         const float * __restrict__ b0, const float * __restrict__ b1,
-                                                         const float * __restrict__ b2, const uint8_t * __restrict__ w1h,
-                                                         const uint8_t * __restrict__ w2h, float sD1, float sD2, float iW1, float iW2,
-                                                         float * __restrict__ out, int64_t out_stride, float * __restrict__ jac)
-{
-  extern __shared__ __attribute__((aligned(16))) unsigned char vl[];
-  unsigned char * D1f = vl;
-  unsigned char * D2f = vl + VJ_DF;
-  float * a2 = reinterpret_cast<float *>(vl + 2 * VJ_DF);   // [512] layer-1 activations (fp32)
-  float * sl1 = a2 + HID;                                    // [512] LeakyReLU slopes of layer 1
-  unsigned char * Af = reinterpret_cast<unsigned char *>(sl1 + HID); // activation fragments of the layer being consumed
-  float * sz = reinterpret_cast<float *>(Af + VJ_AF);       // [32]
-  float * red = sz + LAT;                                    // [16] scratch of the scale reductions
-  float * so = reinterpret_cast<float *>(D1f);               // [126][33] layer-2 output (D1f is dead by then)
-  const int64_t f = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, l31 = l & 31, lh = l >> 5;
-  VPJ_T(0);
-  // ---- layer 0 (+ LeakyReLU 0.01), rows tid and tid + 256: all 64 weights of the two rows in flight at once
-  float w0a[LAT], w0b[LAT];
-#pragma unroll
-  for(int c = 0; c < LAT; c++)
-  {
-    w0a[c] = w0t[c * HID + tid];
-    w0b[c] = w0t[c * HID + tid + 256];
-  }
-  if(tid < LAT) sz[tid] = z[f * z_stride + tid];
-  __syncthreads();
-  float h0 = b0[tid], h1 = b0[tid + 256];
-#pragma unroll
-  for(int c = 0; c < LAT; c++)
-  {
-    h0 += w0a[c] * sz[c];
-    h1 += w0b[c] * sz[c];
-  }
-  const float s00 = (h0 > 0.0f) ? 1.0f : 0.01f, s01 = (h1 > 0.0f) ? 1.0f : 0.01f;
-  h0 *= s00;
-  h1 *= s01;
-  {
-    // tangent block D1[row][c] = slope . W0[row][c] into fragment order: element (k = row, column c) sits in k-step row / 16,
-    // lane 32 ((row % 16) / 8) + c, element row % 8
-#pragma unroll
-    for(int rr = 0; rr < 2; rr++)
-    {
-      const int row = tid + 256 * rr;
-      const float sl = (rr ? s01 : s00) * sD1;
-      _Float16 * base = reinterpret_cast<_Float16 *>(D1f + (row >> 4) * 2048 + ((row >> 3) & 1) * 512) + (row & 7);
-#pragma unroll
-      for(int c = 0; c < LAT; c++)
-      {
-        _Float16 hi, lo;
-        split_f16x2(sl * (rr ? w0b[c] : w0a[c]), hi, lo);
-        base[c * 8] = hi;
-        base[512 + c * 8] = lo;
-      }
-    }
-  }
-  const float sA1 = vscale512(h0, h1, red);
-  vput_act(Af, tid, h0 * sA1);
-  vput_act(Af, tid + 256, h1 * sA1);
-  __syncthreads();
-  VPJ_T(1);
-  // ---- layer 1: wavefront w owns the row tiles 4w .. 4w + 3; per k-step 2 B fragments + 2 activation fragments from LDS (shared by
-  // the four tiles) and 8 A fragments from L2, prefetched three k-steps ahead; 12 MFMAs + 48 v_dot2
-  {
-    f32x16v acc[4];
-    Dot4 hq[4] = {{{0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}}};
-#pragma unroll
-    for(int t = 0; t < 4; t++)
-#pragma unroll
-      for(int r = 0; r < 16; r++) acc[t][r] = 0.0f;
-    const uint8_t * ap = w1h + (size_t)(4 * wave) * (32 * 2048) + l * 16;
-    // A fragments three k-steps ahead in a ring of four register stages (the loop is unrolled by four: static stage indices);
-    // one k-step of lead left the loop waiting ~900 cycles per step for L2
-    v4fv st[4][4][2];
-    auto load_stage = [&](int sidx, int ks) {
-#pragma unroll
-      for(int t = 0; t < 4; t++)
-#pragma unroll
-        for(int p = 0; p < 2; p++) st[sidx][t][p] = *reinterpret_cast<const v4fv *>(ap + (size_t)t * (32 * 2048) + ks * 2048 + p * 1024);
-    };
-    // every workgroup reads the same 1 MB at the same time: each starts its k loop at its own offset, so that at any instant the
-    // CUs ask the L2 channels for different lines (5 blockIdx mod 32: -2 % on the 512-frame latent IK iteration; offsets of
-    // blockIdx or blockIdx / 8 did nothing).  The k order only changes the fp32 summation order of a frame, the same way for
-    // the same position in the batch.
-    const int rot = (int)((blockIdx.x * 5u) & 31u);
-    load_stage(0, rot);
-    load_stage(1, (rot + 1) & 31);
-    load_stage(2, (rot + 2) & 31);
-    for(int k4 = 0; k4 < 32; k4 += 4)
-    {
-#pragma unroll
-      for(int u = 0; u < 4; u++)
-      {
-        const int ks = (k4 + u + rot) & 31;
-        load_stage((u + 3) & 3, (ks + 3) & 31);
-        const v4fv bh = *reinterpret_cast<const v4fv *>(D1f + ks * 2048 + l * 16);
-        const v4fv bl = *reinterpret_cast<const v4fv *>(D1f + ks * 2048 + 1024 + l * 16);
-        const v4fv ah = *reinterpret_cast<const v4fv *>(Af + ks * 64 + lh * 16);
-        const v4fv al = *reinterpret_cast<const v4fv *>(Af + ks * 64 + 32 + lh * 16);
-#pragma unroll
-        for(int t = 0; t < 4; t++)
-        {
-          acc[t] = vmfma(st[u][t][0], bh, acc[t]);
-          acc[t] = vmfma(st[u][t][0], bl, acc[t]);
-          acc[t] = vmfma(st[u][t][1], bh, acc[t]);
-          vdot8x4(st[u][t][1], ah, hq[t]);
-          vdot8x4(st[u][t][0], al, hq[t]);
-          vdot8x4(st[u][t][0], ah, hq[t]);
-        }
-        // (four v_dot2 behind each MFMA instead of all 48 behind the twelve: see vposer_jac2_kernel)
-#pragma unroll
-        for(int i = 0; i < 12; i++)
-        {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        }
-      }
-    }
-    VPJ_T(2);
-    // activations of this wavefront's 128 rows: the two k halves of a row meet through one shuffle
-    const float iv = iW1 / sA1;
-    float hv[4], sv[4];
-#pragma unroll
-    for(int t = 0; t < 4; t++)
-    {
-      const int row = 32 * (4 * wave + t) + l31;
-      const float hs = dot4_sum(hq[t]);
-      const float h = (hs + __shfl_xor(hs, 32, 64)) * iv + b1[row];
-      sv[t] = (h > 0.0f) ? 1.0f : 0.01f;
-      hv[t] = h * sv[t];
-      if(lh == 0)
-      {
-        a2[row] = hv[t];
-        sl1[row] = sv[t];
-      }
-    }
-    __syncthreads(); // slopes and activations of layer 1 are in LDS; every wavefront is done with D1f and Af
-#ifdef VPJ_DUMP
-    jac[f * 63 * LAT + tid] = a2[tid];
-    jac[f * 63 * LAT + tid + 256] = a2[tid + 256];
-    if(wave == 0) jac[f * 63 * LAT + 512 + l] = dot4_sum(hq[0]) * iv;
-    if(wave == 0) jac[f * 63 * LAT + 576 + l] = (float)reinterpret_cast<const _Float16 *>(Af)[l] / sA1; // Af of k-step 0 and 1: hi(h0) hi(h1) lo(h0) lo(h1)
-    return;
-#endif
-    const float sA2 = vscale512(a2[tid], a2[tid + 256], red);
-    vput_act(Af, tid, a2[tid] * sA2);
-    vput_act(Af, tid + 256, a2[tid + 256] * sA2);
-    red[8] = sA2; // (every thread writes the same value)
-    // D2[row][col] = slope1[row] . (W1 . D1)[row][col]: this lane holds column l31 and, per tile, the rows (r & 3) + 8 (r >> 2) + 4 lh.
-    // As the B operand of layer 2 (k = row): the four rows of a register group g = r >> 2 are elements j = 4 lh .. 4 lh + 3 of
-    // lane 32 (g & 1) + column in k-step 2 tile + (g >> 1): one 8-byte store per piece.
-    const float un = iW1 / sD1 * sD2;
-#pragma unroll
-    for(int t = 0; t < 4; t++)
-#pragma unroll
-      for(int g = 0; g < 4; g++)
-      {
-        const int tile = 4 * wave + t, row0 = 32 * tile + 8 * g + 4 * lh;
-        f16x4v hi, lo;
-#pragma unroll
-        for(int i = 0; i < 4; i++)
-        {
-          _Float16 a, b;
-          split_f16x2(sl1[row0 + i] * acc[t][4 * g + i] * un, a, b);
-          hi[i] = a;
-          lo[i] = b;
-        }
-        unsigned char * dst = D2f + (2 * tile + (g >> 1)) * 2048 + (32 * (g & 1) + l31) * 16 + 8 * lh;
-        *reinterpret_cast<f16x4v *>(dst) = hi;
-        *reinterpret_cast<f16x4v *>(dst + 1024) = lo;
-      }
-  }
-  __syncthreads();
-  VPJ_T(3);
-  // ---- layer 2: wavefront w owns rows 32 w .. 32 w + 31 (126 live); tangents on the MFMA, activations by v_dot2 on the same fragments
-  {
-    const float sA2 = red[8];
-    f32x16v acc;
-    Dot4 hq = {{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for(int r = 0; r < 16; r++) acc[r] = 0.0f;
-    const uint8_t * ap = w2h + (size_t)wave * (32 * 2048) + l * 16;
-    v4fv st[4][2];
-#pragma unroll
-    for(int q = 0; q < 3; q++)
-    {
-      st[q][0] = *reinterpret_cast<const v4fv *>(ap + q * 2048);
-      st[q][1] = *reinterpret_cast<const v4fv *>(ap + q * 2048 + 1024);
-    }
-    for(int k4 = 0; k4 < 32; k4 += 4)
-    {
-#pragma unroll
-      for(int u = 0; u < 4; u++)
-      {
-        const int ks = k4 + u, kn = ks + 3 < 32 ? ks + 3 : 31;
-        st[(u + 3) & 3][0] = *reinterpret_cast<const v4fv *>(ap + kn * 2048);
-        st[(u + 3) & 3][1] = *reinterpret_cast<const v4fv *>(ap + kn * 2048 + 1024);
-        const v4fv bh = *reinterpret_cast<const v4fv *>(D2f + ks * 2048 + l * 16);
-        const v4fv bl = *reinterpret_cast<const v4fv *>(D2f + ks * 2048 + 1024 + l * 16);
-        const v4fv ah = *reinterpret_cast<const v4fv *>(Af + ks * 64 + lh * 16);
-        const v4fv al = *reinterpret_cast<const v4fv *>(Af + ks * 64 + 32 + lh * 16);
-        acc = vmfma(st[u][0], bh, acc);
-        acc = vmfma(st[u][0], bl, acc);
-        acc = vmfma(st[u][1], bh, acc);
-        vdot8x4(st[u][1], ah, hq);
-        vdot8x4(st[u][0], al, hq);
-        vdot8x4(st[u][0], ah, hq);
-#pragma unroll
-        for(int i = 0; i < 3; i++)
-        {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        }
-      }
-    }
-    const int arow = 32 * wave + l31;
-    const float hs2 = dot4_sum(hq);
-    const float hsum = hs2 + __shfl_xor(hs2, 32, 64); // (so aliases D1f, whose last readers passed two barriers ago)
-    if(arow < OUT6 && lh == 0) so[arow * 33 + 32] = hsum * (iW2 / sA2) + b2[arow];
-    const float u2 = iW2 / sD2;
-#pragma unroll
-    for(int r = 0; r < 16; r++)
-    {
-      const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if(row < OUT6) so[row * 33 + l31] = acc[r] * u2;
-    }
-  }
-  __syncthreads();
-  VPJ_T(4);
-  // ---- rotation tail: 6D -> axis-angle and its 3 x 6 Jacobian, one thread per joint; the chain rule into the 32 latent columns
-  float * sj = reinterpret_cast<float *>(D2f); // [21][18]
-  if(tid < 21 * 6) // one thread per (joint, input direction): the value path six times over, one derivative column each
-  {
-    const int j = tid / 6, dir = tid % 6;
-    float o6[6], aa[3], jc[3];
-    for(int q = 0; q < 6; q++) o6[q] = so[(j * 6 + q) * 33 + 32];
-    sixd_to_aa_dir<1>(o6, dir, aa, jc);
-    if(dir == 0)
-      for(int i = 0; i < 3; i++) out[f * out_stride + j * 3 + i] = aa[i];
-    for(int i = 0; i < 3; i++) sj[j * 18 + i * 6 + dir] = jc[i];
-  }
-  __syncthreads();
-  VPJ_T(5);
-  // one thread per (joint, latent column): the six tangent entries of the column once for the joint's three output rows
-  for(int item = tid; item < 21 * LAT; item += 256)
-  {
-    const int j = item / LAT, c = item % LAT;
-    float t6[6];
-#pragma unroll
-    for(int q = 0; q < 6; q++) t6[q] = so[(j * 6 + q) * 33 + c];
-#pragma unroll
-    for(int i = 0; i < 3; i++)
-    {
-      float s = 0.f;
-#pragma unroll
-      for(int q = 0; q < 6; q++) s += sj[j * 18 + i * 6 + q] * t6[q];
-      jac[(f * 63 + j * 3 + i) * LAT + c] = s;
-    }
-  }
-  VPJ_T(6);
-}
-
-
 // ---- forward + Jacobian, NF frames per workgroup (vposer_jac2_kernel).
-// vposer_jac_kernel above is bound by its weight stream: per k-step a wavefront pulls 8 KB of W1 fragments for 384 cycles of
-// MFMA (85 B/clk per CU against the 64 B/clk a CU's vector memory path delivers), one frame per workgroup, one workgroup per CU
-// (its two 64 KiB tangent blocks fill the LDS).  Here NF frames share every weight fragment (NF x the MFMAs per byte), made
-// possible by NOT storing the layer-0 tangent block:  T0 = diag(s) W0 with LeakyReLU slopes s in {1, 0.01}, so
+// Round 2's kernel (one frame per workgroup with BOTH tangent blocks in LDS; removed in round 4, when the NF = 1 instantiation of
+// this one proved at least as fast at every batch size and bit-identical per frame to NF = 2) was bound by its weight stream: per
+// k-step a wavefront pulled 8 KB of W1 fragments for 384 cycles of MFMA (85 B/clk per CU against the 64 B/clk a CU's vector memory
+// path delivers).  Here NF frames share every weight fragment (NF x the MFMAs per byte), made possible by NOT storing the layer-0
+// tangent block:  T0 = diag(s) W0 with LeakyReLU slopes s in {1, 0.01}, so
 //     W1 . T0 = 0.99 W1 . (m (.) W0) + 0.01 W1 . W0            (m = the rows with slope 1)
 // — the B operand of layer 1 is ONE W0 fragment stream (w0h, shared by all frames and workgroups, from L2 like the weights),
 // masked per frame in registers (a 1 KiB mask image per frame in LDS), and C10 = W1 . W0 is a constant of the model added in
@@ -798,7 +501,7 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
   {
     // The VALUE path (h1 = W1 a0 + b1) rides on the matrix pipe too: the activation vectors of the NF frames are columns 0 .. NF - 1
     // of ONE more B tile (the other columns zero), three MFMAs per row tile and k-step for all frames together.  (v_dot2c_f32_f16
-    // on the same weight fragments, as vposer_jac_kernel does it, issues once per 16 cycles: its 48 per frame and k-step cost twice
+    // on the same weight fragments, as round 2's kernel did it, issues once per 16 cycles: its 48 per frame and k-step cost twice
     // the 12 tangent MFMAs they were meant to hide behind.)
     f32x16v acc[NF][4], vacc[4];
 #pragma unroll
@@ -825,7 +528,8 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
       sb[sidx][0] = *reinterpret_cast<const v4fv *>(bp + ks * 2048);
       sb[sidx][1] = *reinterpret_cast<const v4fv *>(bp + ks * 2048 + 1024);
     };
-    // (every workgroup starts its k loop elsewhere: see vposer_jac_kernel; by the GLOBAL group, so that sharding moves no bit)
+    // (every workgroup starts its k loop elsewhere, so that the CUs do not ask the L2s for the same weight lines at the same
+    // instant: -2 % per latent IK iteration; by the GLOBAL group, so that sharding moves no bit)
     const int rot = (int)(((unsigned long long)(NF == VJ_GROUP ? group : (frame_base + f0) / VJ_GROUP) * 5ull) & 31ull);
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     // LDS operands of a k-step (value tile pieces, one row mask per frame), read one k-step ahead into a second register set
@@ -1107,7 +811,7 @@ __global__ void rotmat_to_aa_kernel(const float * __restrict__ rot, float * __re
 int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
                           float * jac, hipStream_t st, int64_t frame_base)
 {
-  if(jac && v->jac_form == 2 && v->w0h && v->c10)
+  if(jac && v->w0h && v->c10)
   {
     // One kernel, two instantiations with the SAME arithmetic per frame: more frames than CUs -> two frames per workgroup share
     // every weight fragment; fewer -> one frame per workgroup.  Either way a frame's bits are a function of the frame and of its
@@ -1132,15 +836,7 @@ int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t
     HIP_TRY(hipGetLastError());
     return SMPLPP_OK;
   }
-  if(jac)
-  {
-    static PerDeviceOnce oncej;
-    HIP_TRY(lds_opt_in(oncej, v->device, reinterpret_cast<const void *>(&vposer_jac_kernel), VJ_LDS));
-    vposer_jac_kernel<<<dim3((unsigned)n), dim3(256), VJ_LDS, st>>>(z, z_stride, v->w0t, v->b0, v->b1, v->b2, v->w1h, v->w2h, v->sD1, v->sD2,
-                                                                   1.0f / v->sW1, 1.0f / v->sW2, out, out_stride, jac);
-    HIP_TRY(hipGetLastError());
-    return SMPLPP_OK;
-  }
+  if(jac) return fail(SMPLPP_ERR_INVALID, "smplpp_vposer_forward: this decoder has no Jacobian operands");
   const size_t shmem = sizeof(float) * (size_t)(2 * HID * VS + LAT + HID);
   static PerDeviceOnce once;
   HIP_TRY(lds_opt_in(once, v->device, reinterpret_cast<const void *>(&vposer_kernel), (int)shmem));
@@ -1245,8 +941,6 @@ extern "C" int smplpp_vposer_create(int device, const float * w0, const float * 
       e = hipMalloc((void **)&v->c10, sizeof(float) * c.size());
       if(e == hipSuccess) e = hipMemcpy(v->c10, c.data(), sizeof(float) * c.size(), hipMemcpyHostToDevice);
     }
-    const char * jf = getenv("SMPLPP_VPOSER_JAC"); // read once, here (1: the one-frame-per-workgroup kernel for every batch size)
-    v->jac_form = (jf && jf[0] == '1') ? 1 : 2;
   }
   if(e != hipSuccess)
   {

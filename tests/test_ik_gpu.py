@@ -549,8 +549,10 @@ def _double_fan_model(N):
 def test_ik_vertex_valence_limit():
     """The normal-term Jacobian differentiates through every face around a task's vertices, in tables of MAXADJ = 12 faces per
     vertex (src/SMPL.cpp:527-535, 620-640 put no bound on it).  At the bound (a 12-face fan) the evaluation matches the
-    oracle, normal rows included; beyond it (14) the solver is REFUSED at creation instead of silently dropping faces from
-    the derivative — FK and the mesh queries of such a model keep working."""
+    oracle, normal rows included.  Beyond it (14) the model still gets its solver (round 4: a real topology with ONE such vertex
+    must not lose IK altogether): position-only tasks on the fan match the oracle, a task with a normal term on it is REPORTED —
+    host-space eval / iterate raise, smplpp_ik_get_status carries bit 2 — instead of silently dropping faces from the derivative,
+    and the same solver works again once its normal-term tasks sit elsewhere."""
     from oracle import cpu
     from smplpp_amd import model_io
     from smplpp_amd._lib import SmplppError
@@ -571,14 +573,38 @@ def test_ik_vertex_valence_limit():
         assert np.abs(g["verts"] - o.fk(beta, theta)["verts"]).max() < 1e-5
         K = 4
         faces = np.array([0, 5, N + 2, 2 * N - 1])  # two faces of each fan
-        if N > 12:
-            with pytest.raises(SmplppError, match="adjacent faces"):
-                IkSolver(s, 2, K)
-            continue
         tp = rng.normal(0, 0.3, (2, K, 3)).astype(np.float32)
         tn = rng.normal(0, 1, (2, K, 3)).astype(np.float32)
         tn /= np.linalg.norm(tn, axis=2, keepdims=True)
         sol = IkSolver(s, 2, K)
+        if N > 12:
+            # position-only tasks: nothing differentiates through a vertex normal
+            sol.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, phi_limit=np.zeros(K), normal_task_weight=np.zeros(K))
+            sol.setConfig(beta, theta)
+            e, J = sol.eval()
+            for f in range(2):
+                ts = cpu.TaskSet(faces, tp[f], tn[f], phi_limit=np.zeros(K))
+                ts.normal_task_weight[:] = 0.0
+                r = o.ik_eval(beta[f], theta[f], ts)
+                assert np.abs(r["e"] - e[f]).max() < 5e-6
+                assert np.abs(r["J"] - J[f]).max() < 1e-4 * max(1.0, np.abs(r["J"]).max())
+            assert np.isfinite(sol.iterate(2)).all() and not sol.getStatus().any()
+            # a normal term on the fan: reported
+            sol.setTasks(normal_task_weight=np.ones(K))
+            with pytest.raises(SmplppError, match="adjacent faces"):
+                sol.eval()
+            assert (sol.getStatus() & 4).all()
+            with pytest.raises(SmplppError, match="adjacent faces"):
+                sol.iterate(1)
+            sol.setTasks(normal_task_weight=np.zeros(K), normal_offset=np.full(K, 0.01))  # a normal OFFSET differentiates through it too
+            sol.setConfig(beta, theta)  # (a new configuration starts with clean flags)
+            with pytest.raises(SmplppError, match="adjacent faces"):
+                sol.eval()
+            sol.setTasks(normal_offset=np.zeros(K))
+            sol.setConfig(beta, theta)
+            sol.eval()
+            assert not sol.getStatus().any()
+            continue
         sol.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, phi_limit=np.zeros(K), normal_offset=np.full(K, 0.01),
                      normal_task_weight=np.ones(K))
         sol.setConfig(beta, theta)
