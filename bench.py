@@ -220,6 +220,9 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=2000, help="launches of the long run reported as `sustained` (0 = skip)")
     ap.add_argument("--no-exact-form", action="store_true", help="skip the operand-exact (bf16x3) leg reported as `exact_form`")
     ap.add_argument("--profile-steps", type=int, default=40, help="launches of the separate loop that times the fused kernel with HIP events")
+    ap.add_argument("--model", default=os.environ.get("SMPLPP_MODEL"),
+                    help="a real model in the reference's schema (smpl_male.npz / .json from scripts/preprocess.py:98-117; default: "
+                         "$SMPLPP_MODEL): replaces the synthetic stand-in everywhere in this run, `data` becomes \"real\"")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses GPU 0 (use with --backend gloo)")
@@ -246,7 +249,10 @@ def main():
     torch.cuda.set_device(local)
     D.init_process_group((args.backend or "nccl") if world > 1 else None)
 
-    model = model_io.synthetic_model()
+    # a real smpl_male.{npz,json} overrides the synthetic model (the files are license-gated: none travels here)
+    model = model_io.load_model(args.model) if args.model else model_io.synthetic_model()
+    global V
+    V = int(model["vertices_template"].shape[0])
     smpl = SMPL()
     smpl.setDevice("cuda:%d" % local)
     smpl.init(model)
@@ -517,13 +523,18 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": DTYPES.get(form, "f32"),
-        "data": "synthetic",
+        "data": "real" if args.model else "synthetic",
         "config": {
-            "workload": "configs[1]: batch-%d random beta/theta FK+LBS per GPU, synthetic SMPL-shaped model "
-                        "(6890 verts, 24 joints, 207 pose / 10 shape PCs), HBM-resident in/out" % n,
+            "workload": "configs[1]: batch-%d random beta/theta FK+LBS per GPU, %s "
+                        "(%d verts, 24 joints, 207 pose / 10 shape PCs), HBM-resident in/out"
+                        % (n, ("model file " + os.path.basename(args.model)) if args.model else "synthetic SMPL-shaped model", V),
             "frames_per_gpu": n, "parallelism": "frames sharded x%d, no data-path collective" % world,
         },
         "roofline": roofline,
+        #  where the contract's W + K region sits in this run, so rounds compare like for like: r01-r02 lines timed it
+        # right behind model creation (= today's `cold_start`), r03 on behind the IK legs
+        "value_region": "W warm-up + K timed launches BEHIND the IK legs (a chip that has been busy); the same region right behind "
+                        "model creation is `cold_start`; a 2000-launch run is `sustained`",
     }
     line["cold_start"] = {"ms_per_step": cold_elapsed / args.steps * 1e3, "value": world * n * args.steps / cold_elapsed, "unit": "FK evals/s",
                           "note": "the same W + K launches timed right behind model creation, while the chip is still ramping its clocks "

@@ -31,6 +31,9 @@ constexpr int CT_P_R = 0, CT_P_J = SMPLPP_JOINT_NUM * 9, CT_P_ZERO = CT_P_J + SM
 // [TREE_DMAX + 1] | joints sorted by level [24]
 constexpr int TREE_DMAX = 12;
 constexpr int TREE_ANC = 0, TREE_LVL = SMPLPP_JOINT_NUM, TREE_LVLJ = TREE_LVL + TREE_DMAX + 1, TREE_SIZE = TREE_LVLJ + SMPLPP_JOINT_NUM;
+// slots of smplpp_model::range_flag: enqueue-only user launches (read by smplpp_fk_status), host-space user launches (each reads
+// its own), launches from inside the IK / VPoser loops (intermediate iterates; the solve's own status reports what matters there)
+constexpr int RANGE_DEVICE = 0, RANGE_HOST = 1, RANGE_INTERNAL = 2, RANGE_SLOTS = 4;
 constexpr int MAXADJ = 12;                    // adjacent faces per vertex the IK normal Jacobian differentiates through
 constexpr int MAXRING = 3 * (MAXADJ + 1) + 1; // distinct vertices an IK task can touch: its face's and those of the faces around them
 // Column layout of the B operand: vertex group g = v / 32 owns columns [96 g, 96 g + 96): 32 x, then 32 y, 32 z.
@@ -197,7 +200,7 @@ struct smplpp_model
   int64_t VGPn = 0;            // vertex-group pairs: ceil(V / 64)
   uint8_t * B2h = nullptr;     // bases + skinning weights as fp16x2 pieces in MFMA fragment order (layout above)
   float sB = 1.0f, sG = 1.0f;  // power-of-two scales of the basis operand and of the relative transforms (fp16 range)
-  int * range_flag = nullptr;  // device word: bit 0 = a launch of the fp16x2 form met an operand outside fp16's range (smplpp_fk_status)
+  int * range_flag = nullptr;  // device words [RANGE_SLOTS]: bit 0 = a launch of the fp16x2 form met an operand outside fp16's range
   char form = 'h';             // fused-kernel form (SMPLPP_SKIN, read once at model creation): h | b | p | v
   uint8_t * wIdx = nullptr;    // [VGn*32][maxw]
   float * wVal = nullptr;      // [VGn*32][maxw]

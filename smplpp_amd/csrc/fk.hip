@@ -278,10 +278,11 @@ PoseArgs fk_pose_args(smplpp_model * m, int64_t n, const float * beta, const flo
   return pa;
 }
 
-// pose_done: the pose step's outputs for exactly these inputs are already in the workspace (written by the IK solve kernel at
-// its end: ik.hip) — only the fused kernel is launched
+// range_slot: which word of the model's range status a launch of the fp16x2 form reports to (common.h RANGE_*): enqueue-only user
+// launches, host-space user launches and the IK / VPoser loops' internal launches each have their own, so that an intermediate IK
+// iterate outside the range does not turn a later, in-range smplpp_fk into an error
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
-              float * xforms44, float * rest, float * poserot, hipStream_t st, bool pose_done)
+              float * xforms44, float * rest, float * poserot, hipStream_t st, int range_slot)
 {
   Workspace & ws = m->ws;
   // Form of the fused kernel (m->form, from SMPLPP_SKIN at model creation): h (default,
@@ -296,8 +297,9 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
   {
     HIP_TRY(ws.A2h.reserve((size_t)(n64 / 64) * HB_KS * HB_A_BYTES));
     HIP_TRY(ws.G2h.reserve((size_t)(n64 / 64) * HB_G_BYTES));
-    if(!pose_done)
-      pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(fk_pose_args(m, n, beta, theta, joints, poserot, xforms44, verts || rest));
+    PoseArgs pa = fk_pose_args(m, n, beta, theta, joints, poserot, xforms44, verts || rest);
+    pa.range_flag = m->range_flag + range_slot;
+    pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(pa);
   }
   else if(form == 'b')
   {
@@ -394,13 +396,13 @@ extern "C" int smplpp_profile_read(smplpp_model * m, int64_t * launches, double 
   return SMPLPP_OK;
 }
 
-// reads and clears the range word of the fp16x2 form (the caller has synchronised the stream)
+// reads and clears the enqueue-only launches' range word of the fp16x2 form (the caller has synchronised the stream)
 static int fk_range_status(smplpp_model * m, int * bits)
 {
   *bits = 0;
   if(!m->range_flag || m->form != 'h') return SMPLPP_OK;
-  HIP_TRY(hipMemcpy(bits, m->range_flag, sizeof(int), hipMemcpyDeviceToHost));
-  if(*bits) HIP_TRY(hipMemset(m->range_flag, 0, sizeof(int)));
+  HIP_TRY(hipMemcpy(bits, m->range_flag + RANGE_DEVICE, sizeof(int), hipMemcpyDeviceToHost));
+  if(*bits) HIP_TRY(hipMemset(m->range_flag + RANGE_DEVICE, 0, sizeof(int)));
   return SMPLPP_OK;
 }
 
@@ -421,7 +423,7 @@ extern "C" int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const 
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   TraceRange tr_fwd("forward SMPL"); // the reference's span around SMPL::launch (node/node.cpp:752-781)
-  if(space == SMPLPP_DEVICE) return fk_device(m, n, beta, theta, verts, joints, xforms, rest, nullptr, st, false);
+  if(space == SMPLPP_DEVICE) return fk_device(m, n, beta, theta, verts, joints, xforms, rest, nullptr, st, RANGE_DEVICE);
 
   Workspace & ws = m->ws;
   const size_t nb = sizeof(float) * (size_t)n * NB, nt = sizeof(float) * (size_t)n * (NJ + 1) * 3;
@@ -434,17 +436,20 @@ extern "C" int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const 
   if(xforms) HIP_TRY(ws.xf44.reserve(sizeof(float) * (size_t)n * NJ * 16));
   HIP_TRY(hipMemcpyAsync(ws.beta.p, beta, nb, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(ws.theta.p, theta, nt, hipMemcpyHostToDevice, st));
+  // this call's own range word: cleared in front of the launch, read back on the launch stream beside the results
+  const bool ranged = m->range_flag && m->form == 'h';
+  if(ranged) HIP_TRY(hipMemsetAsync(m->range_flag + RANGE_HOST, 0, sizeof(int), st));
   int rc = fk_device(m, n, ws.beta.as<float>(), ws.theta.as<float>(), verts ? ws.verts.as<float>() : nullptr,
                      joints ? ws.joints.as<float>() : nullptr, xforms ? ws.xf44.as<float>() : nullptr,
-                     rest ? ws.rest.as<float>() : nullptr, nullptr, st, false);
+                     rest ? ws.rest.as<float>() : nullptr, nullptr, st, RANGE_HOST);
   if(rc) return rc;
+  int bits = 0;
+  if(ranged) HIP_TRY(hipMemcpyAsync(&bits, m->range_flag + RANGE_HOST, sizeof(int), hipMemcpyDeviceToHost, st));
   if(verts) HIP_TRY(hipMemcpyAsync(verts, ws.verts.p, nv, hipMemcpyDeviceToHost, st));
   if(rest) HIP_TRY(hipMemcpyAsync(rest, ws.rest.p, nv, hipMemcpyDeviceToHost, st));
   if(joints) HIP_TRY(hipMemcpyAsync(joints, ws.joints.p, sizeof(float) * (size_t)n * NJ * 3, hipMemcpyDeviceToHost, st));
   if(xforms) HIP_TRY(hipMemcpyAsync(xforms, ws.xf44.p, sizeof(float) * (size_t)n * NJ * 16, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  int bits = 0;
-  if(int rs = fk_range_status(m, &bits)) return rs;
   if(bits & 1)
     return fail(SMPLPP_ERR_NUMERIC, "smplpp_fk: an operand left the range of the fp16x2 form (|beta| < 1023, relative transforms within 16 x the "
                                     "template's extent): the vertices of such frames are not finite; create the model under SMPLPP_SKIN=b or p");

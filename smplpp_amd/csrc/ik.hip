@@ -28,7 +28,7 @@ struct smplpp_vposer;
 namespace smplpp_hip
 {
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
-              float * xforms44, float * rest, float * poserot, hipStream_t st, bool pose_done = false);
+              float * xforms44, float * rest, float * poserot, hipStream_t st, int range_slot);
 int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
                           float * jac, hipStream_t st, int64_t frame_base);
 
@@ -682,9 +682,11 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       ta.tang[(tb + k) * 6 + x * 2 + 0] = t1[x];
       ta.tang[(tb + k) * 6 + x * 2 + 1] = t2[x];
       pos804[(tb + k) * 3 + x] = pos[x];
-      // (write-through like the re-projection's own store to the same word, proj_finish_kernel: that kernel starts on the
-      // other stream as soon as this one's flag is up, BEFORE this kernel's end-of-kernel write-back — a plain store here
-      // could reach memory after the re-projected weights and overwrite them)
+      // (write-through like the re-projection's own store to the same word, proj_finish_kernel.  The side stream is forked by
+      // the SOLVE kernel's start flag today, i.e. behind this kernel's end-of-kernel write-back, so a plain store would also be
+      // ordered; when the fork was raised by this kernel's own flag it was not — a plain store could reach memory after the
+      // re-projected weights and overwrite them — and one policy per word stays the rule: two kernels never write a word
+      // with different policies)
       st_agent(&ta.vw[(tb + k) * 3 + x], w[x]);
       st_agent(&ta.apos[(tb + k) * 3 + x], ap[x]);
       e_out[(f * K + k) * 4 + x] = (double)(wp * (ap[x] - tp[x])); // node.cpp:807
@@ -3046,7 +3048,7 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
     }
     s->vcur ^= 1;
     s->verts = s->vbuf[s->vcur];
-    int rc = fk_device(m, n, s->beta, th25, s->verts, s->joints, nullptr, s->rest, s->poserot, st); // node.cpp:777
+    int rc = fk_device(m, n, s->beta, th25, s->verts, s->joints, nullptr, s->rest, s->poserot, st, RANGE_INTERNAL); // node.cpp:777
     if(rc) return rc;
   }
   TraceRange tr_eval("calculate IK matrices"); // node.cpp:796-881

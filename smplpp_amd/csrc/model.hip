@@ -429,8 +429,8 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   }
   TRY_OR_FREE(upload(&m->parent, parent.data(), parent.size()));
   {
-    const int zero = 0;
-    TRY_OR_FREE(upload(&m->range_flag, &zero, 1));
+    const int zero[RANGE_SLOTS] = {};
+    TRY_OR_FREE(upload(&m->range_flag, zero, RANGE_SLOTS));
   }
   {
     // joints by depth: the FK chain advances one tree level per step (SMPL: 9 levels)

@@ -1,6 +1,6 @@
-// The pose step of one frame (one 256-thread workgroup, four wavefronts): shared by pose_kernel (fk.hip) and by the IK solve
-// kernel, which runs it at its end for the frame it has just updated (ik.hip) — the same instructions either way, so the same
-// bits.  References: see fk.hip / pose_math.h.
+// The pose step of one frame (one 256-thread workgroup, four wavefronts) as a header: pose_kernel (fk.hip) is a wrapper around it,
+// and any kernel that includes it executes the same instructions, so the same bits.  (Round 3 ran it as the tail of the IK solve
+// kernel for the frame just updated: bit-identical, no gain — DESIGN.md §8 — and not kept.)  References: see fk.hip / pose_math.h.
 #pragma once
 
 #include "common.h"
