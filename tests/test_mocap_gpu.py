@@ -363,19 +363,19 @@ def test_real_capture_frames_step_by_step_vs_oracle(smpl, oracle_synth):
     """single IK steps on REAL capture frames (41 markers 15 mm off the skin, box QP on, phi pinned — the
     motion stage's settings, node.cpp:553-567, 699, 316-322) against oracle.ik_solve from the engine's own synchronised state
     (configuration + every task's face and weights read back before the step): 1e-4 rad.  The host-driven loop walks the window
-    400..600 of sample_walk.c3d; checked frames: complete ones, several with missing markers (weight 0: zero rows), the first solved
+    400..640 of sample_walk.c3d; checked frames: complete ones, several with missing markers (weight 0: zero rows), the first solved
     frame BEHIND a 0-valid gap (frame 467, behind 466) and the skipped frame itself (the oracle's caller skips it too, node.cpp:785)."""
     from oracle import cpu
     from smplpp_amd import mocap
 
     names, faces, pts, valid = _capture_full()
     K = valid.shape[1]
-    w0, w1 = 400, 600
+    w0, w1 = 400, 640
     nv = valid.sum(axis=1)
     gaps = [t for t in range(w0 + 1, w1) if nv[t] == 0]
     assert gaps and gaps[0] == 466 and nv[467] >= K // 2
     missing = [t for t in range(w0 + 1, w1) if K // 2 <= nv[t] < K]
-    check = sorted(set([401, 402, 450, 466, 467, 468, 599] + missing[:4] + missing[-2:]))
+    check = sorted(set([401, 402, 450, 466, 467, 468, 589, 609] + missing[:4] + missing[-2:]))
     assert sum(1 for t in check if K // 2 <= nv[t] < K) >= 4
     R = 2
     theta0 = np.zeros((R, 25, 3), np.float32)
