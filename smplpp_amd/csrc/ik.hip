@@ -276,6 +276,12 @@ __device__ unsigned long long g_eval_stamps[64 * 16];
 #else
 #define EVAL_STAMP(i) do {} while(0)
 #endif
+#ifdef SMPLPP_SOLVE_STAMPS
+__device__ unsigned long long g_solve_stamps[64 * 16];
+#define SOLVE_STAMP(i) do { if(threadIdx.x == 0 && blockIdx.x < 64) g_solve_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while(0)
+#else
+#define SOLVE_STAMP(i) do {} while(0)
+#endif
 // Cross-stream hand-over through a device flag (the other stream waits with hipStreamWaitValue32): every workgroup of the
 // producing kernel ends here; the last one to arrive publishes `tick`.  Measured on MI355X (tools/micro/waitvalue_cost.hip,
 // join_cost.hip): the waiting stream's next kernel starts 1.4 us after the flag is written, against 11.6 us after an event
@@ -1198,6 +1204,12 @@ __global__ void ik_actual_normals_kernel(ModelView mv, TaskArrays ta, const floa
   for(int x = 0; x < 3; x++) ta.anrm[t * 3 + x] = an[x];
 }
 
+#ifdef SMPLPP_SOLVE_STAMPS
+extern "C" int smplpp_debug_solve_stamps(unsigned long long * out)
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(smplpp_hip::g_solve_stamps), sizeof(unsigned long long) * 64 * 16);
+}
+#endif
 #ifdef SMPLPP_EVAL_STAMPS
 extern "C" int smplpp_debug_eval_stamps(unsigned long long * out)
 {
@@ -1411,6 +1423,60 @@ __device__ inline void stage_rows_cols(double * dst, const double * __restrict__
       if(q < cnt) dst[q] = t[u];
     }
   }
+}
+
+// The same copy by LDS-DMA (buffer_load_dwordx4 ... lds: memory -> LDS without a register in between, 16 bytes per lane, 64
+// consecutive 16-byte LDS slots per instruction from per-lane addresses), all of a wavefront's pieces in flight at once: the 123 live
+// rows x 75 columns of a motion solve (74 KB) are 74 instructions for the whole workgroup and arrive in about one memory round trip,
+// where stage_rows_cols took three (of sixteen 8-byte loads per thread each, ~1.5-2 us apiece with a single workgroup pulling).
+// LDS rows have the EVEN stride Wp = W + (W & 1) doubles, so that every lane's 16 bytes lie inside one row; a row's last lane may
+// carry one double of column W (or, on the last column, of the next row): it lands in the pad slot nobody reads.  The source rows are
+// only 8-byte aligned (odd D): dword-aligned buffer loads.  rl (LDS): the rows to take.  dst must have room for the count rounded
+// up to 64 slots (the caller checks).
+__device__ inline void stage_rows_cols_dma(double * dst, const double * __restrict__ src, int cr, int W, int D, const int * rl, int rows_total)
+{
+  typedef __attribute__((address_space(3))) void * lds_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int SPR = (W + 1) >> 1, cnt = cr * SPR; // 16-byte slots per row, in all
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(src), 0, rows_total * D * 8, 0x00020000);
+  int d = wave * 64 + lane;
+  int row = d / SPR, within = d - row * SPR;
+  // every row index is read from LDS BEFORE the first DMA is issued: the compiler cannot tell the DMA's LDS destination from the
+  // other arrays of the dynamic LDS block, so an LDS read behind a DMA waits for vmcnt(0) — with the reads interleaved in batches
+  // of eight the batches ran one after the other, a memory round trip each (7.3 us for the block instead of 2)
+  constexpr int U = 24; // 24 x 256 slots of 16 bytes = 96 KiB per round
+  for(int base = wave * 64; base < cnt; base += 256 * U)
+  {
+    int voff[U];
+#pragma unroll
+    for(int u = 0; u < U; u++)
+    {
+      // (lanes past the end ask beyond the descriptor's range: nothing is fetched, zeros land in the slack behind the block)
+      voff[u] = (d + 256 * u < cnt) ? (rl[row] * D + 2 * within) * 8 : 0x7ffffff0;
+      within += 256;
+      while(within >= SPR)
+      {
+        within -= SPR;
+        row++;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for(int u = 0; u < U; u++)
+      if(base + 256 * u < cnt) // (wave-uniform)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(reinterpret_cast<unsigned char *>(dst) + (size_t)(base + 256 * u) * 16), 16, voff[u], 0, 0, 0);
+    d += 256 * U;
+  }
+  // (Issuing these from the kernel's set-up, on the guess that theta alone is free, was tried: the compiler cannot tell the DMA's LDS
+  // destination from the other arrays of the same dynamic LDS block and waits for vmcnt(0) in front of the NEXT LDS access, so
+  // nothing overlapped — stop-timed, round 4.  Measured alone (tools/micro/stage_probe.hip): 1.9 us for the 74 KB block, ~16 B/clk,
+  // the same cold or warm and for 8- or 16-byte-aligned rows; 4-byte DMA 6.8 us; sixteen 8-byte register loads per thread 6.8 us.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// rows of the staged block a chunk may hold when it goes through LDS-DMA at (even) row stride Weven; < 4: no DMA
+__device__ inline int dma_chunk_rows(int chunk_rows, int D, int Weven)
+{
+  return (int)(((int64_t)chunk_rows * D) / Weven) - (128 + Weven - 1) / Weven; // (1 KiB of slack: the last instruction's tail)
 }
 
 // Factorisation + both substitutions of the packed (r + 1) x (r + 1) augmented matrix [S v; v' *] by ONE wavefront, lane i
@@ -1676,23 +1742,37 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
     const int W = nf > 0 ? idx[nf - 1] + 1 : 1;
     // ... and only the rows that can be non-zero (rlist): a task without a normal term has a zero fourth row, a missing marker
     // four zero rows — a quarter of the 164 rows of a capture solve.  Zero rows add exact zeros: the sums keep their bits.
-    const int crows = (int)(((int64_t)chunk_rows * D) / W);
+    // LDS row stride: W, or the next even number when the block goes through LDS-DMA (16-byte slots: stage_rows_cols_dma; W < D,
+    // so that a row's pad slot is filled from inside the same source row)
+    const bool whole = W == D && nlive == rows;
+    const int Weven = W + (W & 1);
+    const int crows_dma = dma_chunk_rows(chunk_rows, D, Weven);
+    const bool dma = !whole && W < D && crows_dma >= 4 && (int64_t)rows * D * 8 < 0x7fffff00LL;
+    const int Wp = dma ? Weven : W;
+    const int crows = dma ? crows_dma : (int)(((int64_t)chunk_rows * D) / W);
+    if(dbg_stop == 40) return; // (timing experiments only)
+    SOLVE_STAMP(2);
     for(int c0 = 0; c0 < nlive; c0 += crows)
     {
       const int cr = (nlive - c0 < crows) ? nlive - c0 : crows;
       __syncthreads();
-      if(W == D && nlive == rows)
+      SOLVE_STAMP(3);
+      if(whole)
         stage_rows(Jc, J + (int64_t)c0 * D, cr * D);
+      else if(dma)
+        stage_rows_cols_dma(Jc, J, cr, W, D, rlist + c0, rows);
       else
         stage_rows_cols(Jc, J, cr, W, D, rlist + c0);
+      SOLVE_STAMP(4);
       __syncthreads();
+      SOLVE_STAMP(5);
       if(dbg_stop == 41) return; // (timing experiments only)
       for(int r0 = 0; r0 < cr; r0 += 4)
       {
         const int r = r0 + lq;
         const bool rin = r < cr;
         const double rv = rowv[rlist[c0 + (rin ? r : 0)]];
-        const double * Jr = Jc + (rin ? r : 0) * W;
+        const double * Jr = Jc + (rin ? r : 0) * Wp;
         // (every tile's two operands are read first, then the MFMAs: a read -> wait -> MFMA pair per tile paid the LDS round
         // trip TPW times per four rows)
         double ja[TPW], jb[TPW];
@@ -1713,6 +1793,7 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
       }
     }
     __syncthreads();
+    SOLVE_STAMP(6);
     if(dbg_stop == 42) return;
 #pragma unroll
     for(int u = 0; u < TPW; u++)
@@ -1754,6 +1835,7 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
       if(i == nf && k < nf) acc[a][b] += bpri[idx[k]];
     }
   if(dbg_stop == 4) return;
+  SOLVE_STAMP(7);
   // factorisation, FOUR columns per barrier (round 2: two; the loop is a chain of barrier -> pivot reciprocals -> update, and
   // its length, not its arithmetic, is what it costs: 38 steps of ~1.9 k cycles for the 76 columns of a motion solve).  The
   // holders of columns j_0 .. j_3 publish their raw entries R_q; one barrier later every thread forms, from those four published
@@ -1850,6 +1932,7 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
     }
   }
   __syncthreads();
+  SOLVE_STAMP(8);
   // reciprocal pivots 1/sqrt(d_k) from the final diagonal entries, once
 #pragma unroll
   for(int a = 0; a < NT; a++)
@@ -1902,6 +1985,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int64_t f = blockIdx.x;
   const int tid = threadIdx.x;
+  SOLVE_STAMP(0);
   // "Every workgroup of this kernel is on its CU": the re-projection on the side stream waits for THIS, not for the end of the
   // evaluation.  Both kernels become ready at the same instant, and when the face scan's 1536 workgroups were dispatched first
   // the solve's (one per frame, a whole SIMD's registers per wavefront, 150 KB of LDS) waited for them to drain: 77 us became
@@ -1990,20 +2074,20 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   const double * e = ebuf;
   if(tid < 64)
   {
-    // |e|^2 in ascending order (the CPU checker sums the same way): the terms come out of registers by v_readlane — a
-    // single thread walking LDS pays a round trip per row (4.7 us for the 164 rows of a 41-marker solve)
+    // |e|^2 (node.cpp:893; Eigen's squaredNorm reduces in packets, so no summation order is "the reference's"): each lane squares
+    // and adds its own (up to three) rows, then a fixed butterfly over the 64 lanes — ~400 cycles.  Round 3 walked the rows in
+    // ascending order by v_readlane, a chain of `rows` dependent fp64 FMAs: 2 us of a 41-marker solve's set-up.
     double v[3];
 #pragma unroll
     for(int a = 0; a < 3; a++) v[a] = (tid + 64 * a < rows) ? e[tid + 64 * a] : 0.0;
     double s = 0.0;
     if(rows <= 192)
     {
-      for(int r0 = 0; r0 < rows; r0++)
-      {
-        const int r = __builtin_amdgcn_readfirstlane(r0);
-        const double x = readlane_f64(r < 64 ? v[0] : (r < 128 ? v[1] : v[2]), r & 63);
-        s += x * x;
-      }
+      s = v[0] * v[0];
+      s = fma(v[1], v[1], s);
+      s = fma(v[2], v[2], s);
+#pragma unroll
+      for(int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     }
     else
       for(int r = 0; r < rows; r++) s += e[r] * e[r];
@@ -2076,6 +2160,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   }
   __syncthreads();
 
+  SOLVE_STAMP(1);
   if(dbg_stop == 1) return; // (timing experiments only: SMPLPP_IK_DBG_STOP)
   const int max_it = enable_qp ? 4 * D + 20 : 1;
   for(int it = 0; it < max_it; it++)
@@ -2154,7 +2239,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       // registers, one barrier per column
       __syncthreads();
       build_and_factor_reg<NTR>(M, J, rowv, Jc, diag, bpri, idx, nf, D, rows, chunk_rows, lraw, ldiag, dinv, &s_bad, dbg_stop, s_rlist, s_nlive);
-      if(dbg_stop == 4 || dbg_stop == 41 || dbg_stop == 42) return;
+      if(dbg_stop == 4 || dbg_stop == 40 || dbg_stop == 41 || dbg_stop == 42) return;
     }
     else
     {
@@ -2194,8 +2279,10 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       chol_aug(M, nf, &s_bad, dinv);
     }
     if(dbg_stop == 2) return;
+    SOLVE_STAMP(9);
     if constexpr(!DUAL_ONLY)
       if(!dual) back_subst(M, nf, xs, dinv);
+    SOLVE_STAMP(10);
     if(dbg_stop == 3) return;
     if(!enable_qp)
     {
@@ -2380,6 +2467,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   }
   if(x_out)
     for(int i = tid; i < D; i += 256) x_out[f * D + i] = xfull[i];
+  SOLVE_STAMP(11);
 }
 
 // node.cpp:970-1001 — re-projection of the K query points of every frame onto that frame's posed mesh.
@@ -3126,10 +3214,11 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
   int rc = SMPLPP_OK;
   smplpp_model * m = s->m;
   const int K = (int)s->K;
-  static PerDeviceOnce once_solve[3];
+  static PerDeviceOnce once_solve[4];
   HIP_TRY(lds_opt_in(once_solve[0], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false>), (int)SOLVE_LDS_MAX));
   HIP_TRY(lds_opt_in(once_solve[1], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<true>), (int)SOLVE_LDS_MAX));
   HIP_TRY(lds_opt_in(once_solve[2], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false, 11>), (int)SOLVE_LDS_MAX));
+  HIP_TRY(lds_opt_in(once_solve[3], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false, 5>), (int)SOLVE_LDS_MAX));
   if(s->use_flags && (s->tick_fork > 0x7fff0000u || s->tick_join > 0x7fff0000u))
   {
     // the hand-over flags carry iteration numbers compared with >=: start over long before they could wrap
@@ -3165,16 +3254,23 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
     // the packed system is sized for the unknowns that CAN be free: a pinned phi (zero limit, node.cpp:567,699) never is,
     // which leaves 75 of the 157 unknowns of a 41-marker motion solve and room for its 164 Jacobian rows in two chunks
     const int m_dim = D - ((!phi_live || s->phi_locked) ? 2 * K : 0);
-    const int ntr = (m_dim + 1 <= 96 || m_dim + 1 > 176) ? 6 : 11; // tiles of the register-tiled factorisation (176 < m_dim + 1: all-LDS path)
+    // tiles of 16 the register-tiled factorisation covers (176 < m_dim + 1: all-LDS path).  5 (round 4): the motion solve of a capture
+    // fit has 75 unknowns that can be free (+ the rhs row = 76 <= 80): 15 register tiles per thread instead of 21 in every rank-4
+    // update of its 19 column steps, its own instantiation like 11 (one tile count per instantiation: DESIGN.md §3.3)
+    const int ntr_primal = (m_dim + 1 <= 80) ? 5 : ((m_dim + 1 <= 96 || m_dim + 1 > 176) ? 6 : 11);
+    // theta is never bound, so the free set keeps at least theta_dim unknowns: with fewer residual rows than that every pass
+    // (also every active-set pass of the QP) takes the dual form.  (Decided up here because the kernel's LDS plan depends on the
+    // instantiation's tile count: ik_solve_kernel<true> carries the default, 6.)
+    const bool dual_shape = rows < s->theta_dim && rows <= 63 && D <= 192 && dbg_stop != 9;
+    const int ntr = dual_shape ? 6 : ntr_primal;
     const size_t fixed = sizeof(double) * ((size_t)(m_dim + 1) * (m_dim + 2) / 2 + 7 * (size_t)D + 2 * (size_t)rows + 128 * (size_t)ntr + 4) + sizeof(int) * 2 * (size_t)D;
     const size_t budget = SOLVE_LDS_MAX;
     int chunk_rows = (int)((budget - fixed) / (sizeof(double) * (size_t)D));
     if(chunk_rows > rows) chunk_rows = rows;
     if(chunk_rows < 4) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_iterate: system too large for the in-LDS solver");
     const size_t solve_shmem = fixed + sizeof(double) * (size_t)chunk_rows * D;
-    // theta is never bound, so the free set keeps at least theta_dim unknowns: with fewer residual rows than that every pass
-    // (also every active-set pass of the QP) takes the dual form
-    const bool dual_only = rows < s->theta_dim && rows <= 63 && chunk_rows >= rows && D <= 192 && dbg_stop != 9;
+    const bool dual_only = dual_shape && chunk_rows >= rows;
+    if(dual_shape && !dual_only) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_iterate: system too large for the in-LDS solver");
     const bool last = hook && it == iters - 1;
     float * theta_record = last ? hook->theta_record : nullptr;
     const bool go = beside && s->use_flags; // the side stream's fork: raised by the solve kernel once all its workgroups run
@@ -3183,7 +3279,7 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
     s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
     s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr, theta_record, \
     go ? s->sig : (unsigned *)nullptr, go ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork)
-#define SOLVE11_() ik_solve_kernel<false, 11><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
+#define SOLVE11_(NTR_) ik_solve_kernel<false, NTR_><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
     s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
     s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr, theta_record, \
     go ? s->sig : (unsigned *)nullptr, go ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork)
@@ -3192,7 +3288,9 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
       if(dual_only)
         SOLVE_(true);
       else if(ntr == 11)
-        SOLVE11_();
+        SOLVE11_(11);
+      else if(ntr == 5)
+        SOLVE11_(5);
       else
         SOLVE_(false);
     }

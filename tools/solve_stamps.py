@@ -1,0 +1,24 @@
+"""Development aid: phase timestamps (100 MHz) of the primal ik_solve_kernel in the capture fit (needs a library built with
+-DSMPLPP_SOLVE_STAMPS: tools/build_variant.sh sstamps ik.hip -DSMPLPP_SOLVE_STAMPS ; SMPLPP_HIP_LIB=$PWD/ab/sstamps.so).
+usage: python tools/solve_stamps.py [R]"""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from smplpp_amd import model_io, mocap, _lib
+from smplpp_amd.smpl import SMPL
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+s = SMPL(); s.setDevice("cuda:0"); s.init(model_io.synthetic_model())
+g = np.load(os.path.join(ROOT, "tests", "golden", "sample_walk_excerpt.npz"))
+names = list(g["task_names"]); faces = np.array([mocap.BASELINE41[nm] for nm in names], np.int64); K = len(names)
+pts = g["points"] - g["points"][0][g["valid"][0]].mean(axis=0) + np.array([0, -0.3, 0], np.float32)
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+th0 = np.zeros((R, 25, 3), np.float32)
+ms = mocap.MocapMotionSolver(s, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R)
+ms.solve(pts, g["valid"], np.zeros(10, np.float32), th0, max_frames=40)
+L = _lib.load(); buf = (ctypes.c_ulonglong * (64 * 16))()
+L.smplpp_debug_solve_stamps.restype = ctypes.c_int
+assert L.smplpp_debug_solve_stamps(buf) == 0
+T = np.array(buf, dtype=np.uint64).reshape(64, 16)[:min(R, 64), :12].astype(np.int64)
+nm = ["set-up", "lists+rowv+tiles", "barrier", "voff+DMA+wait", "barrier", "Gram", "tiles->regs", "factorisation", "pivots+scale", "back subst", "QP tail+update"]
+d = np.diff(T, axis=1) * 0.01
+print("us per phase (median over %d workgroups of the last launch): " % len(T) + "  ".join("%s %.2f" % (a, b) for a, b in zip(nm, np.median(d, axis=0))), " total %.1f" % np.median((T[:, 11] - T[:, 0]) * 0.01))
