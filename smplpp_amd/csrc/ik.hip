@@ -1439,33 +1439,28 @@ __device__ inline void stage_rows_cols_dma(double * dst, const double * __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int SPR = (W + 1) >> 1, cnt = cr * SPR; // 16-byte slots per row, in all
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(src), 0, rows_total * D * 8, 0x00020000);
-  int d = wave * 64 + lane;
-  int row = d / SPR, within = d - row * SPR;
-  // every row index is read from LDS BEFORE the first DMA is issued: the compiler cannot tell the DMA's LDS destination from the
-  // other arrays of the dynamic LDS block, so an LDS read behind a DMA waits for vmcnt(0) — with the reads interleaved in batches
-  // of eight the batches ran one after the other, a memory round trip each (7.3 us for the block instead of 2)
+  // every row index is read from LDS BEFORE the first DMA is issued (the compiler cannot tell the DMA's LDS destination from the
+  // other arrays of the dynamic LDS block: an LDS read behind a DMA waits for vmcnt(0))
   constexpr int U = 24; // 24 x 256 slots of 16 bytes = 96 KiB per round
+  const unsigned magic = (unsigned)((0x100000000ull + (unsigned)SPR - 1) / (unsigned)SPR); // floor(d / SPR) = umulhi(d, magic) for d < 2^25 / SPR >= 2^18
   for(int base = wave * 64; base < cnt; base += 256 * U)
   {
     int voff[U];
 #pragma unroll
     for(int u = 0; u < U; u++)
     {
+      const int dd = base + lane + 256 * u;
+      const int row = (int)__umulhi((unsigned)dd, magic), within = dd - row * SPR;
       // (lanes past the end ask beyond the descriptor's range: nothing is fetched, zeros land in the slack behind the block)
-      voff[u] = (d + 256 * u < cnt) ? (rl[row] * D + 2 * within) * 8 : 0x7ffffff0;
-      within += 256;
-      while(within >= SPR)
-      {
-        within -= SPR;
-        row++;
-      }
+      voff[u] = (dd < cnt) ? (rl[row] * D + 2 * within) * 8 : 0x7ffffff0;
     }
     __builtin_amdgcn_sched_barrier(0);
+    SOLVE_STAMP(12);
 #pragma unroll
     for(int u = 0; u < U; u++)
       if(base + 256 * u < cnt) // (wave-uniform)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(reinterpret_cast<unsigned char *>(dst) + (size_t)(base + 256 * u) * 16), 16, voff[u], 0, 0, 0);
-    d += 256 * U;
+    SOLVE_STAMP(13);
   }
   // (Issuing these from the kernel's set-up, on the guess that theta alone is free, was tried: the compiler cannot tell the DMA's LDS
   // destination from the other arrays of the same dynamic LDS block and waits for vmcnt(0) in front of the NEXT LDS access, so
@@ -1714,8 +1709,116 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
   // the rows of J (staged in LDS in chunks) are the k dimension, four per MFMA.  Lane l feeds A[i = l % 16][k = l / 16] and
   // B[k = l / 16][j = l % 16] and receives D[4 r + l / 16][l % 16] in register r (probed: tools/micro/mfma_f64_layout.hip).
   // The tiles go through the packed LDS matrix M into the register layout of the factorisation below.
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int nitemM = (nf + 1) * (nf + 2) / 2;
+  // Two forms of the Gram loop.  ROWS SPLIT OVER THE WAVEFRONTS (round 4; tile counts up to 6, partial sums in the row chunk's LDS
+  // once the chunk is dead): wavefront w takes the row groups w, w + 4, ... and accumulates EVERY live tile from them — per group of
+  // four rows NT operand reads feed NT (NT + 1) / 2 MFMAs (5 reads for 15), where the tile-per-wavefront form below pays two reads
+  // per MFMA and is a chain of read -> wait -> 4 MFMAs per group: 31 groups x ~600 cycles for a capture solve against 8 x ~1100.
+  // The four partial sums are added in wavefront order when the tiles move into the factorisation's register layout.
+  const bool ksplit = NT <= 6 && 3 * nitemM <= chunk_rows * D; // (uniform)
+  if(ksplit)
   {
-    typedef double d4 __attribute__((ext_vector_type(4)));
+    constexpr int NTILE = NT <= 6 ? NT * (NT + 1) / 2 : 1, NTK = NT <= 6 ? NT : 1;
+    const int wave = tid >> 6, l = tid & 63, l16 = l & 15, lq = l >> 4;
+    d4 tacc[NTILE];
+    int colT[NTK]; // column of J (>= 0), -1 the rhs entry, -2 nothing, of this lane's element of tile row / tile column t
+#pragma unroll
+    for(int t = 0; t < NTK; t++)
+    {
+      const int m = 16 * t + l16;
+      colT[t] = (m < nf) ? idx[m] : (m == nf ? -1 : -2);
+    }
+#pragma unroll
+    for(int u = 0; u < NTILE; u++) tacc[u] = d4{0.0, 0.0, 0.0, 0.0};
+    const int W = nf > 0 ? idx[nf - 1] + 1 : 1;
+    const bool whole = W == D && nlive == rows;
+    const int Weven = W + (W & 1);
+    const int crows_dma = dma_chunk_rows(chunk_rows, D, Weven);
+    const bool dma = !whole && W < D && crows_dma >= 4 && (int64_t)rows * D * 8 < 0x7fffff00LL;
+    const int Wp = dma ? Weven : W;
+    const int crows = dma ? crows_dma : (int)(((int64_t)chunk_rows * D) / W);
+    if(dbg_stop == 40) return; // (timing experiments only)
+    SOLVE_STAMP(2);
+    for(int c0 = 0; c0 < nlive; c0 += crows)
+    {
+      const int cr = (nlive - c0 < crows) ? nlive - c0 : crows;
+      __syncthreads();
+      SOLVE_STAMP(3);
+      if(whole)
+        stage_rows(Jc, J + (int64_t)c0 * D, cr * D);
+      else if(dma)
+        stage_rows_cols_dma(Jc, J, cr, W, D, rlist + c0, rows);
+      else
+        stage_rows_cols(Jc, J, cr, W, D, rlist + c0);
+      SOLVE_STAMP(4);
+      __syncthreads();
+      SOLVE_STAMP(5);
+      if(dbg_stop == 41) return; // (timing experiments only)
+      for(int r0 = 4 * wave; r0 < cr; r0 += 16)
+      {
+        const int r = r0 + lq;
+        const bool rin = r < cr;
+        const double rv = rowv[rlist[c0 + (rin ? r : 0)]];
+        const double * Jr = Jc + (rin ? r : 0) * Wp;
+        double v[NTK], va[NTK], vb[NTK];
+#pragma unroll
+        for(int t = 0; t < NTK; t++) v[t] = Jr[colT[t] >= 0 ? colT[t] : 0];
+#pragma unroll
+        for(int t = 0; t < NTK; t++)
+        {
+          va[t] = !rin ? 0.0 : (colT[t] >= 0 ? v[t] : (colT[t] == -1 ? rv : 0.0));
+          vb[t] = (rin && colT[t] >= 0) ? v[t] : 0.0;
+        }
+#pragma unroll
+        for(int ta = 0; ta < NTK; ta++)
+#pragma unroll
+          for(int tb = 0; tb <= ta; tb++)
+          {
+            if(!(16 * ta <= nf && 16 * tb < nf)) continue; // (uniform)
+            d4 & t = tacc[ta * (ta + 1) / 2 + tb];
+            t = __builtin_amdgcn_mfma_f64_16x16x4f64(va[ta], vb[tb], t, 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads(); // every wavefront is done with the row chunk: its LDS takes the partial sums of wavefronts 1..3
+    SOLVE_STAMP(6);
+    if(dbg_stop == 42) return;
+    {
+      double * P = wave == 0 ? M : Jc + (size_t)(wave - 1) * nitemM;
+#pragma unroll
+      for(int ta = 0; ta < NTK; ta++)
+#pragma unroll
+        for(int tb = 0; tb <= ta; tb++)
+        {
+          if(!(16 * ta <= nf && 16 * tb < nf)) continue;
+#pragma unroll
+          for(int rr = 0; rr < 4; rr++)
+          {
+            const int i = 16 * ta + 4 * rr + lq, k = 16 * tb + l16;
+            if(i >= k && i <= nf && k < nf) P[tri_idx(i, k)] = tacc[ta * (ta + 1) / 2 + tb][rr];
+          }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for(int a2 = 0; a2 < NT; a2++)
+#pragma unroll
+      for(int b2 = 0; b2 <= a2; b2++)
+      {
+        const int i = ty + 16 * a2, k = tx + 16 * b2;
+        double sum = 0.0;
+        if(i >= k && i <= nf && k < nf)
+        {
+          const int q = tri_idx(i, k);
+          sum = ((M[q] + Jc[q]) + Jc[nitemM + q]) + Jc[2 * nitemM + q];
+        }
+        acc[a2][b2] = sum;
+      }
+    __syncthreads(); // M is rewritten by the factorisation
+  }
+  else
+  {
     constexpr int NTILE = NT * (NT + 1) / 2, TPW = (NTILE + 3) / 4;
     const int wave = tid >> 6, l = tid & 63, l16 = l & 15, lq = l >> 4;
     d4 tacc[TPW];

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstdlib>
 typedef __attribute__((address_space(3))) void * lds_ptr_t;
 __global__ void fill(double * p, size_t n)
 {
@@ -70,6 +71,13 @@ __global__ __launch_bounds__(256) void pull_regs(const double * J, int D, int ro
   if(tid == 0) out[blockIdx.x] = t1 - t0;
   if(tid == 0) chk[blockIdx.x] = Jc[5];
 }
+// the way ik_eval_kernel leaves J: 8-byte stores, a thread per (row, column) in row-strided order from 256-thread workgroups
+__global__ void fill_scattered(double * p, int D, int nb)
+{
+  const int b = blockIdx.x / 32, part = blockIdx.x % 32;
+  for(int r = part; r < 164; r += 32)
+    for(int c = threadIdx.x; c < D; c += 256) p[((size_t)b * 164 + r) * D + c] = (double)((r * 31 + c) % 977) * 0.001;
+}
 int main()
 {
   const int NB = 8;
@@ -84,7 +92,8 @@ int main()
     for(int mode = 0; mode < 3; mode++)
       for(int pass = 0; pass < 2; pass++)
       {
-        if(pass == 0) { fill<<<(unsigned)((n + 255) / 256), 256>>>(J, n); hipDeviceSynchronize(); }
+        if(pass == 0 && getenv("SCATTER")) fill_scattered<<<NB * 32, 256>>>(J, D, NB); // (no synchronisation: same stream, like eval -> solve)
+        else if(pass == 0) { fill<<<(unsigned)((n + 255) / 256), 256>>>(J, n); hipDeviceSynchronize(); }
         if(mode == 0) pull<16><<<NB, 256, 100 * 1024>>>(J, D, 123, 75, out, chk);
         if(mode == 1) pull<4><<<NB, 256, 100 * 1024>>>(J, D, 123, 75, out, chk);
         if(mode == 2) pull_regs<<<NB, 256, 100 * 1024>>>(J, D, 123, 75, out, chk);

@@ -18,7 +18,9 @@ ms.solve(pts, g["valid"], np.zeros(10, np.float32), th0, max_frames=40)
 L = _lib.load(); buf = (ctypes.c_ulonglong * (64 * 16))()
 L.smplpp_debug_solve_stamps.restype = ctypes.c_int
 assert L.smplpp_debug_solve_stamps(buf) == 0
-T = np.array(buf, dtype=np.uint64).reshape(64, 16)[:min(R, 64), :12].astype(np.int64)
+TT = np.array(buf, dtype=np.uint64).reshape(64, 16)[:min(R, 64)].astype(np.int64)
+print("staging: addresses %.2f us, issue %.2f us, wait %.2f us" % tuple(np.median(x) * 0.01 for x in (TT[:, 12] - TT[:, 3], TT[:, 13] - TT[:, 12], TT[:, 4] - TT[:, 13])))
+T = TT[:, :12]
 nm = ["set-up", "lists+rowv+tiles", "barrier", "voff+DMA+wait", "barrier", "Gram", "tiles->regs", "factorisation", "pivots+scale", "back subst", "QP tail+update"]
 d = np.diff(T, axis=1) * 0.01
 print("us per phase (median over %d workgroups of the last launch): " % len(T) + "  ".join("%s %.2f" % (a, b) for a, b in zip(nm, np.median(d, axis=0))), " total %.1f" % np.median((T[:, 11] - T[:, 0]) * 0.01))
