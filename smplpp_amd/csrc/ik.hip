@@ -1479,7 +1479,10 @@ __device__ inline int dma_chunk_rows(int chunk_rows, int D, int Weven)
 // v_readlane (an SGPR operand of the FMA), so a column costs its pivot's rsqrt plus (r - k) FMAs and no LDS round trip;
 // the factor is written back packed and re-read by columns (independent loads, hoisted) for the back substitution, whose
 // chain is then readlane + FMA only. w[0..r) = S^-1 v.
-template<int RMAX>
+// EXACT: r == RMAX is known where the call is made (the 6-target solve: 24), so the column loop carries no `k < r` branch and the whole
+// factorisation is ONE basic block: the scheduler then starts column k + 1's pivot chain (two v_readlane, rsqrt estimate, two Newton
+// steps: ~100 cycles of dependent latency) as soon as row k + 1 has taken column k's update, beside the remaining updates of column k.
+template<int RMAX, bool EXACT = false>
 __device__ inline void chol_wave_reg(double * M, int r, double * w, int * bad)
 {
   const int i = threadIdx.x; // < 64
@@ -1492,7 +1495,7 @@ __device__ inline void chol_wave_reg(double * M, int r, double * w, int * bad)
 #pragma unroll
   for(int k = 0; k < RMAX; k++)
   {
-    if(k < r) // uniform
+    if(EXACT || k < r) // uniform
     {
       double piv = readlane_f64(row[k], k);
       if(!(piv > 0.0))
@@ -1524,7 +1527,7 @@ __device__ inline void chol_wave_reg(double * M, int r, double * w, int * bad)
 #pragma unroll
   for(int k = RMAX - 1; k >= 0; k--)
   {
-    if(k < r) // uniform
+    if(EXACT || k < r) // uniform
     {
       const double wk = readlane_f64(acc, k) * readlane_f64(myrinv, k);
       acc = (i == k) ? wk : fma(-col[k], wk, acc); // col[k] is 0 for lanes i >= k
@@ -1631,6 +1634,7 @@ __device__ __forceinline__ void solve_dual(double * M, const double * __restrict
     }
   }
   __syncthreads();
+  SOLVE_STAMP(2);
   if(dbg_stop == 31) return; // (timing experiments only)
   if(tid < nf)
   {
@@ -1645,27 +1649,55 @@ __device__ __forceinline__ void solve_dual(double * M, const double * __restrict
     for(int i = 0; i < r; i++) Jf[i * nf + a] *= sg;
   }
   __syncthreads();
+  SOLVE_STAMP(3);
   if(dbg_stop == 32) return;
   {
-    const int nitem = (r + 1) * (r + 2) / 2 - 1; // rows 0..r of the packed lower triangle; the (r, r) corner is never used
-    for(int item = tid; item < nitem; item += 256)
+    // S = I + Jf Jf' (r x r) and the augmented row v' = us' Jf' on the fp64 matrix pipe (round 4): one 16 x 16 tile of the lower
+    // triangle of rows 0..r per wavefront and turn, the nf free columns as the k dimension, four per v_mfma_f64_16x16x4_f64 (operand
+    // and result layout: build_and_factor_reg).  The 325 dot products of 75 terms, one or two per thread with two LDS reads per term,
+    // took 5.1 us of the 6-target solve's 25.
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int wave = tid >> 6, l = tid & 63, l16 = l & 15, lq = l >> 4;
+    const int ntr = (r + 16) >> 4; // tile rows covering rows 0..r
+    const int ntile = ntr * (ntr + 1) / 2;
+    for(int t = wave; t < ntile; t += 4) // (wave-uniform)
     {
-      int i, j;
-      tri_unpack(item, i, j);
-      const double * a = (i < r) ? Jf + i * nf : us;
-      const double * b = Jf + j * nf;
-      double s0 = (i == j) ? 1.0 : 0.0, s1 = 0.0;
-      int q = 0;
-      for(; q + 1 < nf; q += 2)
+      int ta = 0, tb = t;
+      while(tb > ta)
       {
-        s0 += a[q] * b[q];
-        s1 += a[q + 1] * b[q + 1];
+        tb -= ta + 1;
+        ta++;
       }
-      if(q < nf) s0 += a[q] * b[q];
-      M[item] = s0 + s1;
+      const int ia = 16 * ta + l16, ib = 16 * tb + l16;
+      const double * pa = (ia < r) ? Jf + ia * nf : us; // (row r: the rhs; rows beyond: masked below)
+      const double * pb = Jf + (ib < r ? ib : 0) * nf;
+      const bool la = ia <= r, lb = ib < r;
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+      for(int k0 = 0; k0 < nf; k0 += 16)
+      {
+        double a[4], b[4];
+#pragma unroll
+        for(int u = 0; u < 4; u++)
+        {
+          const int k = k0 + 4 * u + lq, kk = k < nf ? k : 0;
+          a[u] = pa[kk];
+          b[u] = pb[kk];
+          if(!(la && k < nf)) a[u] = 0.0;
+          if(!(lb && k < nf)) b[u] = 0.0;
+        }
+#pragma unroll
+        for(int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for(int rr = 0; rr < 4; rr++)
+      {
+        const int i = 16 * ta + 4 * rr + lq, j = 16 * tb + l16;
+        if(i >= j && i <= r && j < r) M[tri_idx(i, j)] = acc[rr] + (i == j ? 1.0 : 0.0);
+      }
     }
   }
   __syncthreads();
+  SOLVE_STAMP(4);
   if(dbg_stop == 33) return;
   if(tid < 64)
   {
@@ -1673,12 +1705,18 @@ __device__ __forceinline__ void solve_dual(double * M, const double * __restrict
     {
       case 1: chol_wave_reg<8>(M, r, w, bad); break;
       case 2: chol_wave_reg<16>(M, r, w, bad); break;
-      case 3: chol_wave_reg<24>(M, r, w, bad); break;
+      case 3:
+        if(r == 24)
+          chol_wave_reg<24, true>(M, r, w, bad);
+        else
+          chol_wave_reg<24>(M, r, w, bad);
+        break;
       case 4: chol_wave_reg<32>(M, r, w, bad); break;
       default: chol_wave_lds(M, r, w, bad); break;
     }
   }
   __syncthreads();
+  SOLVE_STAMP(5);
   if(dbg_stop == 34) return;
   if(tid < nf)
   {

@@ -402,7 +402,7 @@ __device__ __forceinline__ void vput_act(unsigned char * Af, int k, float scaled
 
 #ifdef VPJ_STAMP
 __device__ unsigned long long g_vpj_stamps[16];
-#define VPJ_T(i) if(blockIdx.x == 0 && threadIdx.x == 0) g_vpj_stamps[i] = __builtin_amdgcn_s_memtime()
+#define VPJ_T(i) if(blockIdx.x == 0 && threadIdx.x == 0) { g_vpj_stamps[i] = __builtin_amdgcn_s_memtime(); g_vpj_stamps[8 + (i)] = __builtin_amdgcn_s_memrealtime(); }
 extern "C" int smplpp_debug_vpj_stamps(unsigned long long * out)
 {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vpj_stamps), sizeof(unsigned long long) * 16);

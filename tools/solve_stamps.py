@@ -11,6 +11,26 @@ s = SMPL(); s.setDevice("cuda:0"); s.init(model_io.synthetic_model())
 g = np.load(os.path.join(ROOT, "tests", "golden", "sample_walk_excerpt.npz"))
 names = list(g["task_names"]); faces = np.array([mocap.BASELINE41[nm] for nm in names], np.int64); K = len(names)
 pts = g["points"] - g["points"][0][g["valid"][0]].mean(axis=0) + np.array([0, -0.3, 0], np.float32)
+if len(sys.argv) > 1 and sys.argv[1] == "ik":  # configs[2]: the dual form (24 residual rows against 75 unknowns)
+    from smplpp_amd.ik import IkSolver, reference_task_faces
+    n, K = 256, 6
+    _, fc = reference_task_faces(K)
+    rng = np.random.default_rng(100)
+    tp = rng.normal(0, 0.3, (n, K, 3)).astype(np.float32)
+    th = np.zeros((n, 25, 3), np.float32); th[:, 1:] = rng.normal(0, 0.05, (n, 24, 3))
+    sol = IkSolver(s, n, K)
+    sol.setTasks(face_idx=fc, target_pos=tp, phi_limit=np.zeros(K))
+    sol.setConfig(np.zeros((n, 10), np.float32), th)
+    sol.iterate(10)
+    L = _lib.load(); buf = (ctypes.c_ulonglong * (64 * 16))()
+    L.smplpp_debug_solve_stamps.restype = ctypes.c_int
+    assert L.smplpp_debug_solve_stamps(buf) == 0
+    T = np.array(buf, dtype=np.uint64).reshape(64, 16).astype(np.int64)
+    seq = [0, 1, 2, 3, 4, 5, 11]
+    nm = ["set-up", "lists + gather", "column scaling", "Gram r x r", "factorisation + substitutions (one wavefront)", "x + update"]
+    d = np.diff(T[:, seq], axis=1) * 0.01
+    print("dual solve, us per phase (median over 64 workgroups): " + "  ".join("%s %.2f" % (a, b) for a, b in zip(nm, np.median(d, axis=0))), " total %.1f" % np.median((T[:, 11] - T[:, 0]) * 0.01))
+    sys.exit(0)
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 th0 = np.zeros((R, 25, 3), np.float32)
 ms = mocap.MocapMotionSolver(s, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R)

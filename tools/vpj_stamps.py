@@ -12,7 +12,10 @@ L = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
 L.smplpp_debug_vpj_stamps.restype = ctypes.c_int
 assert L.smplpp_debug_vpj_stamps(buf) == 0
-t = np.array(buf, dtype=np.uint64).astype(np.int64)[:7]
+tt = np.array(buf, dtype=np.uint64).astype(np.int64)
+t = tt[:7]
+rt = (tt[14] - tt[8]) * 0.01  # s_memrealtime: 100 MHz
+print("workgroup 0: %.1f us, %d ticks of s_memtime -> %.2f GHz" % (rt, t[6] - t[0], (t[6] - t[0]) / (rt * 1e3)))
 names = ["layer 0 + fragments", "layer 1 loop", "activations + D2f", "layer 2", "rotation tail", "chain rule"]
 for i in range(6): print("%-20s %7d cycles" % (names[i], t[i + 1] - t[i]))
 print("total %d cycles" % (t[6] - t[0]))
