@@ -387,6 +387,22 @@ def main():
                         "direct theta (D = 157); frame loop on the device (smplpp_ik_solve_sequence)" % (nfr, args.mocap_restarts, world),
         }
 
+        mocap_leg["per_frame_us"] = mt / max(1, iters) * 1e6  # one IK iteration of all this rank's chains in lock step
+        # one GPU's share of the 8-GPU split (64 restarts -> 8 chains per GPU): the serial per-frame period the 8-GPU number is made of
+        # (chains of a frame sequence cannot be parallelised along the sequence: node.cpp:1369-1407), measured here on ONE GPU
+        if world == 1 and args.mocap_restarts >= 8:
+            T8 = min(nfr, 600)
+            ms8 = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=8)
+            ms8.solve(pts[:T8], mvalid[:T8], np.zeros(10, np.float32), np.ascontiguousarray(th0_all[:8]), max_frames=2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ms8.solve(pts[:T8], mvalid[:T8], np.zeros(10, np.float32), np.ascontiguousarray(th0_all[:8]))
+            torch.cuda.synchronize()
+            t8 = time.perf_counter() - t1
+            mocap_leg["per_frame_us_at_8_chains"] = t8 / (mocap.MocapMotionSolver.WARMUP_ITERS + T8 - 1) * 1e6
+            mocap_leg["frames_timed_at_8_chains"] = T8
+            del ms8
+
         vp = VPoserDecoder(VPoserDecoder.synthetic_params(seed=3), device=local)
         # the reference's own capture setting (node.cpp:316-322 forces VPoser + QP on): 44-d layout, D = 44 + 2 * 41
         if R > 0:
