@@ -527,6 +527,9 @@ def main():
         except Exception:
             traffic_all = {}
     roofline = roofline_object(form, n, skin_ms, launches, traffic_all.get("skin_kernel_%s_hbm_bytes_per_launch_n%d" % (form, n)))
+    # `traffic` is a constant of the committed profile collection (separate rocprofv3 --pmc passes cannot run inside this program): which one
+    roofline["traffic_source"] = {"file": "profiles/traffic.json", "tag": traffic_all.get("tag"),
+                                  "kernel_us_in_that_run": traffic_all.get("skin_kernel_%s_rocprofv3_avg_us_same_run" % form)}
     line = {
         "metric": "SMPL FK evals/s + IK iters/s, batch 1024 frames, 1/2/4/8 MI355X",
         "value": value,

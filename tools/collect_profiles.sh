@@ -24,7 +24,7 @@ done
 unset SMPLPP_SKIN
 python3 $ROOT/tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
 cat $OUT/pmc_summary.txt
-python3 $ROOT/tools/make_traffic_json.py $OUT/pmc_summary.txt $OUT/traffic.json
+python3 $ROOT/tools/make_traffic_json.py $OUT/pmc_summary.txt $OUT/traffic.json 1024 $TAG $OUT/kernel_stats.csv
 python3 - <<PY
 import csv
 for r in list(csv.DictReader(open("$OUT/kernel_stats.csv")))[:6]:
