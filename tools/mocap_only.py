@@ -28,3 +28,6 @@ if os.environ.get("SMPLPP_HIP_LIB", "").endswith("stamps.so"):
     d = np.diff(T, axis=1)
     print("eval phases (ticks, median over 64 workgroups of the LAST launch): const %d chain %d A0 %d A1 %d A2 %d A3 %d B %d ; total %d" % tuple(list(np.median(d, axis=0)) + [np.median(T[:, 7] - T[:, 0])]))
     print("max over workgroups:", d.max(axis=0), (T[:, 7] - T[:, 0]).max())
+    TT = np.array(buf, dtype=np.uint64).reshape(64, 16).astype(np.int64)
+    g = TT[:, 8:14]
+    print("first group of phase B: tables %d  B1 %d  B2 (dp) %d  B3n (normal derivatives) %d  B3 %d  B4 (rows) %d" % tuple([np.median(g[:, 0] - TT[:, 6])] + [np.median(g[:, i + 1] - g[:, i]) for i in range(5)]))
