@@ -2628,7 +2628,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // KPR > 0: the (at most 2 * KPR) queries live in registers as KPR packed pairs and the cull runs on packed fp32
 // (v_pk_add / v_pk_fma: two queries per instruction, no LDS read per (face, query)); KPR == 0: any K, queries from LDS.
 // `hint` (nullable): squared distance of each query to its task's own face when the evaluation already has it.
-template<int KPR>
+// NBT: faces a thread takes per batch (all of a batch's loads are issued before any of its tests).  A chunk of at most 3 x 256 faces
+// — the 64-chain capture fit: 13776 faces / 24 chunks = 574 — runs with 3: with 6, a thread's batch held 2.2 real faces and 3.8
+// placeholders whose nine gathers each were issued all the same.
+template<int KPR, int NBT = CP_BATCH>
 __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ verts_all,
                                                          const float * __restrict__ pts, const float * __restrict__ hint, int64_t F,
                                                          int K, int chunks, const int * __restrict__ skip, int * __restrict__ list_cnt,
@@ -2688,13 +2691,13 @@ __global__ __launch_bounds__(256) void proj_scan_kernel(ModelView mv, TaskArrays
   }
   const int64_t per = (F + chunks - 1) / chunks;
   const int64_t f_lo = chunk * per, f_hi = (f_lo + per < F) ? f_lo + per : F;
-  for(int64_t base = f_lo + threadIdx.x; base < f_hi; base += (int64_t)blockDim.x * CP_BATCH)
+  for(int64_t base = f_lo + threadIdx.x; base < f_hi; base += (int64_t)blockDim.x * NBT)
   {
-    TriBatch t;
+    TriBatchT<NBT> t;
     load_tri_batch(verts, mv.faces, f_hi, base, blockDim.x, t);
     if(dbg_stop == 11) { if(t.v[0][0] == 12345.678f) list_cnt[0] = 1; continue; }
 #pragma unroll
-    for(int b = 0; b < CP_BATCH; b++)
+    for(int b = 0; b < NBT; b++)
     {
       if(!t.valid[b]) continue;
       const int64_t face = base + (int64_t)b * blockDim.x;
@@ -3455,11 +3458,13 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
       chunks = chunks < 1 ? 1 : (chunks > 32 ? 32 : chunks);
       const float * hint = beside ? s->ta.hint : nullptr; // the evaluation's distance is to the ACTUAL position
       const dim3 sg((unsigned)(s->n * chunks));
-#define SCAN_(KPR) proj_scan_kernel<KPR><<<sg, dim3(256), 0, pst>>>(view_of(m), s->ta, s->verts, qpts, hint, m->F, K, chunks, s->skip, \
+#define SCAN_(KPR, NBT_) proj_scan_kernel<KPR, NBT_><<<sg, dim3(256), 0, pst>>>(view_of(m), s->ta, s->verts, qpts, hint, m->F, K, chunks, s->skip, \
                                                                    s->list_cnt, s->list_d, s->list_f, dbg_stop)
-      if(K <= 4) SCAN_(2);
-      else if(K <= 8) SCAN_(4);
-      else SCAN_(0);
+      const bool small_chunk = (m->F + chunks - 1) / chunks <= 3 * 256; // (a thread then meets at most three faces)
+      if(K <= 4) SCAN_(2, CP_BATCH);
+      else if(K <= 8) SCAN_(4, CP_BATCH);
+      else if(small_chunk) SCAN_(0, 3);
+      else SCAN_(0, CP_BATCH);
 #undef SCAN_
       HIP_TRY(hipGetLastError());
       int *& dbg_buf = s->dbg_buf; // (SMPLPP_DEBUG_SYNC only; owned by the solver, on its device)

@@ -179,16 +179,19 @@ __device__ inline bool tri_culled_v(const float * a, const float * b, const floa
 // The scan is latency-bound (index load -> dependent vertex gathers), so faces are taken CP_BATCH at a time with all
 // of a batch's loads issued before any of its tests.
 constexpr int CP_BATCH = 6;
-struct TriBatch
+template<int NB>
+struct TriBatchT
 {
-  float v[CP_BATCH][9];
-  bool valid[CP_BATCH];
+  float v[NB][9];
+  bool valid[NB];
 };
-__device__ inline void load_tri_batch(const float * verts, const int32_t * faces, int64_t F, int64_t base, int stride, TriBatch & t)
+typedef TriBatchT<CP_BATCH> TriBatch;
+template<int NB>
+__device__ inline void load_tri_batch(const float * verts, const int32_t * faces, int64_t F, int64_t base, int stride, TriBatchT<NB> & t)
 {
-  int id[CP_BATCH][3];
+  int id[NB][3];
 #pragma unroll
-  for(int b = 0; b < CP_BATCH; b++)
+  for(int b = 0; b < NB; b++)
   {
     const int64_t f = base + (int64_t)b * stride;
     t.valid[b] = f < F;
@@ -198,7 +201,7 @@ __device__ inline void load_tri_batch(const float * verts, const int32_t * faces
     id[b][2] = faces[ff * 3 + 2];
   }
 #pragma unroll
-  for(int b = 0; b < CP_BATCH; b++)
+  for(int b = 0; b < NB; b++)
 #pragma unroll
     for(int c = 0; c < 3; c++)
     {
