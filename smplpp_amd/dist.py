@@ -79,6 +79,43 @@ def launch_ranks(argv: Sequence[str], world: int, extra_env: Optional[dict] = No
     t0 = time.monotonic()
     rc = 0
     live = set(range(world))
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    # a launcher that is told to stop (SIGTERM from whoever timed it, Ctrl-C) takes its ranks with it: ranks left behind would keep
+    # their GPUs busy after the job is gone
+    import signal
+
+    def on_term(signum, frame):
+        raise KeyboardInterrupt
+
+    old_term = None
+    if threading.current_thread() is threading.main_thread():
+        old_term = signal.signal(signal.SIGTERM, on_term)
+    try:
+        rc = _wait_ranks(procs, live, world, timeout, t0, stderr)
+    except BaseException:
+        stop_all()
+        raise
+    finally:
+        if old_term is not None:
+            signal.signal(signal.SIGTERM, old_term)
+    for t in threads:
+        t.join(timeout=5)
+    return rc
+
+
+def _wait_ranks(procs, live, world, timeout, t0, stderr) -> int:
+    rc = 0
     while live:
         for r in sorted(live):
             c = procs[r].poll()
@@ -104,8 +141,6 @@ def launch_ranks(argv: Sequence[str], world: int, extra_env: Optional[dict] = No
             live.clear()
         if live:
             time.sleep(0.05)
-    for t in threads:
-        t.join(timeout=5)
     return rc
 
 

@@ -167,3 +167,32 @@ def test_bench_starts_its_own_ranks_and_refuses_a_contradicting_world_size():
     assert r.stderr.count("bench.py needs an MI355X") >= 1 and "launch_ranks: rank" in r.stderr
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_launch_ranks_stopped_launcher_takes_its_ranks_along(tmp_path):
+    """SIGTERM to the launcher (a driver that timed the job out): the ranks it started are terminated too — none is left holding a GPU."""
+    import signal
+    import time
+
+    worker = tmp_path / "sleeper.py"
+    worker.write_text("import os, sys, time\nopen(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\ntime.sleep(120)\n" % str(tmp_path))
+    parent = tmp_path / "parent.py"
+    parent.write_text("import sys\nsys.path.insert(0, %r)\nfrom smplpp_amd import dist as D\nsys.exit(D.launch_ranks([sys.executable, %r], 2))\n" % (ROOT, str(worker)))
+    p = subprocess.Popen([sys.executable, str(parent)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    deadline = time.time() + 60
+    while time.time() < deadline and not all((tmp_path / ("pid%d" % r)).exists() and (tmp_path / ("pid%d" % r)).read_text() for r in range(2)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / ("pid%d" % r)).read_text()) for r in range(2)]
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=30)
+    assert p.returncode != 0
+    for pid in pids:
+        for _ in range(100):
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                break
+            time.sleep(0.1)
+        else:
+            os.kill(pid, signal.SIGKILL)  # (never leave the test's own children behind)
+            raise AssertionError("rank process %d survived its launcher" % pid)
