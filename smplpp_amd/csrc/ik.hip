@@ -3036,6 +3036,12 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
     if((e = getenv("SMPLPP_IK_DBG_STOP"))) s->dbg_stop = atoi(e);
     if((e = getenv("SMPLPP_IK_OVERLAP"))) s->overlap_ok = e[0] != '0';
     if(s->dbg_sync) s->overlap_ok = false;
+    // workgroups of the face scan.  Few frames: 1536 in all (a capture fit's 64 chains: 24 chunks of 574 faces per frame, measured
+    // against 9 / 18 / 36 chunks).  256 frames: TWO chunks per frame — the scan then runs beside kernels that fill the chip
+    // themselves (solve, pose, FK: one workgroup per frame or per CU), and fewer, longer scan workgroups take less from them than
+    // many short ones: configs[2] 89.2 -> 85.0 us per iteration in three alternating pairs on one box (6 chunks before); 512 frames
+    // keep their three (2 and 3 measured level).  SMPLPP_SCAN_BLOCKS overrides.
+    s->scan_blocks = (n >= 256 && n < 512) ? 2 * n : 1536;
     if((e = getenv("SMPLPP_SCAN_BLOCKS"))) s->scan_blocks = atoll(e);
   }
   const size_t nk = (size_t)n * K;
