@@ -327,6 +327,9 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_tree[TREE_SIZE];
   __shared__ int s_par[NJ];
+  __shared__ float s_gw[NJ * 3];          // world joint positions
+  __shared__ uint8_t s_ancat[NJ * DMAX];  // ancestor of joint i at depth d
+  static_assert(EVAL_NT >= 256 + NJ * DMAX, "one thread per (joint, depth) of the ancestor table");
   const int * sAnc = s_tree + TREE_ANC;
   const int nlev = mv.nlev;
   // grid = n * tsplit: when frames are fewer than CUs (mocap chains: 8 per GPU x 41 markers) a frame's tasks are split over
@@ -336,8 +339,8 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
 
   const int tid = threadIdx.x;
   EVAL_STAMP(0);
-  // this thread's entry of the chain-derivative table at every tree level (built by smplpp_ik_create from the tree): joint |
-  // parent << 5 | column slot << 10 | row << 16 | (the column's joint is the joint itself) << 18; -1: none
+  // this thread's entries of the chain-derivative table (dealt round-robin by smplpp_ik_create from the tree: the live ones fill the
+  // first slots): joint | parent << 5 | column slot << 10 | row << 16 | (the column's joint is the joint itself) << 18; -1: none
   int role[DMAX];
 #pragma unroll
   for(int L = 0; L < DMAX; L++) role[L] = roles[L * EVAL_NT + tid];
@@ -408,91 +411,133 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       rodrigues_grad_dev(th, tid % 3, dR);
       for(int q = 0; q < 9; q++) lds[L_DR + (tid / 3) * DRS + (tid % 3) * 9 + q] = dR[q];
     }
+    else if(tid >= 128 && tid < 128 + NJ * 3) // world position of joint j: g_j = b_j + A_j . rest joint_j (the relative transform undone)
+    {
+      const int j = (tid - 128) / 3, x = (tid - 128) % 3;
+      const float * G = lds + L_G + j * 12 + x * 4;
+      s_gw[j * 3 + x] = G[3] + ((G[0] * lds[L_J + j * 3] + G[1] * lds[L_J + j * 3 + 1]) + G[2] * lds[L_J + j * 3 + 2]);
+    }
+    else if(tid >= 256 && tid < 256 + NJ * DMAX) // the ancestor of joint i at depth d (i itself at its own depth; none below it)
+    {
+      const int i = (tid - 256) / DMAX, d = (tid - 256) % DMAX;
+      int j = i;
+      const int dep = __popc(s_tree[TREE_ANC + i]) - 1;
+      for(int q = dep; q > d; q--) j = s_par[j];
+      s_ancat[i * DMAX + d] = (uint8_t)(d <= dep ? j : 0);
+    }
     __syncthreads();
   }
 
   EVAL_STAMP(1);
   if(dbg_stop == 20) return; // (timing experiments only: SMPLPP_IK_DBG_STOP)
-  // ---- chain derivatives, one tree level per step.  Entry (joint i, ancestor depth da, axis a,
-  // row r) = row r of d[A_i | b_i]/d theta_c for c = (ancestor of i at depth da, axis a); it depends only on the SAME
-  // entry of i's parent (or, when the ancestor is i itself, on dR_c and the parent's A): all joints of a level and all
-  // their columns advance together — 9 steps of one LDS round trip instead of 24-step walks by 216 threads.
-  // The beta columns (joints move, rotations do not) ride in the same steps on another thread range:
-  // d g_i/d beta_k = A_p . dt_i + d g_p; the running d g sits in the (still unused) dp buffer.
+  // ---- chain derivatives.  Entry (joint i, ancestor depth da, axis ax, row r) = row r of
+  // d[A_i | b_i]/d theta_c for c = (the ancestor a of i at depth da, axis ax).  CLOSED FORM (round 4; rounds 1-3 advanced one tree
+  // level per barrier-separated step, each entry from the same entry of i's parent: nine steps of an LDS round trip): with A the
+  // world rotations and g the world joint positions, A_i = A_a (R ... R_i) for every descendant i of a, hence
+  //     dA_i = A_p(a) dR_a A_a' A_i = Omega A_i,   d g_i = Omega (g_i - g_a),   Omega = W A_a',  W = A_p(a) dR_(a, ax)
+  // — one 3 x 3 per (ancestor, axis), then every entry on its own: two barriers instead of nine.  The joint's own column keeps
+  // dA_a = W (Omega A_a up to rounding), the root's dR itself.  The beta columns (item 5: joints move, rotations do not; d g_i /
+  // d beta_k = A_p . dt_i + d g_p is a sum along the path) keep their level-by-level steps, only where beta is optimised.
   {
-    const int * s_lvl = s_tree + TREE_LVL, * s_lvlj = s_tree + TREE_LVLJ;
-    float * dgl = lds + L_DP; // [24][3][NB]
-    // (beside the chain entries' threads when the workgroup is large enough, else sharing threads with them)
-    constexpr int BETA_T0 = (EVAL_NT >= 512 + NJ * NB) ? 512 : EVAL_NT - 256;
-    static_assert(BETA_T0 >= 0 && BETA_T0 + NJ * NB <= EVAL_NT, "the beta columns take NJ * NB threads from BETA_T0");
-    // beta columns: thread (joint i, k) works at the joint's level; its regressor rows are loaded ahead of the steps
-    const bool isb = optimize_beta && tid >= BETA_T0 && tid < BETA_T0 + NJ * NB;
-    const int bi = isb ? (tid - BETA_T0) / NB : 0, bk = isb ? (tid - BETA_T0) % NB : 0, bp = s_par[bi];
-    const int blev = isb ? __popc(sAnc[bi]) - 1 : -1;
-    float dj[3] = {0.f, 0.f, 0.f}, dt[3] = {0.f, 0.f, 0.f};
-    if(isb)
-      for(int x = 0; x < 3; x++)
-      {
-        dj[x] = mv.JS[(bi * 3 + x) * NB + bk];
-        dt[x] = (bi == 0) ? dj[x] : dj[x] - mv.JS[(bp * 3 + x) * NB + bk];
-      }
-#pragma unroll
-    for(int L = 0; L < DMAX; L++)
+    float * dgl = lds + L_DP;              // [24][3][NB] running d g of the beta columns (the dp buffer is unused until phase B)
+    float * om = lds + L_DP + NJ * 3 * NB; // [72 (ancestor, axis)][3 rows][8]: W (3) | Omega (3) | Omega . g_a | -
+    if(tid < NJ * 9)
     {
-      if(L >= nlev) break;
-      if(role[L] >= 0)
+      const int a = tid / 9, ax = (tid / 3) % 3, r = tid % 3, p = s_par[a];
+      const float * M = lds + L_DR + a * DRS + ax * 9;
+      float W[3];
+      if(a == 0) // (the reference's dA_0 = dR itself: no products with a unit row's zeros)
       {
-        // one path for both kinds of entry: row = x . M with x = the parent's dA row and M = R_i (the column's joint is an
-        // ancestor), or x = row r of the parent's A (the unit row for the root) and M = dR_c (it is joint i itself)
-        const int i = role[L] & 31, p = (role[L] >> 5) & 31, cs = (role[L] >> 10) & 63, r = (role[L] >> 16) & 3;
-        const bool self = (role[L] >> 18) & 1;
-        const int pc = (i == 0) ? 0 : p; // (the root has no parent: any valid address, the value is not used)
-        const float4 xr = *reinterpret_cast<const float4 *>(self ? lds + L_G + pc * 12 + r * 4 : lds + L_DAB + ((pc * CS + cs) * 3 + r) * 4);
-        const float * M = self ? lds + L_DR + i * DRS + (cs % 3) * 9 : lds + L_R + i * 9;
-        const float m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3], m4 = M[4], m5 = M[5], m6 = M[6], m7 = M[7], m8 = M[8];
-        const float t0 = lds[L_T + i * 3], t1 = lds[L_T + i * 3 + 1], t2 = lds[L_T + i * 3 + 2];
-        const float jp0 = lds[L_J + pc * 3], jp1 = lds[L_J + pc * 3 + 1], jp2 = lds[L_J + pc * 3 + 2];
-        const float ji0 = lds[L_J + i * 3], ji1 = lds[L_J + i * 3 + 1], ji2 = lds[L_J + i * 3 + 2];
-        const bool unit = self && i == 0;
-        const float x0 = unit ? (r == 0 ? 1.0f : 0.0f) : xr.x, x1 = unit ? (r == 1 ? 1.0f : 0.0f) : xr.y, x2 = unit ? (r == 2 ? 1.0f : 0.0f) : xr.z;
-        float dA[3];
-        if(unit) // (the reference's dA_0 = dR itself: no products with the unit row's zeros)
+        W[0] = M[r * 3];
+        W[1] = M[r * 3 + 1];
+        W[2] = M[r * 3 + 2];
+      }
+      else
+      {
+        const float * x = lds + L_G + p * 12 + r * 4;
+        W[0] = x[0] * M[0] + x[1] * M[3] + x[2] * M[6];
+        W[1] = x[0] * M[1] + x[1] * M[4] + x[2] * M[7];
+        W[2] = x[0] * M[2] + x[1] * M[5] + x[2] * M[8];
+      }
+      const float * Aa = lds + L_G + a * 12;
+      float O[3];
+#pragma unroll
+      for(int c = 0; c < 3; c++) O[c] = W[0] * Aa[c * 4] + W[1] * Aa[c * 4 + 1] + W[2] * Aa[c * 4 + 2];
+      float * o = om + tid * 8;
+      *reinterpret_cast<float4 *>(o) = make_float4(W[0], W[1], W[2], O[0]);
+      *reinterpret_cast<float4 *>(o + 4) = make_float4(O[1], O[2], O[0] * s_gw[a * 3] + O[1] * s_gw[a * 3 + 1] + O[2] * s_gw[a * 3 + 2], 0.0f);
+    }
+    __syncthreads();
+    // (role[u]: this thread's u-th entry, dealt round-robin by smplpp_ik_create: the live ones fill the first slots)
+#pragma unroll
+    for(int u = 0; u < DMAX; u++)
+    {
+      if(role[u] >= 0)
+      {
+        const int i = role[u] & 31, cs = (role[u] >> 10) & 63, r = (role[u] >> 16) & 3;
+        const bool self = (role[u] >> 18) & 1;
+        const int a = s_ancat[i * DMAX + cs / 3];
+        const float * o = om + ((a * 3 + cs % 3) * 3 + r) * 8;
+        const float4 o0 = *reinterpret_cast<const float4 *>(o), o1 = *reinterpret_cast<const float4 *>(o + 4);
+        const float * Ai = lds + L_G + i * 12;
+        float dA[3], dg;
+        if(self)
         {
-          dA[0] = r == 0 ? m0 : (r == 1 ? m3 : m6);
-          dA[1] = r == 0 ? m1 : (r == 1 ? m4 : m7);
-          dA[2] = r == 0 ? m2 : (r == 1 ? m5 : m8);
+          dA[0] = o0.x;
+          dA[1] = o0.y;
+          dA[2] = o0.z;
+          dg = 0.0f;
         }
         else
         {
-          dA[0] = x0 * m0 + x1 * m3 + x2 * m6;
-          dA[1] = x0 * m1 + x1 * m4 + x2 * m7;
-          dA[2] = x0 * m2 + x1 * m5 + x2 * m8;
+#pragma unroll
+          for(int c = 0; c < 3; c++) dA[c] = o0.w * Ai[c] + o1.x * Ai[4 + c] + o1.y * Ai[8 + c];
+          dg = (o0.w * s_gw[i * 3] + o1.x * s_gw[i * 3 + 1] + o1.y * s_gw[i * 3 + 2]) - o1.z;
         }
-        // dg = dA_p . t_i + (db_p + dA_p . j_p) for an ancestor's column, 0 for the joint's own
-        const float dgp = xr.w + (x0 * jp0 + x1 * jp1 + x2 * jp2);
-        const float dg = self ? 0.0f : (x0 * t0 + x1 * t1 + x2 * t2) + dgp;
+        const float ji0 = lds[L_J + i * 3], ji1 = lds[L_J + i * 3 + 1], ji2 = lds[L_J + i * 3 + 2];
         *reinterpret_cast<float4 *>(lds + L_DAB + ((i * CS + cs) * 3 + r) * 4) =
             make_float4(dA[0], dA[1], dA[2], dg - (dA[0] * ji0 + dA[1] * ji1 + dA[2] * ji2));
       }
-      if(blev == L)
-      {
-        float dgi[3];
-        if(bi == 0)
-          for(int x = 0; x < 3; x++) dgi[x] = dt[x];
-        else
-        {
-          const float * Ap = lds + L_G + bp * 12;
-          for(int r = 0; r < 3; r++) dgi[r] = (Ap[r * 4] * dt[0] + Ap[r * 4 + 1] * dt[1] + Ap[r * 4 + 2] * dt[2]) + dgl[(bp * 3 + r) * NB + bk];
-        }
-        const float * Ai = lds + L_G + bi * 12;
-        for(int r = 0; r < 3; r++)
-        {
-          dgl[(bi * 3 + r) * NB + bk] = dgi[r];
-          lds[L_DBB + (bi * 3 + r) * NB + bk] = dgi[r] - (Ai[r * 4] * dj[0] + Ai[r * 4 + 1] * dj[1] + Ai[r * 4 + 2] * dj[2]);
-        }
-      }
-      __syncthreads();
     }
+    if(optimize_beta) // (uniform)
+    {
+      // (beside the chain entries' threads when the workgroup is large enough, else sharing threads with them)
+      constexpr int BETA_T0 = (EVAL_NT >= 512 + NJ * NB) ? 512 : EVAL_NT - 256;
+      static_assert(BETA_T0 >= 0 && BETA_T0 + NJ * NB <= EVAL_NT, "the beta columns take NJ * NB threads from BETA_T0");
+      // thread (joint i, k) works at the joint's level; its regressor rows are loaded ahead of the steps
+      const bool isb = tid >= BETA_T0 && tid < BETA_T0 + NJ * NB;
+      const int bi = isb ? (tid - BETA_T0) / NB : 0, bk = isb ? (tid - BETA_T0) % NB : 0, bp = s_par[bi];
+      const int blev = isb ? __popc(sAnc[bi]) - 1 : -1;
+      float dj[3] = {0.f, 0.f, 0.f}, dt[3] = {0.f, 0.f, 0.f};
+      if(isb)
+        for(int x = 0; x < 3; x++)
+        {
+          dj[x] = mv.JS[(bi * 3 + x) * NB + bk];
+          dt[x] = (bi == 0) ? dj[x] : dj[x] - mv.JS[(bp * 3 + x) * NB + bk];
+        }
+      for(int L = 0; L < nlev; L++)
+      {
+        if(blev == L)
+        {
+          float dgi[3];
+          if(bi == 0)
+            for(int x = 0; x < 3; x++) dgi[x] = dt[x];
+          else
+          {
+            const float * Ap = lds + L_G + bp * 12;
+            for(int r = 0; r < 3; r++) dgi[r] = (Ap[r * 4] * dt[0] + Ap[r * 4 + 1] * dt[1] + Ap[r * 4 + 2] * dt[2]) + dgl[(bp * 3 + r) * NB + bk];
+          }
+          const float * Ai = lds + L_G + bi * 12;
+          for(int r = 0; r < 3; r++)
+          {
+            dgl[(bi * 3 + r) * NB + bk] = dgi[r];
+            lds[L_DBB + (bi * 3 + r) * NB + bk] = dgi[r] - (Ai[r * 4] * dj[0] + Ai[r * 4 + 1] * dj[1] + Ai[r * 4 + 2] * dj[2]);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    __syncthreads();
   }
 
   EVAL_STAMP(2);
@@ -2907,7 +2952,7 @@ struct smplpp_ik
   float *verts = nullptr, *rest = nullptr, *joints = nullptr, *poserot = nullptr, *pts = nullptr;
   double *e = nullptr, *J = nullptr, *Jl = nullptr, *e2 = nullptr, *xout = nullptr;
   int *skip = nullptr, *status = nullptr, *sticky = nullptr, *list_cnt = nullptr, *list_f = nullptr;
-  int32_t * roles = nullptr; // [DMAX][EVAL_NT] chain-derivative entry of every thread of ik_eval_kernel at every tree level
+  int32_t * roles = nullptr; // [DMAX][EVAL_NT] the chain-derivative entries of every thread of ik_eval_kernel (slot u: row u)
   float * list_d = nullptr;
   std::vector<void *> owned;
   bool have_eval = false;
@@ -3007,14 +3052,19 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
       depth[i] = i ? depth[m->h_parent[i]] + 1 : 0;
       at[depth[i]].push_back(i);
     }
+    // every (joint i, ancestor depth da <= depth(i), axis, row) once, dealt to the threads ROUND-ROBIN: entry e goes to thread
+    // e % EVAL_NT as its e / EVAL_NT-th (SMPL: 1.2 k entries, two per thread at most).  (Rounds 1-3 filled row L with the entries
+    // of the joints at tree level L, the order their level-by-level recurrence needed; the closed form has no order, and with
+    // that filling the first wavefronts held nine entries each while the last held none.)
+    size_t e = 0;
     for(int L = 0; L < DMAX; L++)
     {
       const int per = 9 * (L + 1);
-      if((int)at[L].size() * per > EVAL_NT) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: kinematic tree too wide for the evaluation kernel");
-      for(int t = 0; t < (int)at[L].size() * per; t++)
+      for(int t = 0; t < (int)at[L].size() * per; t++, e++)
       {
+        if(e >= roles.size()) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: kinematic tree too wide for the evaluation kernel");
         const int ji = t / per, rem = t % per, da = rem / 9, a9 = rem % 9, i = at[L][ji];
-        roles[(size_t)L * EVAL_NT + t] = i | ((m->h_parent[i] & 31) << 5) | ((3 * da + a9 / 3) << 10) | ((a9 % 3) << 16) | ((da == L ? 1 : 0) << 18);
+        roles[e] = i | ((m->h_parent[i] & 31) << 5) | ((3 * da + a9 / 3) << 10) | ((a9 % 3) << 16) | ((da == L ? 1 : 0) << 18);
       }
     }
   }
