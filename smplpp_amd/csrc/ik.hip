@@ -1798,8 +1798,8 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
   // once the chunk is dead): wavefront w takes the row groups w, w + 4, ... and accumulates EVERY live tile from them — per group of
   // four rows NT operand reads feed NT (NT + 1) / 2 MFMAs (5 reads for 15), where the tile-per-wavefront form below pays two reads
   // per MFMA and is a chain of read -> wait -> 4 MFMAs per group: 31 groups x ~600 cycles for a capture solve against 8 x ~1100.
-  // The four partial sums are added in wavefront order when the tiles move into the factorisation's register layout.
-  const bool ksplit = NT <= 6 && 3 * nitemM <= chunk_rows * D; // (uniform)
+  // The four partial sums are added as (w0 + w2) + (w1 + w3) on the way into the factorisation's register layout.
+  const bool ksplit = NT <= 6 && 2 * (NT * (NT + 1) / 2) * 256 + nitemM <= chunk_rows * D; // (uniform: two raw partials + one packed triangle fit the row chunk)
   if(ksplit)
   {
     constexpr int NTILE = NT <= 6 ? NT * (NT + 1) / 2 : 1, NTK = NT <= 6 ? NT : 1;
@@ -1867,8 +1867,27 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
     __syncthreads(); // every wavefront is done with the row chunk: its LDS takes the partial sums of wavefronts 1..3
     SOLVE_STAMP(6);
     if(dbg_stop == 42) return;
+    // the four partial sums meet in two stages: wavefronts 2 and 3 drop theirs as they lie (lane-linear, [tile][register][lane]: no index
+    // arithmetic, no bank conflicts), wavefronts 0 and 1 add them in registers — (w0 + w2), (w1 + w3) — and write the packed
+    // triangles the factorisation's layout is gathered from, two reads per element instead of four
+    constexpr int PRAW = NTILE * 4 * 64; // doubles of one raw partial
+    double * const praw = Jc + (size_t)((wave & 1) * PRAW);
+    double * const ptri = Jc + 2 * PRAW; // wavefront 1's packed triangle (wavefront 0's: M)
+    if(wave >= 2)
     {
-      double * P = wave == 0 ? M : Jc + (size_t)(wave - 1) * nitemM;
+#pragma unroll
+      for(int u = 0; u < NTILE; u++)
+#pragma unroll
+        for(int rr = 0; rr < 4; rr++) praw[(u * 4 + rr) * 64 + l] = tacc[u][rr];
+    }
+    __syncthreads();
+    if(wave < 2)
+    {
+#pragma unroll
+      for(int u = 0; u < NTILE; u++)
+#pragma unroll
+        for(int rr = 0; rr < 4; rr++) tacc[u][rr] += praw[(u * 4 + rr) * 64 + l];
+      double * P = wave == 0 ? M : ptri;
 #pragma unroll
       for(int ta = 0; ta < NTK; ta++)
 #pragma unroll
@@ -1894,7 +1913,7 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
         if(i >= k && i <= nf && k < nf)
         {
           const int q = tri_idx(i, k);
-          sum = ((M[q] + Jc[q]) + Jc[nitemM + q]) + Jc[2 * nitemM + q];
+          sum = M[q] + ptri[q];
         }
         acc[a2][b2] = sum;
       }
@@ -2011,15 +2030,35 @@ __device__ inline void build_and_factor_reg(double * M, const double * __restric
       }
     __syncthreads(); // M is rewritten by the factorisation
   }
+  // damping on the diagonal, the prior's rhs on the augmented row: branch-free with every index read first, then every value (one
+  // conditional block per tile, each a pair of dependent LDS round trips, was 4 of the 5 us between the Gram and the factorisation)
+  {
+    const int ar = nf >> 4; // (uniform) the tile row that holds the rhs row i == nf
+    int id_[NT], ib_[NT];
 #pragma unroll
-  for(int a = 0; a < NT; a++)
-#pragma unroll
-    for(int b = 0; b <= a; b++)
+    for(int a = 0; a < NT; a++)
     {
-      const int i = ty + 16 * a, k = tx + 16 * b;
-      if(i < nf && i == k) acc[a][b] += diag[idx[i]];
-      if(i == nf && k < nf) acc[a][b] += bpri[idx[k]];
+      const int i = ty + 16 * a, k = tx + 16 * a;
+      id_[a] = idx[(ty == tx && i < nf) ? i : 0];
+      ib_[a] = idx[k < nf ? k : 0];
     }
+    double dv[NT], bv[NT];
+#pragma unroll
+    for(int a = 0; a < NT; a++)
+    {
+      dv[a] = diag[id_[a]];
+      bv[a] = bpri[ib_[a]];
+    }
+#pragma unroll
+    for(int a = 0; a < NT; a++)
+    {
+      const int i = ty + 16 * a;
+      acc[a][a] += (ty == tx && i < nf) ? dv[a] : 0.0;
+#pragma unroll
+      for(int b = 0; b <= a; b++)
+        acc[a][b] += (a == ar && i == nf && tx + 16 * b < nf) ? bv[b] : 0.0;
+    }
+  }
   if(dbg_stop == 4) return;
   SOLVE_STAMP(7);
   // factorisation, FOUR columns per barrier (round 2: two; the loop is a chain of barrier -> pivot reciprocals -> update, and
@@ -2202,7 +2241,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   int * idx = reinterpret_cast<int *>(dinv + D);
   int * state = idx + D; // 0 free, -1 at lo, +1 at hi, 2 pinned (empty box)
   double * ebuf = reinterpret_cast<double *>(state + D); // [rows] the residual, read from HBM once
-  __shared__ int s_bad, s_nf, s_block, s_bside, s_done, s_anybound, s_wcnt[4];
+  __shared__ int s_bad, s_nf, s_block, s_bside, s_done, s_anybound, s_wcnt[4], s_wany[4];
   __shared__ int s_rlist[DUAL_ONLY ? 1 : IK_MAXK * 4], s_nlive; // rows of J that are not identically zero (primal form: build_and_factor_reg)
   __shared__ double s_alpha, s_e2;
   // Everything the set-up reads from HBM is requested NOW, in one round trip: the skip flag, the residual, this thread's limit
@@ -2360,8 +2399,15 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       const int is_free = (st == 0), is_b = ((st == -1 || st == 1) && xfull[tid < D ? tid : 0] != 0.0);
       const uint64_t m = __ballot(is_free);
       const int wave = tid >> 6, lane = tid & 63;
-      if(lane == 0) s_wcnt[wave] = __popcll(m);
-      const int anyb = __syncthreads_or(is_b);
+      // (a ballot per wavefront and one barrier: __syncthreads_or funnels every thread through an LDS atomic — 2.7 us here, stamped)
+      const uint64_t mbnd = __ballot(is_b);
+      if(lane == 0)
+      {
+        s_wcnt[wave] = __popcll(m);
+        s_wany[wave] = mbnd != 0 ? 1 : 0;
+      }
+      __syncthreads();
+      const int anyb = s_wany[0] | s_wany[1] | s_wany[2] | s_wany[3];
       int base = 0;
       for(int w = 0; w < wave; w++) base += s_wcnt[w];
       if(is_free) idx[base + __popcll(m & ((1ull << lane) - 1ull))] = tid;
@@ -2387,6 +2433,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       s_block = -1;
     }
     __syncthreads();
+    SOLVE_STAMP(14);
     const int nf = s_nf;
     if(nf > m_dim) // (cannot happen: the host bound counts every variable that can be free)
     {
@@ -2404,6 +2451,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
           if(state[q] == -1 || state[q] == 1) s += J[(int64_t)r * D + q] * xfull[q];
       rowv[r] = s;
     }
+    SOLVE_STAMP(15);
     const bool dual = rows < nf && rows <= 63 && chunk_rows >= rows && nf <= 192 && (DUAL_ONLY || dbg_stop != 9);
     if(DUAL_ONLY && !dual) // (cannot happen: the host selects this instantiation only when every pass qualifies)
     {
@@ -2579,7 +2627,11 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     {
       int atb = 0;
       for(int i = tid; i < D; i += 256) atb |= (state[i] == -1 || state[i] == 1);
-      if(!__syncthreads_or(atb))
+      const uint64_t matb = __ballot(atb);
+      __syncthreads(); // (s_wany's readers of the free-set step are long past)
+      if((tid & 63) == 0) s_wany[tid >> 6] = matb != 0 ? 1 : 0;
+      __syncthreads();
+      if(!(s_wany[0] | s_wany[1] | s_wany[2] | s_wany[3]))
       {
         if(tid == 0) s_done = 1;
         __syncthreads();

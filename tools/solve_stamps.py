@@ -39,6 +39,7 @@ L = _lib.load(); buf = (ctypes.c_ulonglong * (64 * 16))()
 L.smplpp_debug_solve_stamps.restype = ctypes.c_int
 assert L.smplpp_debug_solve_stamps(buf) == 0
 TT = np.array(buf, dtype=np.uint64).reshape(64, 16)[:min(R, 64)].astype(np.int64)
+print("between set-up and staging: free-set list %.2f us, rowv %.2f us, into the build (tile columns, W) %.2f us" % tuple(np.median(x) * 0.01 for x in (TT[:, 14] - TT[:, 1], TT[:, 15] - TT[:, 14], TT[:, 2] - TT[:, 15])))
 print("staging: addresses %.2f us, issue %.2f us, wait %.2f us" % tuple(np.median(x) * 0.01 for x in (TT[:, 12] - TT[:, 3], TT[:, 13] - TT[:, 12], TT[:, 4] - TT[:, 13])))
 T = TT[:, :12]
 nm = ["set-up", "lists+rowv+tiles", "barrier", "voff+DMA+wait", "barrier", "Gram", "tiles->regs", "factorisation", "pivots+scale", "back subst", "QP tail+update"]
