@@ -222,7 +222,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=40, help="launches of the separate loop that times the fused kernel with HIP events")
     ap.add_argument("--model", default=os.environ.get("SMPLPP_MODEL"),
                     help="a real model in the reference's schema (smpl_male.npz / .json from scripts/preprocess.py:98-117; default: "
-                         "$SMPLPP_MODEL): replaces the synthetic stand-in everywhere in this run, `data` becomes \"real\"")
+                         "$SMPLPP_MODEL): replaces the synthetic stand-in everywhere in this run, `data` becomes \"real\" (or "
+                         "\"synthetic (model file)\" when the file holds the synthetic stand-in)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses GPU 0 (use with --backend gloo)")
@@ -263,16 +264,21 @@ def main():
     theta = torch.from_numpy(theta_h).cuda()
     out = {"verts": torch.empty((n, V, 3), dtype=torch.float32, device="cuda")}
 
+    def region(work):
+        """The contract's bracket (dist.timed_region): synchronize + barrier, clock, work, synchronize, THIS rank's clock read, closing
+        barrier, then max / min over ranks — no collective inside the clock.  Returns {"max" (the job's seconds), "min", "per_rank", ...}."""
+        return D.timed_region(work, torch.cuda.synchronize)
+
     def timed(engine, steps):
-        """`steps` launches of the FK step bracketed by barrier + synchronize on both sides; max over ranks (seconds)."""
-        torch.cuda.synchronize()
-        D.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            engine.launch(beta, theta, want=("verts",), out=out)
-        torch.cuda.synchronize()
-        D.barrier()
-        return D.max_over_ranks(time.perf_counter() - t0)
+        """`steps` launches of the FK step in the contract's bracket; spread over ranks (seconds)."""
+        def work():
+            for _ in range(steps):
+                engine.launch(beta, theta, want=("verts",), out=out)
+        return region(work)
+
+    def rank_ms(spread, per=1.0):
+        """per-rank milliseconds of a region (min / max / which rank was slowest) for the N > 1 lines"""
+        return {"min": spread["min"] / per * 1e3, "max": spread["max"] / per * 1e3, "slowest_rank": spread["rank_of_max"]}
 
     def kernel_ms(engine, steps):
         """the fused kernel's own duration: a separate short loop with HIP events on the launch stream (never inside a timed region)"""
@@ -292,7 +298,7 @@ def main():
     # `sustained` (2000 launches) beside it the line no longer depends on how short --steps is.
     for _ in range(args.preroll_steps + args.warmup):
         smpl.launch(beta, theta, want=("verts",), out=out)
-    cold_elapsed = timed(smpl, args.steps)
+    cold_elapsed = timed(smpl, args.steps)["max"]
 
     # ---- IK leg (BASELINE.json configs[2]): 6 targets, 50 iterations, 256 frames per GPU
     ik = None
@@ -314,22 +320,20 @@ def main():
         solver = IkSolver(smpl, args.ik_frames, K)
         solver.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, phi_limit=np.zeros(K), normal_task_weight=np.ones(K))
         reps = 3
-        ik_t = 0.0
+        ik_t, ik_min = 0.0, 0.0
+        res = {}
         for rep in range(reps + 1):
             solver.setTasks(face_idx=faces, vertex_weights=np.full((K, 3), 1 / 3, np.float32))
             solver.setConfig(np.zeros((args.ik_frames, 10), np.float32), theta0)
-            torch.cuda.synchronize()
-            D.barrier()
-            t1 = time.perf_counter()
-            e2 = solver.iterate(args.ik_iters)
-            torch.cuda.synchronize()
-            D.barrier()
+            sp = region(lambda: res.__setitem__("e2", solver.iterate(args.ik_iters)))
             if rep > 0:  # rep 0 is warm-up
-                ik_t += time.perf_counter() - t1
-        ik_t = D.max_over_ranks(ik_t / reps)
+                ik_t += sp["max"] / reps
+                ik_min += sp["min"] / reps
+        e2 = res["e2"]
         ik = {
             "value": world * args.ik_frames * args.ik_iters / ik_t, "unit": "IK iterations/s", "frames_per_gpu": args.ik_frames,
             "iters": args.ik_iters, "tasks": K, "ms_per_iter_batch": ik_t / args.ik_iters * 1e3,
+            "ms_per_iter_batch_fastest_rank": ik_min / args.ik_iters * 1e3,
             "final_max_e_sqnorm": float(np.max(e2)), "final_median_e_sqnorm": float(np.median(e2)),
             "frames_below_1e-3": int((e2 < 1e-3).sum()),  # the normal terms make the problem non-convex: a start can end in a local minimum
             "workload": "configs[2]: 6-target IK (position + normal term per target), 50 iterations, direct theta (D = 87)",
@@ -367,14 +371,11 @@ def main():
             th0 = np.ascontiguousarray(th0_all[rlo:rhi])
             ms = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R, chain_base=rlo)
             ms.solve(pts, mvalid, np.zeros(10, np.float32), th0, max_frames=2)  # warm-up of the code path
-        torch.cuda.synchronize()
-        D.barrier()
-        t1 = time.perf_counter()
+        res = {}
+        msp = region(lambda: res.__setitem__("m", ms.solve(pts, mvalid, np.zeros(10, np.float32), th0)) if R > 0 else None)
+        mt = msp["max"]
         if R > 0:
-            thm, fr = ms.solve(pts, mvalid, np.zeros(10, np.float32), th0)
-        torch.cuda.synchronize()
-        D.barrier()
-        mt = D.max_over_ranks(time.perf_counter() - t1)
+            thm, fr = res["m"]
         nfr = T
         iters = mocap.MocapMotionSolver.WARMUP_ITERS + nfr - 1
         skipped = int((mvalid.sum(axis=1) < Km // 2).sum())
@@ -387,7 +388,11 @@ def main():
                         "direct theta (D = 157); frame loop on the device (smplpp_ik_solve_sequence)" % (nfr, args.mocap_restarts, world),
         }
 
-        mocap_leg["per_frame_us"] = mt / max(1, iters) * 1e6  # one IK iteration of all this rank's chains in lock step
+        # one IK iteration of a rank's chains in lock step: the job's (slowest rank's) period, and every rank's own — at N = 8 each rank
+        # holds 8 chains and this IS the 8-chain figure the 1-GPU line reports as per_frame_us_at_8_chains
+        mocap_leg["per_frame_us"] = mt / max(1, iters) * 1e6
+        mocap_leg["per_frame_us_per_rank"] = [t / max(1, iters) * 1e6 for t in msp["per_rank"]]
+        mocap_leg["chains_per_rank"] = D.shard_sizes(args.mocap_restarts, world)
         # one GPU's share of the 8-GPU split (64 restarts -> 8 chains per GPU): the serial per-frame period the 8-GPU number is made of
         # (chains of a frame sequence cannot be parallelised along the sequence: node.cpp:1369-1407), measured here on ONE GPU
         if world == 1 and args.mocap_restarts >= 8:
@@ -409,16 +414,13 @@ def main():
             msv = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R, vposer=vp, chain_base=rlo)
             gv0 = np.ascontiguousarray(gv0_all[rlo:rhi])
             msv.solve(pts, mvalid, np.zeros(10, np.float32), gv0, max_frames=2)
-        torch.cuda.synchronize()
-        D.barrier()
-        t1 = time.perf_counter()
+        msvp = region(lambda: res.__setitem__("v", msv.solve(pts, mvalid, np.zeros(10, np.float32), gv0)) if R > 0 else None)
+        mtv = msvp["max"]
         if R > 0:
-            thv, frv = msv.solve(pts, mvalid, np.zeros(10, np.float32), gv0)
-        torch.cuda.synchronize()
-        D.barrier()
-        mtv = D.max_over_ranks(time.perf_counter() - t1)
+            thv, frv = res["v"]
         mocap_leg["vposer_latent"] = {
             "value": args.mocap_restarts * nfr / mtv, "unit": "solved capture frames/s", "seconds": mtv,
+            "per_frame_us": mtv / max(1, iters) * 1e6, "per_frame_us_per_rank": [t / max(1, iters) * 1e6 for t in msvp["per_rank"]],
             "finite": bool(np.isfinite(thv).all()) if R > 0 else True,
             "workload": "same sequence with the 44-d VPoser layout the reference forces on capture solves (D = 126), synthetic decoder weights",
         }
@@ -439,20 +441,19 @@ def main():
             if nv > 0:
                 vs.setTasks(face_idx=vfaces, vertex_weights=np.full((Kv, 3), 1 / 3, np.float32))
                 vs.setConfig(np.zeros((nv, 10), np.float32), g0)
-            torch.cuda.synchronize()
-            D.barrier()
-            t1 = time.perf_counter()
-            if nv > 0:
-                ev = vs.iterate(args.ik_iters)
-            torch.cuda.synchronize()
-            D.barrier()
+            sp = region(lambda: res.__setitem__("ev", vs.iterate(args.ik_iters)) if nv > 0 else None)
             if rep > 0:
-                vt += time.perf_counter() - t1
-        vt = D.max_over_ranks(vt / 2)
+                vt += sp["max"] / 2
+        if nv > 0:
+            ev = res["ev"]
+        # convergence of the timed solves, over ALL ranks' frames (like the `ik` leg: the line shows whether the 50 iterations ran on
+        # converging solves, not only the worst frame)
+        ev_all = D.gather_values(np.asarray(ev, np.float64) if nv > 0 else np.zeros(0))
         vposer_leg = {
             "value": args.vposer_frames * args.ik_iters / vt, "unit": "IK iterations/s", "frames_total": args.vposer_frames,
             "frames_this_rank": nv, "iters": args.ik_iters, "tasks": Kv,
-            "ms_per_iter_batch": vt / args.ik_iters * 1e3, "final_max_e_sqnorm": float(np.max(ev)),
+            "ms_per_iter_batch": vt / args.ik_iters * 1e3, "final_max_e_sqnorm": float(np.max(ev_all)),
+            "final_median_e_sqnorm": float(np.median(ev_all)), "frames_below_1e-3": int((ev_all < 1e-3).sum()),
             "workload": "configs[4]: VPoser-latent IK (32-d latent + decoder in the loop, 44-d layout, D = 56), %d frames sharded x%d, "
                         "synthetic decoder weights" % (args.vposer_frames, world),
         }
@@ -460,14 +461,15 @@ def main():
     # ---- the headline FK region (see `cold_start` above): W warm-up launches, then exactly K timed ones
     for _ in range(args.warmup):
         smpl.launch(beta, theta, want=("verts",), out=out)
-    elapsed = timed(smpl, args.steps)
+    elapsed_sp = timed(smpl, args.steps)
+    elapsed = elapsed_sp["max"]
     launches, skin_ms = kernel_ms(smpl, args.profile_steps)
     # the steady clock: after idle the chip ramps its clocks UP over the first ~400 launches (57 -> 49 us per step over 25 ms,
     # tools/fk_ramp.py), so a short --steps region right behind model creation is timed on a chip that has not settled; the
     # same step is timed once more over a long run, after the contract's region
     sustained = None
     if args.sustained_steps > 0:
-        sus_t = timed(smpl, args.sustained_steps)
+        sus_t = timed(smpl, args.sustained_steps)["max"]
         sustained = {"launches": args.sustained_steps, "ms_per_step": sus_t / args.sustained_steps * 1e3,
                      "value": world * n * args.sustained_steps / sus_t, "unit": "FK evals/s",
                      "note": "the same step over a long run behind the contract's region: the steady-clock figure (after idle the chip "
@@ -491,7 +493,7 @@ def main():
         for _ in range(args.warmup):
             smpl_b.launch(beta, theta, want=("verts",), out=out)
         ex_steps = max(args.steps, 200)
-        ex_t = timed(smpl_b, ex_steps)
+        ex_t = timed(smpl_b, ex_steps)["max"]
         ex_launches, ex_kms = kernel_ms(smpl_b, args.profile_steps)
         exact = {"steps": ex_steps, "t": ex_t, "kernel_ms": ex_kms, "launches": ex_launches}
         del smpl_b
@@ -500,24 +502,26 @@ def main():
     # the only exchange of the path: the final gather of the results to rank 0 (every peer sends its block once, into its slot
     # of rank 0's array: dist.gather_rows), always timed when N > 1
     gather_ms = None
-    ranks_reported = 1
+    counted = None
     if world > 1:
-        import torch.distributed as tdist
-
-        ranks_reported = int(tdist.get_world_size())
+        counted = D.count_ranks()  # an all-reduce(SUM) of a one per rank through the collective library itself (on the device under RCCL)
         D.gather_rows(out["verts"][:1], world)  # one row per rank first: the point-to-point channels are set up outside the timed gather
-        torch.cuda.synchronize()
-        D.barrier()
-        t1 = time.perf_counter()
-        full = D.gather_rows(out["verts"], n * world)
-        torch.cuda.synchronize()
-        gather_ms = D.max_over_ranks((time.perf_counter() - t1) * 1e3)
-        del full
+        res = {}
+        gather_ms = region(lambda: res.__setitem__("full", D.gather_rows(out["verts"], n * world)))["max"] * 1e3
+        res.clear()
 
     if rank != 0:
         return
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n * args.steps / elapsed
+    # "synthetic" unless a model FILE was given; a file is "real" only when it is not the synthetic stand-in written to disk
+    # (tests do that to walk the on-disk schema): the stand-in's template is recognised by content
+    data_label = "synthetic"
+    if args.model:
+        syn = model_io.synthetic_model()
+        same = syn["vertices_template"].shape == model["vertices_template"].shape and np.array_equal(
+            np.asarray(syn["vertices_template"], np.float32), np.asarray(model["vertices_template"], np.float32))
+        data_label = "synthetic (model file)" if same else "real"
     form = form_env if form_env in ("h", "b", "p", "v") else "h"
     traffic_all = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -528,6 +532,9 @@ def main():
             traffic_all = {}
     roofline = roofline_object(form, n, skin_ms, launches, traffic_all.get("skin_kernel_%s_hbm_bytes_per_launch_n%d" % (form, n)))
     # `traffic` is a constant of the committed profile collection (separate rocprofv3 --pmc passes cannot run inside this program): which one
+    # the same bytes against the whole STEP (pose kernel + fused kernel + launch gaps): what `value` is made of
+    alg_bytes = ALG_BYTES_CONST + ALG_BYTES_PER_FRAME * n
+    roofline["step_hbm_frac"] = alg_bytes / (ms_per_step * 1e-3) / (PEAK_HBM_GBS * 1e9)
     roofline["traffic_source"] = {"file": "profiles/traffic.json", "tag": traffic_all.get("tag"),
                                   "kernel_us_in_that_run": traffic_all.get("skin_kernel_%s_rocprofv3_avg_us_same_run" % form)}
     line = {
@@ -542,7 +549,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": DTYPES.get(form, "f32"),
-        "data": "real" if args.model else "synthetic",
+        "data": data_label,
         "config": {
             "workload": "configs[1]: batch-%d random beta/theta FK+LBS per GPU, %s "
                         "(%d verts, 24 joints, 207 pose / 10 shape PCs), HBM-resident in/out"
@@ -550,6 +557,7 @@ def main():
             "frames_per_gpu": n, "parallelism": "frames sharded x%d, no data-path collective" % world,
         },
         "roofline": roofline,
+        "model_source": ("file " + os.path.basename(args.model) + (" (from $SMPLPP_MODEL)" if os.environ.get("SMPLPP_MODEL") == args.model and "--model" not in sys.argv else "")) if args.model else "built in (model_io.synthetic_model)",
         #  where the contract's W + K region sits in this run, so rounds compare like for like: r01-r02 lines timed it
         # right behind model creation (= today's `cold_start`), r03 on behind the IK legs
         "value_region": "W warm-up + K timed launches BEHIND the IK legs (a chip that has been busy); the same region right behind "
@@ -577,7 +585,9 @@ def main():
         line["vposer_ik"] = vposer_leg
     if gather_ms is not None:
         line["final_gather_ms"] = gather_ms
-        line["ranks_reported_by_rccl"] = ranks_reported
+        line.update(counted)  # "collective_backend" ("nccl" = RCCL, or "gloo" in rehearsals), "ranks_counted_by_allreduce"
+        line["ms_per_step_ranks"] = rank_ms(elapsed_sp, args.steps)
+        line["timing"] = "per rank: synchronize + barrier, clock, K launches, synchronize, clock; max over ranks (no collective inside the clock)"
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(model, n)
         if ik is not None:

@@ -184,12 +184,15 @@ int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * target_pos,
 int smplpp_ik_get_vertices(smplpp_ik * s, float * verts, int space, void * stream);
 /* Outcome of the solves so far, per frame: bit 0 = the LAST solve failed with the reference's "LLT has numerical issue!"
  * (node/node.cpp:934-937; that frame's update was skipped), bit 1 = some solve failed since the configuration was set /
- * the sequence started, bit 2 = an evaluation since then met a task WITH A NORMAL TERM (normal weight or normal offset) on a
- * vertex of more than 12 adjacent faces: the analytic Jacobian differentiates vertex normals through tables of 12 faces per vertex
- * (src/SMPL.cpp:527-535 puts no bound on it), so those rows are unsupported; position-only tasks are unaffected and any model gets
- * its solver.  Host-space eval / iterate / solve_sequence calls return SMPLPP_ERR_NUMERIC (bits 0, 1) or SMPLPP_ERR_INVALID
- * (bit 2) themselves; enqueue-only (SMPLPP_DEVICE) callers have no return value to inspect and read it here (waits for `stream`
- * first). flags [n]. */
+ * the sequence started, bit 2 = an evaluation since the tasks were last set met a task WITH A NORMAL TERM (normal weight or normal
+ * offset) on a vertex of more than 12 adjacent faces: the analytic Jacobian differentiates vertex normals through tables of 12 faces
+ * per vertex (src/SMPL.cpp:527-535 puts no bound on it), so those rows are unsupported — the solve SKIPS the update of such a frame
+ * (no caller moves on a truncated Jacobian) and smplpp_ik_set_tasks clears the bit (it belongs to the tasks; the next evaluation
+ * raises it again where it still applies); position-only tasks are unaffected and any model gets its solver.  Bit 3 = a forward
+ * pass inside a loop on this model met an operand outside the fp16x2 form's range since the last smplpp_ik_set_config (one word per
+ * model: every frame of the batch carries it).  Host-space eval / iterate / solve_sequence calls return SMPLPP_ERR_NUMERIC
+ * (bits 0, 1) or SMPLPP_ERR_INVALID (bit 2) themselves; enqueue-only (SMPLPP_DEVICE) callers have no return value to inspect and
+ * read it here (waits for `stream` first). flags [n]. */
 int smplpp_ik_get_status(smplpp_ik * s, int32_t * flags, int space, void * stream);
 
 /* Streams and sharing.  A model owns ONE workspace (pose coefficients, relative transforms of the last forward pass) that
@@ -213,6 +216,10 @@ int smplpp_gather(void * comm, const float * send, float * recv, const int64_t *
  * of the all-gather's traffic at eight ranks.  In place on root when `send` is its own slot of `recv`. */
 int smplpp_gather_to_root(void * comm, const float * send, float * recv, const int64_t * rows_per_rank, int world, int rank, int root,
                           int64_t row_floats, void * stream);
+/* Start-up check of the RCCL binding (resolved at run time, see above): `rank` exchanges `count_floats` floats with ITSELF in one
+ * ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd — the calls smplpp_gather_to_root makes for a peer — so a host learns before
+ * the job, not at its end, whether the library it loaded speaks this ABI.  Device pointers, `send` != `recv`; enqueued on `stream`. */
+int smplpp_gather_selfcheck(void * comm, int rank, const float * send, float * recv, int64_t count_floats, void * stream);
 /* Where each rank's block lies in the gathered array: offsets[world + 1] in floats (the last entry is the total).  Host-only
  * arithmetic shared by the two collectives; callable without a GPU. */
 int smplpp_gather_offsets(const int64_t * rows_per_rank, int world, int64_t row_floats, int64_t * offsets);

@@ -85,6 +85,7 @@ def load():
         "smplpp_gather": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp],
         "smplpp_gather_to_root": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp],
         "smplpp_gather_offsets": [i64p, C.c_int, C.c_int64, i64p],
+        "smplpp_gather_selfcheck": [vp, C.c_int, vp, vp, C.c_int64, vp],
         "smplpp_vposer_create": [C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(vp)],
         "smplpp_vposer_destroy": [vp],
         "smplpp_vposer_forward": [vp, C.c_int64, vp, vp, vp, C.c_int, vp],

@@ -443,13 +443,15 @@ extern "C" int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const 
                      joints ? ws.joints.as<float>() : nullptr, xforms ? ws.xf44.as<float>() : nullptr,
                      rest ? ws.rest.as<float>() : nullptr, nullptr, st, RANGE_HOST);
   if(rc) return rc;
-  int bits = 0;
-  if(ranged) HIP_TRY(hipMemcpyAsync(&bits, m->range_flag + RANGE_HOST, sizeof(int), hipMemcpyDeviceToHost, st));
   if(verts) HIP_TRY(hipMemcpyAsync(verts, ws.verts.p, nv, hipMemcpyDeviceToHost, st));
   if(rest) HIP_TRY(hipMemcpyAsync(rest, ws.rest.p, nv, hipMemcpyDeviceToHost, st));
   if(joints) HIP_TRY(hipMemcpyAsync(joints, ws.joints.p, sizeof(float) * (size_t)n * NJ * 3, hipMemcpyDeviceToHost, st));
   if(xforms) HIP_TRY(hipMemcpyAsync(xforms, ws.xf44.p, sizeof(float) * (size_t)n * NJ * 16, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  // (read AFTER the synchronisation, synchronously: an asynchronous copy into this frame's stack could still be pending when one of
+  // the copies above fails and the function returns)
+  int bits = 0;
+  if(ranged) HIP_TRY(hipMemcpy(&bits, m->range_flag + RANGE_HOST, sizeof(int), hipMemcpyDeviceToHost));
   if(bits & 1)
     return fail(SMPLPP_ERR_NUMERIC, "smplpp_fk: an operand left the range of the fp16x2 form (|beta| < 1023, relative transforms within 16 x the "
                                     "template's extent): the vertices of such frames are not finite; create the model under SMPLPP_SKIN=b or p");

@@ -114,6 +114,33 @@ extern "C" int smplpp_gather_to_root(void * comm, const float * send, float * re
   return check(r.gend(), "ncclGroupEnd");
 }
 
+// Start-up check of the run-time binding for a host about to use the gather: one grouped ncclSend / ncclRecv pair of `rank` with
+// ITSELF (RCCL completes a self-exchange inside the group as a device copy), through the very function pointers, datatype constant
+// and group calls smplpp_gather_to_root uses.  A one-rank communicator never reaches those calls through the gather itself (it
+// has no peer), so this is also how the send / receive leg is exercised on a one-GPU box (tests/test_gather_gpu.py).
+extern "C" int smplpp_gather_selfcheck(void * comm, int rank, const float * send, float * recv, int64_t count_floats, void * stream)
+{
+  if(!comm || rank < 0 || !send || !recv || count_floats <= 0 || send == recv) return fail(SMPLPP_ERR_INVALID, "smplpp_gather_selfcheck: bad argument");
+  Rccl & r = rccl();
+  if(!r.send || !r.recv || !r.gstart || !r.gend)
+    return fail(SMPLPP_ERR_HIP, "smplpp_gather_selfcheck: RCCL is not available (librccl.so could not be loaded)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  auto check = [&](int e, const char * what) -> int {
+    if(e == 0) return (int)SMPLPP_OK;
+    return fail(SMPLPP_ERR_HIP, std::string("smplpp_gather_selfcheck: ") + what + " failed: " + (r.errstr ? r.errstr(e) : "RCCL error"));
+  };
+  int rc;
+  if((rc = check(r.gstart(), "ncclGroupStart"))) return rc;
+  const int es = r.send(send, (size_t)count_floats, NCCL_FLOAT32, rank, comm, st);
+  const int er = es ? 0 : r.recv(recv, (size_t)count_floats, NCCL_FLOAT32, rank, comm, st);
+  if(es || er)
+  {
+    (void)r.gend();
+    return check(es ? es : er, es ? "ncclSend" : "ncclRecv");
+  }
+  return check(r.gend(), "ncclGroupEnd");
+}
+
 extern "C" int smplpp_gather(void * comm, const float * send, float * recv, const int64_t * rows_per_rank, int world, int rank,
                              int64_t row_floats, void * stream)
 {

@@ -54,7 +54,8 @@ struct TaskArrays
   float * anrm;    // [n,K,3]
   float * hint;    // [n,K] squared distance of the actual position to the task's own face (cull radius of the re-projection)
   int * flags;     // [n] sticky per-frame status word (smplpp_ik_get_status): bit 0 a solve failed, bit 2 a task with a normal term
-                   // touches a vertex with more than MAXADJ adjacent faces (its Jacobian rows are not supported)
+                   // touches a vertex with more than MAXADJ adjacent faces (its Jacobian rows are not supported; cleared by
+                   // smplpp_ik_set_tasks, the solve skips the update of a frame that carries it)
   float * roww;    // [n,K,2] the (position, normal) task weights the LAST evaluation used: what decides which rows of J can be
                    // non-zero.  Written by ik_eval_kernel, read by ik_solve_kernel on the same stream — posw itself may already
                    // hold the NEXT frame's validity by then (the sequence driver's switch rides on the side stream's finish kernel)
@@ -2319,7 +2320,10 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     if(tid == 0)
     {
       s_e2 = s;
-      s_bad = 0;
+      // bit 2 of the frame's word (this stream's evaluation raised it: a normal term on a vertex beyond MAXADJ faces): its Jacobian
+      // rows are truncated, so the update is skipped like one whose factorisation failed — an enqueue-only caller never moves on a
+      // wrong Jacobian, and reads the reason in smplpp_ik_get_status
+      s_bad = (sticky[f] & 4) ? 1 : 0;
       s_done = 0;
       if(e2_out) e2_out[f] = s;
     }
@@ -2678,7 +2682,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   if(tid == 0)
   {
     status[f] = s_bad ? 1 : ((enable_qp && !s_done) ? 2 : 0);
-    if(s_bad) sticky[f] = sticky[f] | 1; // survives later solves (sequence driver); bit 2 is the evaluation's (TaskArrays::flags)
+    if(s_bad && !(sticky[f] & 4)) sticky[f] = sticky[f] | 1; // survives later solves (sequence driver); bit 2 is the evaluation's (TaskArrays::flags)
   }
   const bool ok = !s_bad;
   // config update (node.cpp:945-968), fp32
@@ -2963,6 +2967,11 @@ __global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArra
   wg_signal(sig_flag, sig_counter, sig_tick);
 }
 
+__global__ void clear_bits_kernel(int * p, int bits, int64_t n)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n) p[i] &= ~bits;
+}
 __global__ void fill_f32_kernel(float * p, float v, int64_t n)
 {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3283,6 +3292,13 @@ extern "C" int smplpp_ik_set_tasks(smplpp_ik * s, const int64_t * face_idx, cons
   auto cpf = [](const float * a, float * b, int64_t c) { (void)hipMemcpy(b, a, sizeof(float) * c, hipMemcpyDeviceToDevice); };
   auto cvd = [&](const double * a, float * b, int64_t c) { f64_to_f32_kernel<<<g(c), 256>>>(a, b, c); };
   auto cvi = [&](const int64_t * a, int32_t * b, int64_t c) { i64_to_i32_kernel<<<g(c), 256>>>(a, b, c); };
+  // bit 2 of the status word (a normal term on a vertex beyond MAXADJ faces) belongs to the tasks the evaluation met: new faces,
+  // weights or normal terms start clean, and the next evaluation raises it again where it still applies
+  if(face_idx || normal_task_weight || normal_offset || vertex_weights)
+  {
+    clear_bits_kernel<<<g((int64_t)s->n), 256>>>(s->sticky, 4, (int64_t)s->n);
+    HIP_TRY(hipGetLastError());
+  }
   if((rc = set_array(face_idx, s->ta.face, nk, space, cvi))) return rc;
   if((rc = set_array(vertex_weights, s->ta.vw, nk * 3, space, cpf))) return rc;
   if((rc = set_array(target_pos, s->ta.tpos, nk * 3, space, cpf))) return rc;
@@ -3314,6 +3330,7 @@ extern "C" int smplpp_ik_set_config(smplpp_ik * s, const float * beta, const flo
   // status bit 1 (smplpp_ik_get_status) reports failures "since the configuration was set": a new configuration starts clean
   HIP_TRY(hipMemset(s->status, 0, sizeof(int) * s->n));
   HIP_TRY(hipMemset(s->sticky, 0, sizeof(int) * s->n));
+  if(s->m->range_flag) HIP_TRY(hipMemset(s->m->range_flag + RANGE_INTERNAL, 0, sizeof(int))); // (status bit 3: same lifetime)
   if(theta && s->vp) // latent layout: the entries that pass through to theta25 (the decoder fills the rest at every evaluation)
   {
     ik_splice_kernel<<<dim3((unsigned)((s->n * 75 + 255) / 256)), 256>>>(s->theta, nullptr, s->theta25, s->n);
@@ -3661,8 +3678,8 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
   if(space == SMPLPP_HOST)
   {
     HIP_TRY(hipStreamSynchronize(st));
+    if((rc = ik_check_valence(s))) return rc; // (first: such a frame's solve reports itself as skipped too)
     if((rc = ik_check_status(s, s->status))) return rc;
-    if((rc = ik_check_valence(s))) return rc;
   }
   return SMPLPP_OK;
 }
@@ -3733,16 +3750,17 @@ extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * 
   if(space == SMPLPP_HOST)
   {
     HIP_TRY(hipStreamSynchronize(st));
-    if((rc = ik_check_status(s, s->sticky))) return rc;
     if((rc = ik_check_valence(s))) return rc;
+    if((rc = ik_check_status(s, s->sticky))) return rc;
   }
   return SMPLPP_OK;
 }
 
 // Per-frame outcome of the solves so far: flags[f] bit 0 = the last solve of frame f failed ("LLT has numerical issue!",
 // node/node.cpp:934-937: the update of that frame was skipped), bit 1 = some solve since the last set_config /
-// solve_sequence start failed, bit 2 = an evaluation since then met a task with a normal term on a vertex of more than 12
-// adjacent faces (its Jacobian rows are not supported).  SMPLPP_HOST calls of iterate / solve_sequence report the same condition as an error; a
+// solve_sequence start failed, bit 2 = an evaluation since the tasks were last set (smplpp_ik_set_tasks clears it; so do set_config
+// and solve_sequence) met a task with a normal term on a vertex of more than 12 adjacent faces: its Jacobian rows are not supported,
+// and the solve skips that frame's update (bit 0 then reads 1 as for any skipped update).  SMPLPP_HOST calls of iterate / solve_sequence report the same condition as an error; a
 // SMPLPP_DEVICE (enqueue-only) caller reads it here once its stream has reached the point of interest.
 extern "C" int smplpp_ik_get_status(smplpp_ik * s, int32_t * flags, int space, void * stream)
 {
@@ -3755,8 +3773,14 @@ extern "C" int smplpp_ik_get_status(smplpp_ik * s, int32_t * flags, int space, v
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipMemcpy(a.data(), s->status, sizeof(int) * s->n, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(b.data(), s->sticky, sizeof(int) * s->n, hipMemcpyDeviceToHost));
+  // bit 3: a forward pass INSIDE the loops of a solver on this model met an operand outside the fp16x2 form's range since the last
+  // set_config (one word per model — which frame is not recorded, so every frame of the batch carries it; such a frame's vertices
+  // are not finite and its solve then fails on its own)
+  int internal = 0;
+  if(s->m->range_flag && s->m->form == 'h') HIP_TRY(hipMemcpy(&internal, s->m->range_flag + RANGE_INTERNAL, sizeof(int), hipMemcpyDeviceToHost));
   std::vector<int32_t> h((size_t)s->n);
-  for(int64_t f = 0; f < s->n; f++) h[(size_t)f] = (a[(size_t)f] == 1 ? 1 : 0) | ((b[(size_t)f] & 1) ? 2 : 0) | (b[(size_t)f] & 4);
+  for(int64_t f = 0; f < s->n; f++)
+    h[(size_t)f] = (a[(size_t)f] == 1 ? 1 : 0) | ((b[(size_t)f] & 1) ? 2 : 0) | (b[(size_t)f] & 4) | ((internal & 1) ? 8 : 0);
   if(space == SMPLPP_HOST)
     memcpy(flags, h.data(), sizeof(int32_t) * (size_t)s->n);
   else

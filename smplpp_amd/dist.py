@@ -32,6 +32,11 @@ def launch_plan(gpus: int, environ=None) -> str:
         raise SystemExit("--gpus must be >= 1")
     ws = environ.get("WORLD_SIZE")
     if ws is None:
+        if gpus > 1 and profiler_preloaded(environ):
+            # the ranks are FRESH processes (allowed: nothing here re-execs a process that touched the GPU), but each inherits the
+            # profiler's preload and writes its own trace — say so instead of leaving N interleaved outputs unexplained
+            sys.stderr.write("launch_plan: a profiler preload is active (LD_PRELOAD / ROCP*): each of the %d ranks this program starts "
+                             "will be profiled on its own; to profile ONE rank, run it under torch.distributed.run instead\n" % gpus)
         return "single" if gpus == 1 else "spawn"
     if int(ws) != gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%s in the environment: launch %d ranks, or unset WORLD_SIZE and let the "
@@ -39,46 +44,85 @@ def launch_plan(gpus: int, environ=None) -> str:
     return "single" if gpus == 1 else "rank"
 
 
+def profiler_preloaded(environ=None) -> bool:
+    """rocprofv3 and friends work by preloading a tool library into the program (LD_PRELOAD, ROCP_TOOL_LIBRARIES / ROCPROFILER_*)."""
+    environ = os.environ if environ is None else environ
+    pre = environ.get("LD_PRELOAD", "")
+    return ("rocprof" in pre) or any(k.startswith(("ROCP_", "ROCPROFILER_", "ROCPROF_")) for k in environ)
+
+
 def free_port() -> int:
+    """A port that was free a moment ago.  The socket is closed before the ranks bind it (torch's TCPStore cannot adopt a bound
+    socket), so two jobs started at the same instant can still collide: launch_ranks retries the whole launch on EADDRINUSE."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
+TAIL_LINES = 40  # of a failed rank's stderr, repeated under a header once the job has stopped
+PORT_RETRIES = 3
+
+
 def launch_ranks(argv: Sequence[str], world: int, extra_env: Optional[dict] = None, timeout: Optional[float] = None,
                  stdout=None, stderr=None) -> int:
     """Start `world` FRESH child processes of `argv` — one per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
-    MASTER_PORT in their environment, rendezvous on 127.0.0.1 — wait for them, forward rank 0's stdout (the ranks' stderr
-    goes to ours, prefixed by nothing: they are few) and return 0 only if every rank exited 0.  The caller must not have
-    touched the GPU: children are new processes (fork + exec of the interpreter), never a re-exec of this one.  When a rank
-    fails the others are terminated (their own process handles only), so a dead peer cannot leave the job hanging in a
-    barrier; the first non-zero exit code is returned."""
+    MASTER_PORT in their environment, rendezvous on 127.0.0.1 — wait for them, forward rank 0's stdout (every rank's stderr
+    goes to ours as it comes) and return 0 only if every rank exited 0.  The caller must not have touched the GPU: children
+    are new processes (fork + exec of the interpreter), never a re-exec of this one.  When a rank fails the others are
+    terminated (their own process handles only), so a dead peer cannot leave the job hanging in a barrier; the first
+    non-zero exit code is returned and the failed rank's last TAIL_LINES stderr lines are repeated under a header (with N
+    ranks writing at once, the reason is otherwise buried in the peers' shutdown noise).
+    Environment of the ranks, beyond the rendezvous: HSA_ENABLE_IPC_MODE_LEGACY=0 unless the caller set it (this pool's host
+    driver only supports dmabuf IPC: without it RCCL's buffer exchange between processes fails with `hipIpcGetMemHandle:
+    invalid argument`); NCCL_DEBUG=WARN unless set (RCCL then names the failing call instead of "unhandled system error").
+    A rendezvous port that was taken between free_port() and rank 0's bind (EADDRINUSE) restarts the launch on a new port."""
     if world < 1:
         raise ValueError("world must be >= 1")
     stdout = sys.stdout if stdout is None else stdout
     stderr = sys.stderr if stderr is None else stderr
+    rc = 0
+    for attempt in range(PORT_RETRIES):
+        rc, tails = _launch_once(argv, world, extra_env, timeout, stdout, stderr)
+        if rc == 0:
+            return 0
+        text = "".join("".join(t) for t in tails.values())
+        if attempt + 1 < PORT_RETRIES and ("EADDRINUSE" in text or "Address already in use" in text or "address already in use" in text):
+            stderr.write("launch_ranks: the rendezvous port was taken by someone else; starting the ranks again on another port\n")
+            continue
+        return rc
+    return rc
+
+
+def _launch_once(argv, world, extra_env, timeout, stdout, stderr):
+    import collections
+
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("NCCL_DEBUG", "WARN")
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+    tails = {r: collections.deque(maxlen=TAIL_LINES) for r in range(world)}
 
-    def pump(src, dst):
+    def pump(src, dst, keep=None):
         for ln in src:
+            if keep is not None:
+                keep.append(ln)
             dst.write(ln)
             dst.flush()
 
     threads = [threading.Thread(target=pump, args=(procs[0].stdout, stdout), daemon=True)]
-    threads += [threading.Thread(target=pump, args=(p.stderr, stderr), daemon=True) for p in procs]
+    threads += [threading.Thread(target=pump, args=(p.stderr, stderr, tails[r]), daemon=True) for r, p in enumerate(procs)]
     for t in threads:
         t.start()
     t0 = time.monotonic()
-    rc = 0
     live = set(range(world))
+    failed: List[int] = []
 
     def stop_all():
         for p in procs:
@@ -102,7 +146,7 @@ def launch_ranks(argv: Sequence[str], world: int, extra_env: Optional[dict] = No
     if threading.current_thread() is threading.main_thread():
         old_term = signal.signal(signal.SIGTERM, on_term)
     try:
-        rc = _wait_ranks(procs, live, world, timeout, t0, stderr)
+        rc = _wait_ranks(procs, live, world, timeout, t0, stderr, failed)
     except BaseException:
         stop_all()
         raise
@@ -111,10 +155,15 @@ def launch_ranks(argv: Sequence[str], world: int, extra_env: Optional[dict] = No
             signal.signal(signal.SIGTERM, old_term)
     for t in threads:
         t.join(timeout=5)
-    return rc
+    for r in failed:
+        stderr.write("launch_ranks: ---- last %d stderr lines of rank %d (exit code %s) ----\n" % (len(tails[r]), r, procs[r].returncode))
+        for ln in tails[r]:
+            stderr.write("  [rank %d] %s" % (r, ln if ln.endswith("\n") else ln + "\n"))
+        stderr.flush()
+    return rc, tails
 
 
-def _wait_ranks(procs, live, world, timeout, t0, stderr) -> int:
+def _wait_ranks(procs, live, world, timeout, t0, stderr, failed=None) -> int:
     rc = 0
     while live:
         for r in sorted(live):
@@ -124,6 +173,8 @@ def _wait_ranks(procs, live, world, timeout, t0, stderr) -> int:
             live.discard(r)
             if c != 0 and rc == 0:
                 rc = c
+                if failed is not None:
+                    failed.append(r)
                 stderr.write("launch_ranks: rank %d exited with %d; stopping the other ranks\n" % (r, c))
         timed_out = timeout is not None and time.monotonic() - t0 > timeout
         if (rc != 0 or timed_out) and live:
@@ -222,8 +273,7 @@ def max_over_ranks(value: float) -> float:
 
     if not (dist.is_available() and dist.is_initialized()):
         return value
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"  # gloo reduces host tensors
-    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    t = torch.tensor([value], dtype=torch.float64, device=_collective_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -233,3 +283,66 @@ def barrier():
 
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+def _collective_device():
+    import torch.distributed as dist
+
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"  # gloo reduces host tensors
+
+
+def spread_over_ranks(value: float) -> dict:
+    """{"max", "min", "rank_of_max", "per_rank"} of one number per rank (an all-gather of 8 bytes), so a slow rank is visible in
+    the line and not only the maximum it causes.  Not launched distributed: the number itself."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"max": float(value), "min": float(value), "rank_of_max": 0, "per_rank": [float(value)]}
+    t = torch.tensor([value], dtype=torch.float64, device=_collective_device())
+    got = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, t)
+    per = [float(g.item()) for g in got]
+    return {"max": max(per), "min": min(per), "rank_of_max": int(np.argmax(per)), "per_rank": per}
+
+
+def gather_values(values) -> np.ndarray:
+    """Every rank's 1-D array of per-unit results (ragged: shard sizes differ), concatenated in rank order on every rank — for the
+    statistics a line reports over the WHOLE job (medians, counts).  A few kilobytes, outside every timed region."""
+    import torch.distributed as dist
+
+    values = np.asarray(values)
+    if not (dist.is_available() and dist.is_initialized()):
+        return values
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, values)
+    return np.concatenate([np.asarray(g).reshape(-1) for g in got]) if got else values
+
+
+def timed_region(work, sync) -> dict:
+    """The contract's bracket with NO collective inside the clock: sync + barrier, start the clock, `work()`, `sync()`, stop THIS
+    rank's clock, then the closing barrier and the spread over ranks (its "max" is the job's time).  A barrier inside the clock
+    would put one RCCL round trip (tens of microseconds at eight ranks) into a region that is one millisecond long at --steps 20,
+    on a path whose data plane has no communication at all; the maximum over ranks already is "everyone has finished"."""
+    sync()
+    barrier()
+    t0 = time.perf_counter()
+    work()
+    sync()
+    dt = time.perf_counter() - t0
+    barrier()
+    return spread_over_ranks(dt)
+
+
+def count_ranks() -> dict:
+    """Evidence that the COLLECTIVE library saw every rank: an all-reduce (sum) of a one per rank, on the device under backend
+    "nccl" (= RCCL: the sum travels over xGMI), on the host under gloo.  torch.distributed's own world size is configuration, not
+    evidence.  {"collective_backend", "ranks_counted_by_allreduce"}."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"collective_backend": None, "ranks_counted_by_allreduce": 1}
+    t = torch.ones(1, dtype=torch.float32, device=_collective_device())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return {"collective_backend": str(dist.get_backend()), "ranks_counted_by_allreduce": int(round(float(t.item())))}

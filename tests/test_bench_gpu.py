@@ -28,6 +28,7 @@ def test_bench_prints_one_contract_line():
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert d["ik"]["value"] > 0 and d["mocap"]["finite"] and d["vposer_ik"]["value"] > 0
+    assert 0 < rf["step_hbm_frac"] <= rf["hbm"]["frac"] and "frames_below_1e-3" in d["vposer_ik"]
     # burst-proof figure (a long run after the contract's region) and the operand-exact (bf16x3) figure in the same line
     cold = d["cold_start"]
     assert cold["ms_per_step"] > 0 and cold["value"] > 1e4
@@ -51,6 +52,12 @@ def test_bench_gpus_2_starts_its_own_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["ranks_reported_by_rccl"] == 2 and d["final_gather_ms"] > 0
+    assert d["n_gpus"] == 2 and d["final_gather_ms"] > 0
+    # the rank count comes from an all-reduce and carries the backend that ran it: a gloo rehearsal must not read as RCCL
+    assert d["collective_backend"] == "gloo" and d["ranks_counted_by_allreduce"] == 2 and "ranks_reported_by_rccl" not in d
+    r_ms = d["ms_per_step_ranks"]
+    assert 0 < r_ms["min"] <= r_ms["max"] and abs(r_ms["max"] - d["ms_per_step"]) < 1e-9 and r_ms["slowest_rank"] in (0, 1)
+    assert len(d["mocap"]["per_frame_us_per_rank"]) == 2 and d["mocap"]["chains_per_rank"] == [32, 32]
+    assert "frames_below_1e-3" in d["vposer_ik"] and d["vposer_ik"]["final_median_e_sqnorm"] <= d["vposer_ik"]["final_max_e_sqnorm"]
     assert d["mocap"]["restarts_this_rank"] == 32 and d["vposer_ik"]["frames_this_rank"] == 256
     assert d["value"] > 1e4

@@ -157,6 +157,114 @@ def test_launch_ranks_a_failing_rank_stops_the_job(tmp_path):
     assert "n_gpus" not in out.getvalue()
 
 
+MEASURED = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch
+from smplpp_amd import dist as D
+d = D.init_process_group("gloo")
+rank, world, local = D.env_rank_world()
+assert os.environ.get("NCCL_DEBUG") == "WARN" and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+# rank 1 is the slow one: the job's time is ITS time, and rank 0's own clock must not contain the wait for it
+sp = D.timed_region(lambda: time.sleep(0.4 if rank == 1 else 0.05), lambda: None)
+assert sp["rank_of_max"] == 1 and 0.39 < sp["max"] < 0.8 and 0.04 < sp["min"] < 0.2, sp
+assert len(sp["per_rank"]) == 2 and sp["per_rank"][0] == sp["min"]
+c = D.count_ranks()
+assert c == {{"collective_backend": "gloo", "ranks_counted_by_allreduce": 2}}, c
+vals = D.gather_values(np.arange(3 if rank == 0 else 2, dtype=np.float64) + 10 * rank)
+assert vals.tolist() == [0.0, 1.0, 2.0, 10.0, 11.0], vals
+if rank == 0:
+    print("MEASURED-OK")
+D.barrier()
+d.destroy_process_group()
+"""
+
+
+def test_timed_region_keeps_collectives_out_of_the_clock_and_counts_ranks_by_allreduce(tmp_path):
+    """the closing barrier is outside every rank's clock (the fast rank's own time stays its own), the
+    spread over ranks names the slow rank, and the rank count in the line comes from a collective, labelled with the backend that ran
+    it ("gloo" here — never "rccl")."""
+    import io
+
+    script = tmp_path / "measured.py"
+    script.write_text(MEASURED.format(root=ROOT))
+    out, err = io.StringIO(), io.StringIO()
+    rc = D.launch_ranks([sys.executable, str(script)], 2, timeout=120, stdout=out, stderr=err)
+    assert rc == 0, err.getvalue()
+    assert "MEASURED-OK" in out.getvalue()
+    # not launched distributed: the helpers are the identity
+    sp = D.timed_region(lambda: None, lambda: None)
+    assert sp["rank_of_max"] == 0 and sp["max"] == sp["min"] and len(sp["per_rank"]) == 1
+    assert D.count_ranks() == {"collective_backend": None, "ranks_counted_by_allreduce": 1}
+
+
+NOISY_FAILURE = r"""
+import os, sys, time
+rank = int(os.environ["RANK"])
+if rank == 1:
+    for i in range(60):
+        print("rank one diagnostic line %d" % i, file=sys.stderr)
+    sys.exit(5)
+for i in range(200):
+    print("peer noise %d" % i, file=sys.stderr)
+    time.sleep(0.01)
+time.sleep(60)
+"""
+
+
+def test_launch_ranks_repeats_the_failed_ranks_last_lines(tmp_path):
+    """(d) with N ranks writing at once the reason a rank died is buried in the peers' output: its last 40 stderr lines come again,
+    under a header, once the job has stopped."""
+    import io
+
+    script = tmp_path / "noisy.py"
+    script.write_text(NOISY_FAILURE)
+    out, err = io.StringIO(), io.StringIO()
+    rc = D.launch_ranks([sys.executable, str(script)], 2, timeout=120, stdout=out, stderr=err)
+    text = err.getvalue()
+    assert rc == 5
+    head = "last 40 stderr lines of rank 1 (exit code 5)"
+    assert head in text
+    tail = text[text.index(head):]
+    assert tail.count("[rank 1] rank one diagnostic line") == 40 and "[rank 1] rank one diagnostic line 59" in tail
+    assert "line 19\n" not in tail and "peer noise" not in tail
+
+
+PORT_RACE = r"""
+import os, sys
+marker = os.path.join({tmp!r}, "first_attempt_done")
+if not os.path.exists(marker):
+    if os.environ["RANK"] == "0":
+        open(marker, "w").write(os.environ["MASTER_PORT"])
+        print("RuntimeError: The server socket has failed to listen on any local network address. port: %s, EADDRINUSE: address already in use" % os.environ["MASTER_PORT"], file=sys.stderr)
+        sys.exit(1)
+    import time
+    time.sleep(30)
+print("second attempt on port", os.environ["MASTER_PORT"]) if os.environ["RANK"] == "0" else None
+"""
+
+
+def test_launch_ranks_retries_when_the_port_was_taken(tmp_path):
+    """free_port() closes its socket before rank 0 binds the port: a launch that loses that race is started again."""
+    import io
+
+    script = tmp_path / "race.py"
+    script.write_text(PORT_RACE.format(tmp=str(tmp_path)))
+    out, err = io.StringIO(), io.StringIO()
+    rc = D.launch_ranks([sys.executable, str(script)], 2, timeout=120, stdout=out, stderr=err)
+    assert rc == 0, err.getvalue()
+    assert "starting the ranks again on another port" in err.getvalue() and "second attempt on port" in out.getvalue()
+
+
+def test_launch_plan_warns_under_a_profiler_preload(capsys):
+    assert D.profiler_preloaded({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"}) and D.profiler_preloaded({"ROCP_TOOL_LIBRARIES": "x"})
+    assert not D.profiler_preloaded({"LD_PRELOAD": "/usr/lib/libjemalloc.so", "PATH": "/bin"})
+    assert D.launch_plan(2, {"ROCP_TOOL_LIBRARIES": "x"}) == "spawn"
+    assert "each of the 2 ranks" in capsys.readouterr().err
+    assert D.launch_plan(1, {"ROCP_TOOL_LIBRARIES": "x"}) == "single" and capsys.readouterr().err == ""
+
+
 def test_bench_starts_its_own_ranks_and_refuses_a_contradicting_world_size():
     """No GPU here: each rank bench.py starts fails loudly ("needs an MI355X"), and the parent — which must not have touched the
     GPU or torch.distributed itself — reports it and exits non-zero; WORLD_SIZE=1 with --gpus 2 is refused outright."""

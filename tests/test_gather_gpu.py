@@ -21,6 +21,59 @@ def _rccl():
     return C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
 
 
+def _unique_id_comm(rccl):
+    """A communicator the way a multi-process C++ host makes one: ncclGetUniqueId on rank 0, ncclCommInitRank on every rank (here:
+    world 1), the id passed BY VALUE (ncclUniqueId is a 128-byte struct)."""
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    return comm
+
+
+def test_send_recv_binding_executes_on_a_one_rank_communicator():
+    """the grouped ncclSend / ncclRecv leg of smplpp_gather_to_root has no peer to talk to on a one-GPU box;
+    smplpp_gather_selfcheck drives the same bound function pointers, datatype constant and group calls as a self-exchange, on a
+    communicator from ncclCommInitRank (the multi-process way), and the floats must arrive."""
+    from smplpp_amd import _lib
+
+    L = _lib.load()
+    rccl = _rccl()
+    torch.cuda.set_device(0)
+    comm = _unique_id_comm(rccl)
+    try:
+        n = 6890 * 3 * 2 + 5
+        send = torch.arange(n, dtype=torch.float32, device="cuda:0") * 0.25 - 7.0
+        recv = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda:0")
+        rc = L.smplpp_gather_selfcheck(comm, 0, send.data_ptr(), recv.data_ptr(), n, None)
+        assert rc == 0, L.smplpp_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+        # on a side stream as a host would issue it, and the argument checks
+        st = torch.cuda.Stream()
+        recv.fill_(-1.0)
+        torch.cuda.synchronize()
+        assert L.smplpp_gather_selfcheck(comm, 0, send.data_ptr(), recv.data_ptr(), 1000, C.c_void_p(st.cuda_stream)) == 0, L.smplpp_last_error()
+        st.synchronize()
+        assert torch.equal(send[:1000], recv[:1000]) and bool((recv[1000:] == -1.0).all())
+        assert L.smplpp_gather_selfcheck(comm, 0, send.data_ptr(), send.data_ptr(), 10, None) != 0
+        assert L.smplpp_gather_selfcheck(None, 0, send.data_ptr(), recv.data_ptr(), 10, None) != 0
+        # and the gather itself on this communicator (one rank: root's block by a device copy)
+        per = (C.c_int64 * 1)(3)
+        out = torch.zeros(3 * 75, dtype=torch.float32, device="cuda:0")
+        assert L.smplpp_gather_to_root(comm, send.data_ptr(), out.data_ptr(), per, 1, 0, 0, 75, None) == 0, L.smplpp_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(out, send[:225])
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
 def test_gather_one_rank_roundtrip():
     from smplpp_amd import _lib
 

@@ -594,16 +594,20 @@ def test_ik_vertex_valence_limit():
             with pytest.raises(SmplppError, match="adjacent faces"):
                 sol.eval()
             assert (sol.getStatus() & 4).all()
+            before = sol.getConfig()[1].copy()
             with pytest.raises(SmplppError, match="adjacent faces"):
                 sol.iterate(1)
+            # ... and not consumed: the solve skips the update of a frame whose Jacobian rows are truncated
+            assert np.array_equal(sol.getConfig()[1], before)
             sol.setTasks(normal_task_weight=np.zeros(K), normal_offset=np.full(K, 0.01))  # a normal OFFSET differentiates through it too
-            sol.setConfig(beta, theta)  # (a new configuration starts with clean flags)
+            assert not (sol.getStatus() & 4).any()  # the bit belongs to the tasks: setting them clears it, the next evaluation raises it again
             with pytest.raises(SmplppError, match="adjacent faces"):
                 sol.eval()
-            sol.setTasks(normal_offset=np.zeros(K))
-            sol.setConfig(beta, theta)
+            sol.setTasks(normal_offset=np.zeros(K))  # recovery needs no new configuration
             sol.eval()
-            assert not sol.getStatus().any()
+            assert not (sol.getStatus() & 4).any()
+            sol.setConfig(beta, theta)
+            assert np.isfinite(sol.iterate(2)).all() and not sol.getStatus().any()
             continue
         sol.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, phi_limit=np.zeros(K), normal_offset=np.full(K, 0.01),
                      normal_task_weight=np.ones(K))

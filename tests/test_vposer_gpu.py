@@ -219,9 +219,11 @@ def test_decoder_bits_do_not_depend_on_the_shard(decoders):
         o, j = gpu.forward(z[lo:hi], want_jac=True, frame_base=lo)
         assert np.array_equal(o, out[lo:hi]), (lo, hi)
         assert np.array_equal(j, jac[lo:hi]), (lo, hi)
-    # (the guard that makes the test meaningful: WITHOUT the base the rotation differs and so do the last bits somewhere)
-    o0, j0 = gpu.forward(z[128:256], want_jac=True, frame_base=0)
+    # the guard that makes the test meaningful: with a WRONG base the k loop starts elsewhere (5 * group mod 32: a base of 2 moves
+    # every group by one; 0 would not do — 128 / 2 groups is a multiple of 32) and the last bits differ somewhere, nothing more
+    o0, j0 = gpu.forward(z[128:256], want_jac=True, frame_base=2)
     assert np.abs(j0 - jac[128:256]).max() < 1e-4
+    assert not np.array_equal(j0, jac[128:256])
 
 
 def test_latent_ik_trajectory_does_not_depend_on_the_shard(decoders, synth_model):
