@@ -365,8 +365,10 @@ def main():
         th0_all[:, 1:] = rng.normal(0, 0.03, (args.mocap_restarts, 24, 3))  # the restarts differ in their initial pose
         gv0_all = np.zeros((args.mocap_restarts, 44), np.float32)
         gv0_all[:, 6:38] = rng.normal(0, 0.05, (args.mocap_restarts, 32))
-        hidv_all = np.zeros((args.vposer_frames, 25, 3), np.float32)
-        hidv_all[:, 1:22] = rng.normal(0, 0.15, (args.vposer_frames, 21, 3))
+        # configs[4]'s hidden poses are drawn in LATENT space and decoded (below), so the targets lie inside the decoder's range and the
+        # 50 timed iterations run on converging solves (round 4 drew joint angles directly: with random decoder weights such targets
+        # are unreachable and every solve settled at a residual of 3e-3..6e-2)
+        hidz_all = rng.normal(0, 0.5, (args.vposer_frames, 32)).astype(np.float32)
         if R > 0:
             th0 = np.ascontiguousarray(th0_all[rlo:rhi])
             ms = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=R, chain_base=rlo)
@@ -393,6 +395,10 @@ def main():
         mocap_leg["per_frame_us"] = mt / max(1, iters) * 1e6
         mocap_leg["per_frame_us_per_rank"] = [t / max(1, iters) * 1e6 for t in msp["per_rank"]]
         mocap_leg["chains_per_rank"] = D.shard_sizes(args.mocap_restarts, world)
+        mocap_leg["scaling_note"] = ("a chain is serial along the sequence (node.cpp:1369-1407: one warm-started iteration per frame), so N GPUs "
+                                     "shorten this leg only by the shorter per-frame period of 64 / N chains in lock step — its floor is %d "
+                                     "iterations x per_frame_us_at_8_chains, about 1.5x for 8x the hardware; the leg scales in RESTARTS "
+                                     "(more chains per GPU at the same period), not in time" % iters)
         # one GPU's share of the 8-GPU split (64 restarts -> 8 chains per GPU): the serial per-frame period the 8-GPU number is made of
         # (chains of a frame sequence cannot be parallelised along the sequence: node.cpp:1369-1407), measured here on ONE GPU
         if world == 1 and args.mocap_restarts >= 8:
@@ -431,7 +437,8 @@ def main():
         _, vfaces = reference_task_faces(Kv)
         vt, ev = 0.0, np.zeros(1)
         if nv > 0:
-            hidv = np.ascontiguousarray(hidv_all[vlo:vhi])
+            hidv = np.zeros((nv, 25, 3), np.float32)
+            hidv[:, 2:23] = vp.forward(np.ascontiguousarray(hidz_all[vlo:vhi]), frame_base=vlo)  # theta25 = [pos | root | vposer(z) | aa22 | aa23]
             hvv = smpl.launch(np.zeros((nv, 10), np.float32), hidv, want=("verts",))["verts"]
             tpv = hvv[:, model["face_indices"][vfaces] - 1].mean(axis=2)
             vs = IkSolver(smpl, nv, Kv, vposer=vp, frame_base=vlo)
@@ -455,7 +462,7 @@ def main():
             "ms_per_iter_batch": vt / args.ik_iters * 1e3, "final_max_e_sqnorm": float(np.max(ev_all)),
             "final_median_e_sqnorm": float(np.median(ev_all)), "frames_below_1e-3": int((ev_all < 1e-3).sum()),
             "workload": "configs[4]: VPoser-latent IK (32-d latent + decoder in the loop, 44-d layout, D = 56), %d frames sharded x%d, "
-                        "synthetic decoder weights" % (args.vposer_frames, world),
+                        "synthetic decoder weights, targets = task points of hidden latents (reachable)" % (args.vposer_frames, world),
         }
 
     # ---- the headline FK region (see `cold_start` above): W warm-up launches, then exactly K timed ones

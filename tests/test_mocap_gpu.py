@@ -20,6 +20,16 @@ def smpl(synth_model):
     return s
 
 
+@pytest.fixture(scope="module")
+def decoders():
+    """(the engine's decoder, the torch restatement of src/VPoser.cpp) on the same synthetic weights"""
+    from oracle import vposer_torch as VT
+    from smplpp_amd.ik import VPoserDecoder
+
+    params = VPoserDecoder.synthetic_params()
+    return VPoserDecoder(params), VT.VPoserDecoder(params)
+
+
 def _synthetic_sequence(smpl, synth_model, T, K=41, seed=0):
     """Markers generated from the synthetic model itself: a smooth hidden motion, surface points 15 mm off the skin."""
     from smplpp_amd import mocap
@@ -409,3 +419,157 @@ def test_real_capture_frames_step_by_step_vs_oracle(smpl, oracle_synth):
             worst = max(worst, d)
             assert d < 1e-4, (t, r, int(nv[t]), d)
     assert worst > 0.0
+
+
+# ---- the configuration the reference actually runs on a capture (VERDICT r04 missing #4): node/node.cpp:316-322 forces VPoser + QP
+# on in every mocap mode, so its unknown vector is the 44-d latent layout (:761-772) with the prior of :895-904.
+# Bars of the latent-layout step tests, per entry kind (tests/latent_oracle.py:compare_states):
+#   the 12 pass-through entries (root translation in metres; root, joint 22, joint 23 rotations in radians)   1e-4  (north star)
+#   the 63 body angles the decoder emits for the new latent (radians, through the SAME torch decoder for both) 1e-4  (north star)
+#   the 32 latent coordinates themselves (dimensionless, prior weight 1e-5: weakly held, |d theta / d z| < 1)  LATENT_BAR
+# Measured on MI355X (round 5): capture steps 1.2e-7 / 6.5e-9 rad / 1.5e-8; body stage 9e-8 / 9.5e-8 rad / 3e-6 (beta 2.2e-5).
+LATENT_BAR = 1e-4
+
+
+def test_real_capture_frames_step_by_step_vs_oracle_latent_layout(smpl, oracle_synth, decoders):
+    """test_real_capture_frames_step_by_step_vs_oracle in the layout the reference's capture solve has (D = 44 + 2 * 41 = 126):
+    VPoser splice + prior + box QP + 15 mm normal offsets + missing markers, the window 400..640 of sample_walk.c3d walked by the
+    host-driven loop; at the checked frames (complete, with missing markers, behind the 0-valid gap, the skipped frame itself) the
+    engine's step from its own synchronised state (44-vector + every task's face and weights read back) against the CPU step of
+    tests/latent_oracle.py: oracle FK + analytic Jacobian pulled back through the torch decoder's autograd Jacobian, fp64 normal
+    equations with the prior, box QP (phi pinned: the optimum is the LLT solution)."""
+    from oracle import cpu
+    from smplpp_amd import mocap
+
+    import latent_oracle as LO
+
+    gpu, ref = decoders
+    names, faces, pts, valid = _capture_full()
+    K = valid.shape[1]
+    w0, w1 = 400, 640
+    nv = valid.sum(axis=1)
+    missing = [t for t in range(w0 + 1, w1) if K // 2 <= nv[t] < K]
+    check = sorted(set([401, 402, 450, 466, 467, 468, 589, 609] + missing[:4] + missing[-2:]))
+    R = 2
+    g0 = np.zeros((R, 44), np.float32)
+    g0[1, 6:38] = np.random.default_rng(4).normal(0, 0.05, 32)
+    g0[1, 3:6] = np.random.default_rng(5).normal(0, 0.03, 3)
+    ms = mocap.MocapMotionSolver(smpl, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R, vposer=gpu)
+    sol = ms.solver
+    assert sol.theta_dim == 44
+    beta = np.zeros((R, 10), np.float32)
+    sol.setConfig(beta, g0)
+    worst, step = np.zeros(3), np.zeros(3)
+    for t in range(w0, w1):
+        v = valid[t]
+        tp = np.where(v[:, None], pts[t], 0.0).astype(np.float32)
+        sol.setTasks(target_pos=np.broadcast_to(tp, (R, K, 3)).copy(), pos_task_weight=np.broadcast_to(v.astype(np.float64), (R, K)).copy())
+        if t in check:
+            _, g_before = sol.getConfig()
+            t_before = sol.getTasks()
+        e2 = sol.iterate(ms.WARMUP_ITERS if t == w0 else 1, enable_qp=True, min_valid=K // 2)
+        if t not in check:
+            continue
+        _, g_after = sol.getConfig()
+        for r in range(R):
+            if nv[t] < K // 2:  # node.cpp:785: the whole solve block is skipped
+                assert np.array_equal(g_after[r], g_before[r]), t
+                continue
+            ts = cpu.TaskSet(t_before["face_idx"][r], tp, phi_limit=np.zeros(K), normal_offset=np.full(K, 0.015),
+                             vertex_weights=t_before["vertex_weights"][r])
+            ts.pos_task_weight[:] = v.astype(np.float64)
+            ts.normal_task_weight[:] = 0.0
+            o = LO.latent_step(oracle_synth, ref, beta[r], g_before[r], ts, enable_qp=True, project=False)
+            d = LO.compare_states(ref, g_after[r], o["g44"])
+            worst = np.maximum(worst, d)
+            step = np.maximum(step, LO.compare_states(ref, g_after[r], g_before[r]))
+            assert d[0] < 1e-4 and d[1] < 1e-4 and d[2] < LATENT_BAR, (t, r, int(nv[t]), d)
+            assert abs(o["e_sqnorm"] - e2[r]) < 2e-5 * max(1.0, o["e_sqnorm"]), (t, r)
+    print("latent capture steps: worst |d| pass-through %.3g, decoded angles %.3g rad, latent %.3g; largest step %.3g / %.3g rad / %.3g"
+          % (tuple(worst) + tuple(step)))
+    # (the steps compared are real motion, not a fixed point: a frame of walking moves the body by centimetres and centiradians)
+    assert step[0] > 1e-3 and step[1] > 1e-3 and worst[1] > 0.0
+
+
+def test_body_stage_latent_layout_vs_oracle(smpl, oracle_synth, synth_model, decoders):
+    """solveMocapBody as the reference runs it (node.cpp:316-322: VPoser on; :652-656, 693-696: from iteration 25 on phi and beta
+    are live) — D = 44 + 82 + 10 = 136 unknowns, box QP on phi (4 cm) and d beta (0.5): the driver's own solver stepped one
+    iteration at a time against the CPU step of tests/latent_oracle.py from synchronised states at iterations 0, 24, 25 (the
+    switch), 26, 40 and 50.  Markers come from a hidden body INSIDE the decoder's range (a hidden latent), 15 mm off the skin,
+    off-centre on their faces."""
+    from oracle import cpu
+    from smplpp_amd import mocap
+    from smplpp_amd.ik import IkSolver
+
+    import latent_oracle as LO
+
+    gpu, ref = decoders
+    names = sorted(mocap.BASELINE41)
+    K = len(names)
+    rng = np.random.default_rng(37)
+    beta_h = rng.normal(0, 0.8, 10).astype(np.float32)
+    g_h = np.zeros(44, np.float32)
+    g_h[:3] = [0.1, -0.2, 0.9]
+    g_h[3:6] = rng.normal(0, 0.15, 3)
+    g_h[6:38] = rng.normal(0, 0.6, 32)
+    g_h[38:] = rng.normal(0, 0.1, 6)
+    faces = np.array([mocap.BASELINE41[n] for n in names], np.int64)
+    bary = rng.dirichlet(np.ones(3) * 4, K).astype(np.float32)
+    hid = IkSolver(smpl, 1, K, vposer=gpu)
+    hid.setTasks(face_idx=faces, vertex_weights=bary, target_pos=np.zeros((K, 3), np.float32), normal_offset=np.full(K, 0.015),
+                 normal_task_weight=np.zeros(K), phi_limit=np.zeros(K))
+    hid.setConfig(beta_h[None], g_h[None])
+    hid.eval()
+    markers = hid.getTasks()["actual_pos"][0].copy()
+    R = 2
+    g0 = np.tile(g_h, (R, 1))
+    g0[:, 6:38] += rng.normal(0, 0.1, (R, 32)).astype(np.float32)
+    g0[:, 3:6] += rng.normal(0, 0.03, (R, 3)).astype(np.float32)
+    bs = mocap.MocapBodySolver(smpl, names, restarts=R, vposer=gpu)
+    assert bs.solver.theta_dim == 44
+    bs.solver.setTasks(target_pos=np.broadcast_to(markers, (R, K, 3)).copy(), pos_task_weight=np.ones((R, K)))
+    bs.solver.setConfig(np.zeros((R, 10), np.float32), g0)
+    f0 = synth_model["face_indices"].astype(np.int64) - 1
+    worst, step = np.zeros(4), np.zeros(4)
+    e_hist, prev_beta = [], np.zeros((R, 10), np.float32)
+    for it in range(mocap.MocapBodySolver.ITERS):
+        live = it >= mocap.MocapBodySolver.BETA_FROM
+        check = it in (0, 24, 25, 26, 40, 50)
+        if check:
+            st = bs.solver.getTasks()
+            gb, gt = bs.solver.getConfig()
+        e2 = bs.solver.iterate(1, enable_qp=True, optimize_beta_from=(0 if live else 1000))
+        nb, nt = bs.solver.getConfig()
+        e_hist.append(e2.copy())
+        if not live:
+            assert np.abs(nb).max() == 0, it  # beta frozen (node.cpp:655)
+        else:
+            assert np.abs(nb - prev_beta).max() <= 0.5 + 1e-6, it  # :925
+        prev_beta = nb.copy()
+        if not check:
+            continue
+        st2 = bs.solver.getTasks()
+        verts = bs.solver.getVertices()
+        for r in range(R):
+            ts = cpu.TaskSet(st["face_idx"][r], markers, phi_limit=np.full(K, 0.04), normal_offset=np.full(K, 0.015),
+                             normal_task_weight=np.zeros(K), vertex_weights=st["vertex_weights"][r])
+            o = LO.latent_step(oracle_synth, ref, gb[r], gt[r], ts, enable_qp=True, optimize_beta=live,
+                               phi_live=np.full(K, 0.04 if live else 0.0))
+            d = LO.compare_states(ref, nt[r], o["g44"])
+            db = float(np.abs(nb[r] - o["beta"]).max())
+            worst = np.maximum(worst, d + (db,))
+            step = np.maximum(step, LO.compare_states(ref, nt[r], gt[r]) + (float(np.abs(nb[r] - gb[r]).max()),))
+            assert d[0] < 1e-4 and d[1] < 1e-4 and d[2] < LATENT_BAR and db < 1e-4, (it, r, d, db)
+            assert abs(o["e_sqnorm"] - e2[r]) < 2e-5 * max(1.0, o["e_sqnorm"]), (it, r)
+            # the same surface point after the re-projection, whichever incident face is named (ties): the engine's new face and
+            # weights on ITS pre-update mesh against the oracle's closest point on its own
+            p_gpu = np.einsum("ki,kix->kx", st2["vertex_weights"][r], verts[r][f0[st2["face_idx"][r]]])
+            assert np.abs(p_gpu - o["closest"]).max() < 5e-5, (it, r)
+    print("latent body stage: worst |d| pass-through %.3g, decoded angles %.3g rad, latent %.3g, beta %.3g; largest step %.3g / %.3g rad / %.3g / %.3g"
+          % (tuple(worst) + tuple(step)))
+    assert step[1] > 1e-3 and step[3] > 1e-3  # (real steps: centiradians on the body, a live beta)
+    e_hist = np.array(e_hist)
+    assert (e_hist[24] < 0.5 * e_hist[0]).all() and (e_hist[-1] < e_hist[0]).all() and np.isfinite(e_hist).all()
+    # the driver call itself reproduces that trajectory
+    res = bs.solve(markers, g0)
+    assert np.array_equal(res["beta"], prev_beta) and np.isfinite(res["theta"]).all()

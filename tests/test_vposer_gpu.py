@@ -132,7 +132,12 @@ def test_latent_ik_eval_and_step(decoders, synth_model, oracle_synth, golden_ik_
             x0 = x
     sol.iterate(1)
     _, t44 = sol.getConfig()
-    assert np.abs((t44[0] - g44[0]) - x0[:44]).max() < 2e-4
+    # bars per entry kind (tests/latent_oracle.py): metres / radians on the 12 pass-through entries and on the 63 body angles the
+    # decoder emits for the new latent (the north star's 1e-4); the 32 dimensionless latent coordinates (prior weight 1e-5) 1e-4 too
+    import latent_oracle as LO
+
+    d_pass, d_ang, d_lat = LO.compare_states(ref, t44[0], g44[0] + x0[:44].astype(np.float32))
+    assert d_pass < 1e-4 and d_ang < 1e-4 and d_lat < 1e-4, (d_pass, d_ang, d_lat)
     e2 = sol.iterate(15)
     assert np.isfinite(e2).all()
 
@@ -176,8 +181,11 @@ def test_latent_ik_config4_size_512_frames_50_iterations(decoders, synth_model, 
         A, b = cpu.normal_equations(r["e"], Jl, 44, 2 * K, 0, vposer_theta=g44)
         return cpu.llt_solve(A, b)[:44], float(r["e"] @ r["e"])
 
+    import latent_oracle as LO
+
     sample = [0, 91, 300, 511]
     done = 0
+    worst = np.zeros(3)
     for target in (1, 10, 25, 50):
         if target - 1 > done:
             sol.iterate(target - 1 - done)
@@ -194,11 +202,15 @@ def test_latent_ik_config4_size_512_frames_50_iterations(decoders, synth_model, 
             check += [int(f) for f in np.argsort(-e2)[:3]]
         for f in check:
             x, e2o = oracle_step(f, g_before[f], t_before)
-            # latent coordinates are O(1) numbers, the other 12 are metres / radians: one bar for all (1e-4 rad on the angles
-            # the decoder emits is implied: |d theta / d z| < 1 for the synthetic decoder)
-            assert np.abs((g_after[f] - g_before[f]) - x).max() < 2e-4, (target, f)
+            # per entry kind (tests/latent_oracle.py:compare_states): the 12 pass-through entries (metres / radians) and the 63
+            # body angles decoded from the new latent within the north star's 1e-4; the 32 latent coordinates (dimensionless,
+            # held by a 1e-5 prior only) within 1e-4 as well (measured 3.6e-7)
+            d_pass, d_ang, d_lat = LO.compare_states(ref, g_after[f], g_before[f] + x.astype(np.float32))
+            worst = np.maximum(worst, (d_pass, d_ang, d_lat))
+            assert d_pass < 1e-4 and d_ang < 1e-4 and d_lat < 1e-4, (target, f, d_pass, d_ang, d_lat)
             assert abs(e2o - e2[f]) < 2e-5 * max(1.0, e2o), (target, f)
     assert done == iters
+    print("configs[4] steps: worst |d| pass-through %.3g, decoded angles %.3g rad, latent %.3g" % tuple(worst))
     assert np.isfinite(e2).all() and np.isfinite(g_after).all()
     # (with random decoder weights the targets — poses drawn in joint-angle space — lie outside the decoder's range: the solves
     # settle at residuals of 3e-3..6e-2 instead of converging, which is what makes their last steps worth checking above)
