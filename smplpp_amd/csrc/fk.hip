@@ -281,8 +281,13 @@ PoseArgs fk_pose_args(smplpp_model * m, int64_t n, const float * beta, const flo
 // range_slot: which word of the model's range status a launch of the fp16x2 form reports to (common.h RANGE_*): enqueue-only user
 // launches, host-space user launches and the IK / VPoser loops' internal launches each have their own, so that an intermediate IK
 // iterate outside the range does not turn a later, in-range smplpp_fk into an error
-int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
-              float * xforms44, float * rest, float * poserot, hipStream_t st, int range_slot)
+// The two halves of the forward pass, for callers that place them on different streams (the IK loops: the evaluation computes the
+// few vertices it reads itself, so only the re-projection's face scan needs the posed mesh and the fused kernel can run beside the
+// solve).  fk_pose_device: pose step (joints, relative transforms, the fused kernel's operand images when `with_ops`) into the
+// model's workspace; fk_skin_device: the fused kernel of the model's form from that workspace.  `theta` of the skin half is read
+// for the root translation only (theta[f, 0, :], stride 75).
+int fk_pose_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * joints, float * xforms44, float * poserot,
+                   hipStream_t st, int range_slot, bool with_ops)
 {
   Workspace & ws = m->ws;
   // Form of the fused kernel (m->form, from SMPLPP_SKIN at model creation): h (default,
@@ -297,7 +302,7 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
   {
     HIP_TRY(ws.A2h.reserve((size_t)(n64 / 64) * HB_KS * HB_A_BYTES));
     HIP_TRY(ws.G2h.reserve((size_t)(n64 / 64) * HB_G_BYTES));
-    PoseArgs pa = fk_pose_args(m, n, beta, theta, joints, poserot, xforms44, verts || rest);
+    PoseArgs pa = fk_pose_args(m, n, beta, theta, joints, poserot, xforms44, with_ops);
     pa.range_flag = m->range_flag + range_slot;
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(pa);
   }
@@ -329,6 +334,14 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(pa);
   }
   HIP_TRY(hipGetLastError());
+  return SMPLPP_OK;
+}
+
+int fk_skin_device(smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st)
+{
+  Workspace & ws = m->ws;
+  char form = m->form;
+  if(form == 'p' && n * m->V * 12 >= 0x7fffff00LL) form = 'v';
   if(verts || rest)
   {
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -359,6 +372,14 @@ int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * the
     if(m->profiling) HIP_TRY(hipEventRecord(e1, st));
   }
   return SMPLPP_OK;
+}
+
+int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
+              float * xforms44, float * rest, float * poserot, hipStream_t st, int range_slot)
+{
+  int rc = fk_pose_device(m, n, beta, theta, joints, xforms44, poserot, st, range_slot, verts || rest);
+  if(rc) return rc;
+  return fk_skin_device(m, n, theta, verts, rest, st);
 }
 } // namespace smplpp_hip
 

@@ -356,7 +356,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   // ---- what phase A will read of the tasks is requested NOW: its addresses depend on nothing the kernel computes, and the
   // dependent pair face id -> ring list (two round trips) then runs beside the set-up and the chain-derivative steps instead
   // of in front of phase A.  (The re-projection that wrote faces, weights and targets has been waited for by the stream.)
-  const int ntask = k_end - k_begin;
+  const int ntask = (k_end > k_begin) ? k_end - k_begin : 0; // (a part beyond the last task — more parts than tasks — has none)
   const bool a0_live = tid < ntask * (MAXRING + 1); // A0's first pass: one (task, ring-list word) per thread
   const int a0_t = a0_live ? tid / (MAXRING + 1) : 0, a0_q = a0_live ? tid % (MAXRING + 1) : 0;
   // (a workgroup whose share of the tasks is empty — more parts than tasks — or a thread without an item reads task 0 of its

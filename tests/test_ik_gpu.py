@@ -371,9 +371,21 @@ def test_ik_config2_size_256_frames_50_iterations(smpl, oracle_synth, synth_mode
     _, th_after = s.getConfig()
     for f in stuck:
         ts = cpu.TaskSet(t_before["face_idx"][f], tp[f], tn[f], phi_limit=np.zeros(K), vertex_weights=t_before["vertex_weights"][f])
+        ts_eval = ts.copy()  # (ik_solve moves the tasks: the yardstick below evaluates at the state BEFORE the step)
         _, tho, e2o = oracle_synth.ik_solve(np.zeros(10, np.float32), th_before[f].reshape(25, 3), ts, 1)
         assert np.abs(tho - th_after[f].reshape(25, 3)).max() < 1e-4, f
-        assert abs(e2o - e2[f]) < 5e-2 * e2o, f  # (normal terms of a folded configuration: ill-conditioned in fp32)
+        # |e|^2 of a folded configuration is ill-conditioned in fp32 through its normal rows: 5 % where the stuck state is a benign one;
+        # where a sliver face sits among the faces around a task's vertices the yardstick is the ORACLE's own spread of |e|^2 when
+        # theta moves by 3e-7 rad (vertices by ~1e-7 m: what separates two fp32 evaluations of the same FK).  Which frames end stuck,
+        # and in which state, depends on the last bits of the FK: a build whose vertices differed by 1e-7 m (round 5's experiment,
+        # profiles/r05_self_eval_ab.txt) left frame 227 of this run in such a state — engine 4.9e-4 against 2.8e-4 with actual
+        # positions equal to 1.2e-7 m, the oracle moving by more than that between perturbed copies of itself (tools/ik_eval_conditioning.py)
+        spread = 0.0
+        for seed in range(4):
+            pert = th_before[f].reshape(25, 3) + np.random.default_rng(seed).normal(0, 3e-7, (25, 3)).astype(np.float32)
+            ro = oracle_synth.ik_eval(np.zeros(10, np.float32), pert, ts_eval)["e"]
+            spread = max(spread, abs(float(ro @ ro) - e2o))
+        assert abs(e2o - e2[f]) < max(5e-2 * e2o, 2.0 * spread), (f, e2o, e2[f], spread)
 
 
 def test_ik_status_flags_visible_to_enqueue_only_callers(smpl, golden_ik_synth):
