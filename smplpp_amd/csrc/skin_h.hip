@@ -229,7 +229,10 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
     constexpr int ROWC = (R & 3) + 8 * (R >> 2);
     // write-once output; the descriptor's range check drops frames >= n and vertex-less lanes
     if constexpr(SKINH_ABL & 32)
-      asm volatile("" ::"v"(ovh));
+    {
+      const float o0 = ovh.x, o1 = ovh.y, o2 = ovh.z; // (timing ablation: the row is computed, not stored)
+      asm volatile("" ::"v"(o0), "v"(o1), "v"(o2));
+    }
     else
       __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ovh), rsV, prev.voff, prev.sb + ROWC * frameB, SKINH_STORE_AUX);
     // HAZARD (measured on gfx950, see skin_b.hip): keep one instruction between a 96-bit buffer store and the next VALU

@@ -9,6 +9,8 @@ bash tools/mocap_full_profile.sh > $O/mocap_full_sequence.txt 2>&1
 bash tools/mocap_timeline.sh 64 > $O/mocap_timeline.txt 2>&1
 bash tools/mocap_chains_profile.sh 8 > $O/mocap_8chains_timeline.txt 2>&1
 bash tools/mocap_chains_profile.sh 64 > $O/mocap_64chains_timeline.txt 2>&1
+bash tools/mocap_chains_profile.sh 8 latent > $O/mocap_8chains_latent_timeline.txt 2>&1
+bash tools/mocap_chains_profile.sh 64 latent > $O/mocap_64chains_latent_timeline.txt 2>&1
 timeout -k 10 300 python tests/ik_stress_cases.py > $O/ik_sweep.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 SMPLPP_ROCTX=1 rocprofv3 --marker-trace --kernel-trace --output-format csv -d $O/mk -- python3 $ROOT/tools/quick_ik.py > $O/mk.log 2>&1

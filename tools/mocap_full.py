@@ -1,5 +1,6 @@
-"""Development aid: configs[3] alone — every frame of sample_walk.c3d, R restarts, direct theta (for rocprofv3 --kernel-trace --stats).
-usage: python tools/mocap_full.py [R] [frames]"""
+"""Development aid: configs[3] alone — every frame of sample_walk.c3d, R restarts, direct theta or (third argument `latent`) the
+44-d VPoser layout the reference forces on capture solves (for rocprofv3 --kernel-trace --stats).
+usage: python tools/mocap_full.py [R] [frames] [latent]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,10 +16,16 @@ pts = (g["points"][:T] - g["points"][0][g["valid"][0]].mean(axis=0) + np.array([
 valid = g["valid"][:T]
 rng = np.random.default_rng(200)
 th0 = np.zeros((R, 25, 3), np.float32); th0[:, 1:] = rng.normal(0, 0.03, (R, 24, 3))
-ms = mocap.MocapMotionSolver(s, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R)
+latent = len(sys.argv) > 3 and sys.argv[3] == "latent"
+vp = None
+if latent:
+    from smplpp_amd.ik import VPoserDecoder
+    vp = VPoserDecoder(VPoserDecoder.synthetic_params(seed=3))
+    th0 = np.zeros((R, 44), np.float32); th0[:, 6:38] = rng.normal(0, 0.05, (R, 32))
+ms = mocap.MocapMotionSolver(s, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R, vposer=vp)
 ms.solve(pts, valid, np.zeros(10, np.float32), th0, max_frames=2)
 torch.cuda.synchronize(); t = time.perf_counter()
 th, fr = ms.solve(pts, valid, np.zeros(10, np.float32), th0)
 torch.cuda.synchronize(); dt = time.perf_counter() - t
 iters = mocap.MocapMotionSolver.WARMUP_ITERS + T - 1
-print("R=%d: %d frames (%d iterations) in %.1f ms -> %.0f solved frames/s, %.1f us per iteration" % (R, T, iters, dt * 1e3, R * T / dt, dt / iters * 1e6))
+print(("latent layout, " if latent else "") + "R=%d: %d frames (%d iterations) in %.1f ms -> %.0f solved frames/s, %.1f us per iteration" % (R, T, iters, dt * 1e3, R * T / dt, dt / iters * 1e6))
