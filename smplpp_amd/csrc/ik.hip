@@ -1201,23 +1201,36 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       if(r0 > 0) __syncthreads(); // the previous chunk's readers are done with sJ
       for(int i = tid; i < nr * 63; i += EVAL_NT) sJ[i] = Jf[(int64_t)(r0 + i / 63) * D + 6 + i % 63];
       __syncthreads();
-      for(int item = tid; item < nr * Dl; item += EVAL_NT)
+      // the 32 latent columns: one (row, column) per thread, the 63 terms in FOUR interleaved partial sums.  (Round 5: as one loop
+      // over all Dl columns with a single 63-term chain per latent entry, the 32 latent columns of a row sat in one wavefront, which
+      // walked dependent fp64 FMAs while the others copied: 16 us of a 57 us evaluation at 64 chains, 4 us at 8.)
+      for(int item = tid; item < nr * 32; item += EVAL_NT)
       {
-        const int rl = item / Dl, c = item % Dl, r = r0 + rl;
-        double v;
-        if(c < 6)
-          v = Jf[(int64_t)r * D + c];
-        else if(c < 6 + 32)
+        const int rl = item >> 5, c = item & 31, r = r0 + rl;
+        const double * jr = sJ + rl * 63;
+        const float * vj = svj + c;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for(int q = 0; q < 60; q += 4)
         {
-          double sacc = 0.0;
-          for(int q = 0; q < 63; q++) sacc += sJ[rl * 63 + q] * (double)svj[q * 32 + (c - 6)];
-          v = sacc;
+          s0 += jr[q] * (double)vj[q * 32];
+          s1 += jr[q + 1] * (double)vj[(q + 1) * 32];
+          s2 += jr[q + 2] * (double)vj[(q + 2) * 32];
+          s3 += jr[q + 3] * (double)vj[(q + 3) * 32];
         }
-        else if(c < TD44)
-          v = Jf[(int64_t)r * D + 69 + (c - 38)];
-        else
-          v = Jf[(int64_t)r * D + TD75 + (c - TD44)];
-        Lf[(int64_t)r * Dl + c] = v;
+        s0 += jr[60] * (double)vj[60 * 32];
+        s1 += jr[61] * (double)vj[61 * 32];
+        s2 += jr[62] * (double)vj[62 * 32];
+        Lf[(int64_t)r * Dl + 6 + c] = (s0 + s1) + (s2 + s3);
+      }
+      // the columns that pass through: [pos 3 | root 3] | [aa22 3 | aa23 3] | [phi | beta]
+      const int npass = Dl - 32;
+      for(int item = tid; item < nr * npass; item += EVAL_NT)
+      {
+        const int rl = item / npass, cc = item - rl * npass, r = r0 + rl;
+        const int c = cc < 6 ? cc : cc + 32; // column of the latent layout
+        const int src = cc < 6 ? cc : (c < TD44 ? 69 + (c - 38) : TD75 + (c - TD44));
+        Lf[(int64_t)r * Dl + c] = Jf[(int64_t)r * D + src];
       }
     }
   }
