@@ -1100,15 +1100,23 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
           for(int x = 0; x < 3; x++) lds[L_VN + (k - k_lo) * 12 + 9 + x] = msum[x];
       }
       const int jcol = (q < TD75) ? q : TD75 + 2 * K + (q - TD75);
+      // VPoser latent layout: the columns that pass through ([pos 3 | root 3] <- 0..5, [aa22 | aa23] <- 69..74, beta) are written to
+      // the latent rows as they are made (a copy pass behind the rows cost a second global round trip per 768 entries); the 63
+      // body-joint columns are pulled back through the decoder's Jacobian behind the groups
+      const int Dl = TD44 + 2 * K + (nq - TD75);
+      const int lcol = !Jl_out ? -1 : (q < 6 ? q : (q < 69 ? -1 : (q < TD75 ? TD44 - 6 + (q - 69) : TD44 + 2 * K + (q - TD75))));
+      double * Lk = Jl_out ? Jl_out + ((f * K + k) * 4) * (int64_t)Dl : nullptr;
       float nd = 0.f;
       for(int x = 0; x < 3; x++)
       {
         float dpos = (w0 * dp[(0 * 3 + x) * NQ + q] + w1 * dp[(1 * 3 + x) * NQ + q]) + w2 * dp[(2 * 3 + x) * NQ + q];
         if(off > 0.0f) dpos += off * dn[x];
         Jk[(int64_t)x * D + jcol] = (double)(wp * dpos);
+        if(lcol >= 0) Lk[(int64_t)x * Dl + lcol] = (double)(wp * dpos);
         nd += dn[x] * ta.tnrm[(tb + k) * 3 + x];
       }
       Jk[(int64_t)3 * D + jcol] = (wn > 0.0f) ? (double)(wn * nd) : 0.0;
+      if(lcol >= 0) Lk[(int64_t)3 * Dl + lcol] = (wn > 0.0f) ? (double)(wn * nd) : 0.0;
     }
     // phi columns of every task are zero except the task's own two (node.cpp:792, :834-839)
     for(int item = tid; item < (k_hi - k_lo) * 2 * K; item += EVAL_NT)
@@ -1117,7 +1125,15 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       const float plim = ta.philim[tb + k];
       double * Jk = J_out + ((f * K + k) * 4) * (int64_t)D;
       if(c / 2 != k || !(phi_live && plim > 0.0f))
+      {
         for(int r = 0; r < 4; r++) Jk[(int64_t)r * D + TD75 + c] = 0.0;
+        if(Jl_out)
+        {
+          const int Dl = TD44 + 2 * K + (nq - TD75);
+          double * Lk = Jl_out + ((f * K + k) * 4) * (int64_t)Dl;
+          for(int r = 0; r < 4; r++) Lk[(int64_t)r * Dl + TD44 + c] = 0.0;
+        }
+      }
     }
     lds_barrier(); // (global stores of this phase stay in flight: nothing reads them before the next full barrier)
     if(k_lo == k_begin) EVAL_STAMP(12);
@@ -1167,21 +1183,25 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
           dnormalize_jac(lds + L_VN + (k - k_lo) * 12 + 9, dmm, dnn);
         }
         float ndot = 0.f;
+        const int Dl = TD44 + 2 * K + (nq - TD75);
+        double * Lk = Jl_out ? Jl_out + ((f * K + k) * 4) * (int64_t)Dl : nullptr;
         for(int x = 0; x < 3; x++)
         {
           if(off > 0.0f) dpos[x] += off * dnn[x];
           Jk[(int64_t)x * D + TD75 + 2 * k + c] = (double)(wp * dpos[x]);
+          if(Lk) Lk[(int64_t)x * Dl + TD44 + 2 * k + c] = (double)(wp * dpos[x]);
           ndot += dnn[x] * ta.tnrm[(tb + k) * 3 + x];
         }
         Jk[(int64_t)3 * D + TD75 + 2 * k + c] = (wn > 0.0f) ? (double)(wn * ndot) : 0.0;
+        if(Lk) Lk[(int64_t)3 * Dl + TD44 + 2 * k + c] = (wn > 0.0f) ? (double)(wn * ndot) : 0.0;
       }
     }
     lds_barrier();
     if(k_lo == k_begin) EVAL_STAMP(13);
   }
   // ---- VPoser latent layout (node.cpp:761-772): the rows this workgroup wrote, over [pos 3 | root 3 | z 32 | aa22 3 | aa23 3 |
-  // phi | beta]: columns 0..5 and 69..74 of J75 pass through, columns 6..68 (joints 1..21) are pulled back through
-  // d(vposer out)/dz [63, 32] of the frame.  (A separate kernel for this cost the loop 19 us per iteration; here it is 768
+  // phi | beta]: columns 0..5 and 69..74 of J75 pass through (written by B3 / B4 beside the direct rows), columns 6..68 (joints
+  // 1..21) are pulled back HERE through d(vposer out)/dz [63, 32] of the frame.  (A separate kernel for this cost the loop 19 us per iteration; here it is 768
   // threads x 63 FMAs behind the rows they follow.)
   if(Jl_out && k_end > k_begin)
   {
@@ -1223,15 +1243,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         s2 += jr[62] * (double)vj[62 * 32];
         Lf[(int64_t)r * Dl + 6 + c] = (s0 + s1) + (s2 + s3);
       }
-      // the columns that pass through: [pos 3 | root 3] | [aa22 3 | aa23 3] | [phi | beta]
-      const int npass = Dl - 32;
-      for(int item = tid; item < nr * npass; item += EVAL_NT)
-      {
-        const int rl = item / npass, cc = item - rl * npass, r = r0 + rl;
-        const int c = cc < 6 ? cc : cc + 32; // column of the latent layout
-        const int src = cc < 6 ? cc : (c < TD44 ? 69 + (c - 38) : TD75 + (c - TD44));
-        Lf[(int64_t)r * Dl + c] = Jf[(int64_t)r * D + src];
-      }
+      // (the columns that pass through — [pos 3 | root 3], [aa22 | aa23], phi, beta — were written with the rows themselves: B3, B4)
     }
   }
   EVAL_STAMP(7);

@@ -1,4 +1,4 @@
-"""Development aid: the capture-excerpt leg alone (for rocprofv3 --kernel-trace --stats)."""
+"""Development aid: the capture-excerpt leg alone (for rocprofv3 --kernel-trace --stats).  usage: python tools/mocap_only.py [R] [latent]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,7 +12,12 @@ pts = g["points"] - g["points"][0][g["valid"][0]].mean(axis=0) + np.array([0, -0
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rng = np.random.default_rng(200)
 th0 = np.zeros((R, 25, 3), np.float32); th0[:, 1:] = rng.normal(0, 0.03, (R, 24, 3))
-ms = mocap.MocapMotionSolver(s, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R)
+vp = None
+if len(sys.argv) > 2 and sys.argv[2] == "latent":  # the 44-d VPoser layout (synthetic decoder)
+    from smplpp_amd.ik import VPoserDecoder
+    vp = VPoserDecoder(VPoserDecoder.synthetic_params(seed=3))
+    th0 = np.zeros((R, 44), np.float32); th0[:, 6:38] = rng.normal(0, 0.05, (R, 32))
+ms = mocap.MocapMotionSolver(s, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R, vposer=vp)
 ms.solve(pts, g["valid"], np.zeros(10, np.float32), th0, max_frames=2)
 torch.cuda.synchronize(); t = time.perf_counter()
 th, fr = ms.solve(pts, g["valid"], np.zeros(10, np.float32), th0)
