@@ -105,3 +105,50 @@ def test_gather_one_rank_roundtrip():
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+NCCL_ONE_RANK = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch
+import torch.distributed as tdist
+from smplpp_amd import dist as D
+torch.cuda.set_device(0)
+tdist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1)
+c = D.count_ranks()
+assert c == {{"collective_backend": "nccl", "ranks_counted_by_allreduce": 1}}, c
+sp = D.timed_region(lambda: time.sleep(0.01), torch.cuda.synchronize)
+assert sp["rank_of_max"] == 0 and len(sp["per_rank"]) == 1 and 0.009 < sp["max"] < 0.5, sp
+assert D.max_over_ranks(3.5) == 3.5
+rows = torch.arange(12, dtype=torch.float32, device="cuda").reshape(4, 3)
+full = D.gather_rows(rows, 4)
+assert full is not None and torch.equal(full, rows)
+vals = D.gather_values(np.array([1.0, 2.0, 5.0]))
+assert vals.tolist() == [1.0, 2.0, 5.0]
+D.barrier()
+tdist.destroy_process_group()
+print("NCCL-ONE-RANK-OK")
+"""
+
+
+def test_measurement_helpers_under_the_nccl_backend_one_rank(tmp_path):
+    """dist.count_ranks / timed_region / max_over_ranks / gather_rows / gather_values with torch.distributed's nccl backend (= RCCL):
+    the device-tensor branches of the helpers the N > 1 bench line is made of.  RCCL refuses a second rank on the same device
+    (profiles/r05_rccl_same_device_probe.txt), so one rank is what a one-GPU box can run; the two-rank control flow runs under gloo
+    (tests/test_dist_cpu.py)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "nccl_one_rank.py"
+    script.write_text(NCCL_ONE_RANK.format(root=root, port=port))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "NCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
