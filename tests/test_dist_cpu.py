@@ -167,8 +167,9 @@ d = D.init_process_group("gloo")
 rank, world, local = D.env_rank_world()
 assert os.environ.get("NCCL_DEBUG") == "WARN" and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
 # rank 1 is the slow one: the job's time is ITS time, and rank 0's own clock must not contain the wait for it
-sp = D.timed_region(lambda: time.sleep(0.4 if rank == 1 else 0.05), lambda: None)
-assert sp["rank_of_max"] == 1 and 0.39 < sp["max"] < 0.8 and 0.04 < sp["min"] < 0.2, sp
+sp = D.timed_region(lambda: time.sleep(0.6 if rank == 1 else 0.05), lambda: None)
+# (generous upper bounds: a loaded host may deschedule a rank for a while; what matters is min << max)
+assert sp["rank_of_max"] == 1 and 0.59 < sp["max"] < 3.0 and 0.04 < sp["min"] < 0.4, sp
 assert len(sp["per_rank"]) == 2 and sp["per_rank"][0] == sp["min"]
 c = D.count_ranks()
 assert c == {{"collective_backend": "gloo", "ranks_counted_by_allreduce": 2}}, c
