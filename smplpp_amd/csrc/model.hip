@@ -95,9 +95,11 @@ __global__ void relayout_basis_bf16x3_kernel(const float * __restrict__ Bm, int6
 
 // B2h <- Bm and the skinning weights as fp16x2 pieces in MFMA fragment order (layout: common.h).  One thread per 16-byte
 // chunk pair (hi, lo): slots 0..13: ((vg * 15 + ks) * 6 + vh * 3 + x) * 64 + lane; slot 14: weights, cw, padding.
+// hperm [nvg * 64]: the vertex in each slot of each group (-1: none), gflags [nvg]: the group's k-step flags (common.h, HB_PERM_OFF).
 __global__ void relayout_basis_f16x2_kernel(const float * __restrict__ Bm, int64_t ldB, const float * __restrict__ W,
                                             const float * __restrict__ wSum, int64_t V, int64_t nvg, float sB, float sG,
-                                            uint8_t * __restrict__ B2h)
+                                            uint8_t * __restrict__ B2h, const int32_t * __restrict__ hperm,
+                                            const int32_t * __restrict__ gflags)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int per_vg = HB_KS * 6 * 64 + 4 * 64 + 64; // basis chunk pairs + weight chunk pairs + cw entries
@@ -110,11 +112,11 @@ __global__ void relayout_basis_f16x2_kernel(const float * __restrict__ Bm, int64
   {
     const int lane = q % 64, h = lane >> 5, r = lane & 31;
     const int vx = (q / 64) % 6, vh = vx / 3, x = vx % 3, ks = q / (64 * 6);
-    const int64_t v = vg * 64 + vh * 32 + r;
+    const int64_t v = hperm[vg * 64 + vh * 32 + r];
     for(int j = 0; j < 8; j++)
     {
       const int k = ks * 16 + 8 * h + j;
-      const float val = (v < V && k < KP) ? Bm[(int64_t)k * ldB + bcol(v, x)] : 0.0f;
+      const float val = (v >= 0 && k < KP) ? Bm[(int64_t)k * ldB + bcol(v, x)] : 0.0f;
       _Float16 a, b;
       split_f16x2(val * sB, a, b);
       hi[j] = a;
@@ -127,11 +129,11 @@ __global__ void relayout_basis_f16x2_kernel(const float * __restrict__ Bm, int64
   else if(q < HB_KS * 6 * 64 + 4 * 64)
   {
     const int w = q - HB_KS * 6 * 64, lane = w % 64, h = lane >> 5, r = lane & 31, vh = (w / 64) % 2, ks = w / 128;
-    const int64_t v = vg * 64 + vh * 32 + r;
+    const int64_t v = hperm[vg * 64 + vh * 32 + r];
     for(int j = 0; j < 8; j++)
     {
       const int k = ks * 16 + 8 * h + j; // joint
-      const float val = (v < V && k < NJ) ? W[v * NJ + k] : 0.0f;
+      const float val = (v >= 0 && k < NJ) ? W[v * NJ + k] : 0.0f;
       _Float16 a, b;
       split_f16x2(val * HB_SW, a, b);
       hi[j] = a;
@@ -154,15 +156,14 @@ __global__ void relayout_basis_f16x2_kernel(const float * __restrict__ Bm, int64
     // cw = 1 / (sG sW h[3]) with h[3] = sum_j W[v,j], the homogeneous coordinate the reference divides by
     // (src/LinearBlendSkinning.cpp:545-550): one reciprocal per vertex (<= 1 ulp from the division)
     const int c = q - (HB_KS * 6 * 64 + 4 * 64);
-    const int64_t v = vg * 64 + c;
-    float * cw = reinterpret_cast<float *>(base + HB_KS * HB_IMG + HB_CW_OFF);
-    cw[c] = v < V ? (1.0f / wSum[v]) / (sG * HB_SW) : 0.0f;
-    if(c < 60) // padding of the slot (its DMA copies whole 12 KiB images): 4096 - 256 bytes = 60 x 64 bytes
-    {
-      uint4 z = {0u, 0u, 0u, 0u};
-      uint4 * pad = reinterpret_cast<uint4 *>(base + HB_KS * HB_IMG + HB_CW_OFF + 256 + c * 64);
-      pad[0] = z; pad[1] = z; pad[2] = z; pad[3] = z;
-    }
+    const int64_t v = hperm[vg * 64 + c];
+    uint8_t * s14 = base + HB_KS * HB_IMG;
+    float * cw = reinterpret_cast<float *>(s14 + HB_CW_OFF);
+    cw[c] = v >= 0 ? (1.0f / wSum[v]) / (sG * HB_SW) : 0.0f;
+    reinterpret_cast<int32_t *>(s14 + HB_PERM_OFF)[c] = (int32_t)v; // where this slot's vertex goes in the outputs
+    // the flags word, then zeros up to the end of the slot (its DMA copies whole 12 KiB images)
+    int32_t * tail = reinterpret_cast<int32_t *>(s14 + HB_FLAGS_OFF);
+    for(int i = c; i < (HB_IMG - HB_FLAGS_OFF) / 4; i += 64) tail[i] = (i == 0) ? gflags[vg] : 0;
   }
 }
 
@@ -408,11 +409,80 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
     m->sB = std::exp2(std::floor(std::log2(32768.0f / bmax)));
     m->sG = std::exp2(std::floor(std::log2(32768.0f / (16.0f * tmax > 1.0f ? 16.0f * tmax : 1.0f))));
     TRY_OR_FREE(hipMalloc((void **)&m->B2h, (size_t)m->VGPn * HB_SLOTS * HB_IMG));
+    // Vertex groups by skinning class (common.h, HB_PERM_OFF).  (1) A group is 64 CONSECUTIVE vertices and its class what their
+    // weights touch — joints 0..15 only, both halves, joints 16..23 only.  (Sorting the VERTICES by class first, which makes 73 of
+    // the synthetic model's 108 groups single-class instead of 11, was measured: the step went from 46 to 62 us — a group's 64
+    // output rows of 12 bytes were then scattered over ~200 vertex positions, and the 85 MB of write-once output lost its
+    // coalescing.  Models whose vertex order follows the body parts — SMPL's does — have their single-class groups as they are.)
+    // (2) the groups dealt round-robin over the eight XCD slices of skin_kernel_h ([x nvg / 8, (x + 1) nvg / 8)), so that every XCD
+    // gets the same mix; (3) inside a slice the classes interleaved by fractional rank, so that every workgroup's run of
+    // consecutive groups gets it too (a slice of cheap groups beside a slice of full ones would finish with the full ones).
+    const int64_t nvg = m->VGPn;
+    std::vector<int32_t> hperm((size_t)nvg * 64, -1), gflags((size_t)nvg, 1);
+    {
+      std::vector<int> vcls((size_t)V);
+      for(int64_t v = 0; v < V; v++)
+      {
+        bool lo = false, hi = false;
+        for(int j = 0; j < NJ; j++)
+          if(W[v * NJ + j] != 0.0f) (j < 16 ? lo : hi) = true;
+        vcls[(size_t)v] = hi ? (lo ? 1 : 2) : 0;
+      }
+      std::vector<int32_t> order((size_t)V);
+      for(int64_t v = 0; v < V; v++) order[(size_t)v] = (int32_t)v;
+      std::vector<int> tflags((size_t)nvg, 0);
+      for(int64_t t = 0; t < nvg; t++)
+        for(int i = 0; i < 64 && t * 64 + i < V; i++)
+        {
+          const int c = vcls[(size_t)order[(size_t)(t * 64 + i)]];
+          tflags[(size_t)t] |= (c == 0 ? 1 : (c == 1 ? 3 : 2));
+        }
+      // (2) + (3): per XCD slice the sorted groups it is dealt, then their order inside the slice
+      std::vector<std::vector<int64_t>> bin(8);
+      {
+        int x = 0;
+        for(int64_t t = 0; t < nvg; t++)
+        {
+          for(int tries = 0; tries < 8 && (int64_t)bin[x].size() >= (((x + 1) * nvg) >> 3) - ((x * nvg) >> 3); tries++) x = (x + 1) & 7;
+          bin[x].push_back(t);
+          x = (x + 1) & 7;
+        }
+      }
+      int64_t g = 0;
+      for(int x = 0; x < 8; x++)
+      {
+        int cnt[4] = {0, 0, 0, 0}, seen[4] = {0, 0, 0, 0};
+        for(int64_t t : bin[x]) cnt[tflags[(size_t)t]]++;
+        std::vector<std::pair<double, int64_t>> keyed;
+        for(int64_t t : bin[x])
+        {
+          const int f = tflags[(size_t)t];
+          keyed.push_back({(seen[f] + 0.5) / cnt[f], t});
+          seen[f]++;
+        }
+        std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<double, int64_t> & a, const std::pair<double, int64_t> & b) { return a.first < b.first; });
+        for(auto & kt : keyed)
+        {
+          const int64_t t = kt.second;
+          for(int i = 0; i < 64 && t * 64 + i < V; i++) hperm[(size_t)(g * 64 + i)] = order[(size_t)(t * 64 + i)];
+          gflags[(size_t)g] = tflags[(size_t)t] ? tflags[(size_t)t] : 1;
+          g++;
+        }
+      }
+    }
+    DevBuf dPerm, dFlags;
+    TRY_OR_FREE(dPerm.reserve(sizeof(int32_t) * hperm.size()));
+    TRY_OR_FREE(dFlags.reserve(sizeof(int32_t) * gflags.size()));
+    TRY_OR_FREE(hipMemcpy(dPerm.p, hperm.data(), sizeof(int32_t) * hperm.size(), hipMemcpyHostToDevice));
+    TRY_OR_FREE(hipMemcpy(dFlags.p, gflags.data(), sizeof(int32_t) * gflags.size(), hipMemcpyHostToDevice));
     const int64_t cnt = m->VGPn * (HB_KS * 6 * 64 + 4 * 64 + 64);
     relayout_basis_f16x2_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256)>>>(m->Bm, m->ldB, m->Wdense, m->wSum, V, m->VGPn,
-                                                                                 m->sB, m->sG, m->B2h);
-    TRY_OR_FREE(hipGetLastError());
-    TRY_OR_FREE(hipDeviceSynchronize());
+                                                                                 m->sB, m->sG, m->B2h, dPerm.as<int32_t>(), dFlags.as<int32_t>());
+    hipError_t le = hipGetLastError();
+    if(le == hipSuccess) le = hipDeviceSynchronize();
+    dPerm.release();
+    dFlags.release();
+    TRY_OR_FREE(le);
   }
   // b and p keep at most 8 weights per vertex in registers: a model with more takes the first form from here on (decided
   // once, so that the layouts kept below are the ones the launches will read)

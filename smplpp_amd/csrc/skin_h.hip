@@ -22,6 +22,10 @@
 // (buffer_load_dwordx4 ... lds) seven slots ahead; slot 14 of an item carries the group's skinning weights.
 // One raw s_barrier per slot publishes the next image (counted vmcnt: DMAs stay in flight across it).
 // XCD x owns an eighth of the vertex groups (its slice of B2h, 2.4 MB, lives in that XCD's L2 and is read from HBM once).
+// Round 5: a vertex group is 64 vertices of ONE skinning class where the model allows it (common.h, HB_PERM_OFF: the groups are cut
+// from the vertices sorted by which k-step of the skinning product their weights touch; slot 14 carries the group's vertex ids and
+// its flags).  A group whose weights live in one k-step runs the skinning phase in the instantiation that issues only that k-step's
+// MFMAs and G' fragment reads — 3 (joints 0..15 only) or 2 (joints 16..23 only) MFMAs per entry instead of 5; exact zeros skipped.
 #include "common.h"
 
 #include <type_traits>
@@ -306,9 +310,10 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
     constexpr bool HT = decltype(ht_tag)::value;
     const int ft = __builtin_amdgcn_readfirstlane(ft_in), vg = __builtin_amdgcn_readfirstlane(vg_in), vgn = __builtin_amdgcn_readfirstlane(vgn_in);
     const int Bcur = vg * (HB_SLOTS * HB_IMG), Bnext = vgn * (HB_SLOTS * HB_IMG);
-    const int64_t v = (int64_t)vg * 64 + wv * 32 + l31;
-    cur.voff = v < V ? (int)(v * 12 + (int64_t)(4 * half) * frameB) : 0x7fffff00;
+    // (cur.voff — where this lane's vertex goes in the outputs — comes from the group's perm[] in slot 14, at k-step 13: its first
+    // user is the rest store of entry 2 of this item's skinning phase)
     cur.sb = __builtin_amdgcn_readfirstlane((ft * 64 + wf * 32) * frameB);
+    int gcls = 3;
 
 #if SKINH_ABL & 512
     if(blockIdx.x == 8 && tid == 0 && dbg_item < 8)
@@ -373,7 +378,13 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
           // slot 14's image: skinning weights of this vertex group (fragments) and the lane's cw; first G' fragments
           const unsigned char * wimg = imgV[HB_KS % H_R] - wv * 4096; // = image + wv * 2048 + lane * 16
           if constexpr(M >= 2 && M <= 5) wfr[M - 2] = *reinterpret_cast<const v4f *>(wimg + ((M - 2) / 2) * 4096 + ((M - 2) % 2) * 1024);
-          if constexpr(M == 6) cur.cw = *reinterpret_cast<const float *>(lds + imgS[HB_KS % H_R] + HB_CW_OFF + (wv * 32 + l31) * 4);
+          if constexpr(M == 6)
+          {
+            cur.cw = *reinterpret_cast<const float *>(lds + imgS[HB_KS % H_R] + HB_CW_OFF + (wv * 32 + l31) * 4);
+            const int pv = *reinterpret_cast<const int *>(lds + imgS[HB_KS % H_R] + HB_PERM_OFF + (wv * 32 + l31) * 4);
+            cur.voff = pv >= 0 ? pv * 12 + (4 * half) * frameB : 0x7fffff00; // (V * 12 * 64 frames < 2^31: launch_skin_f16x2 cuts the batch)
+            gcls = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(lds + imgS[HB_KS % H_R] + HB_FLAGS_OFF));
+          }
           if constexpr(M == 7)
           {
             gfr[0][0] = *reinterpret_cast<const v4f *>(gLane0);
@@ -399,10 +410,16 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
     // ---- skinning: 12 entries of 5 MFMAs; the VALU work of entry E - 1 rides behind the MFMAs of entry E.  K = 24 joints:
     // k-step 0 (joints 0..15) takes the three piece products; of k-step 1 only eight k are live (joints 16..23) and both lane
     // halves read the same G' piece, so Ghi1.Whi1 + Ghi1.Wlo1 is ONE MFMA against the weight fragment [Whi1 | Wlo1]
+    // CLS = the group's flags: 1 joints 0..15 only (k-step 0: MFMAs 0, 1, 3), 2 joints 16..23 only (k-step 1: MFMAs 2, 4), 3 both
+    auto skin_phase = [&](auto ctag) {
+    constexpr int CLS = decltype(ctag)::value;
+    constexpr bool K0 = (CLS & 1) != 0, K1 = (CLS & 2) != 0;
     hstatic_for<12>([&](auto ee) {
       constexpr int E = decltype(ee)::value, MPE = E & 1, ME = E % 3;
       hstatic_for<5>([&](auto bb) {
         constexpr int B = decltype(bb)::value;
+        constexpr bool LIVE = (B == 0 || B == 1 || B == 3) ? K0 : K1; // this position's MFMA belongs to a k-step the group uses
+        constexpr int FIRST = K0 ? 0 : 2;                             // the entry's first MFMA (starts from zero)
         // B: 0 Ghi0.Whi0, 1 Ghi0.Wlo0, 2 Ghi1.[Whi1 | Wlo1], 3 Glo0.Whi0, 4 Glo1.[Whi1 | 0]
         // (G' fragment index = 2 ks + piece; weight fragments: 0 Whi0, 1 Wlo0, 2 [Whi1 | 0], 3 [Whi1 | Wlo1])
         constexpr int GI = B < 2 ? 0 : (B == 2 ? 2 : (B == 3 ? 1 : 3));
@@ -414,7 +431,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
         {
           if constexpr(B == 0) macc[ME] = zero16;
         }
-        else if constexpr(B == 0)
+        else if constexpr(!LIVE)
+          ; // (a k-step none of the group's vertices has a weight in: its products are exact zeros)
+        else if constexpr(B == FIRST)
           macc[ME] = mfma(gfr[MPE][GI], wfr[WI], zero16);
         else
           macc[ME] = mfma(gfr[MPE][GI], wfr[WI], macc[ME]);
@@ -429,7 +448,8 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
         if constexpr(E < 11 && B <= 3 && !(SKINH_ABL & (8 | 16))) // G' fragments of the next entry, in the order of their first use
         {
           constexpr int I = B == 0 ? 0 : (B == 1 ? 2 : (B == 2 ? 1 : 3));
-          gfr[MPE ^ 1][I] = *reinterpret_cast<const v4f *>((I < 2 ? gLane0 + I * 1024 : gLane1 + (I - 2) * 512) + (E + 1) * 3072);
+          if constexpr(I < 2 ? K0 : K1) // (only the k-steps the group uses)
+            gfr[MPE ^ 1][I] = *reinterpret_cast<const v4f *>((I < 2 ? gLane0 + I * 1024 : gLane1 + (I - 2) * 512) + (E + 1) * 3072);
         }
         if constexpr(E == 11 && B == 4) // root translation of the tail's first row
           trb[0] = *reinterpret_cast<const v4f *>(trLane);
@@ -467,6 +487,14 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_h(const uint8_t * __restri
         HSB();
       });
     });
+    };
+    // (wave-uniform: the flags word of the group, read at k-step 13)
+    if(gcls == 1)
+      skin_phase(std::integral_constant<int, 1>{});
+    else if(gcls == 2)
+      skin_phase(std::integral_constant<int, 2>{});
+    else
+      skin_phase(std::integral_constant<int, 3>{});
 
     prev = cur;
 #if SKINH_ABL & (256 | 512)

@@ -229,3 +229,30 @@ def synthetic_inputs(n: int, seed: int = 1):
     if n > 1:
         theta[n // 2, 1:, :] = 0.0
     return beta, theta
+
+
+def relabel_vertices(model: dict, order) -> dict:
+    """The same model with vertex order[i] as its vertex i (every per-vertex array, the regressor's columns and the 1-based face
+    indices permuted consistently): another numbering of the same body.  Used to build vertex orders that follow the body parts,
+    as SMPL's does (tools/fk_part_ordered.py, tests/test_fk_gpu.py)."""
+    import numpy as np
+
+    order = np.asarray(order, np.int64)
+    inv = np.empty_like(order)
+    inv[order] = np.arange(len(order))
+    m = {k: v.copy() for k, v in model.items()}
+    for k in ("vertices_template", "weights", "shape_blend_shapes", "pose_blend_shapes"):
+        m[k] = np.ascontiguousarray(model[k][order])
+    m["joint_regressor"] = np.ascontiguousarray(model["joint_regressor"][:, order])
+    m["face_indices"] = (inv[model["face_indices"].astype(np.int64) - 1] + 1).astype(model["face_indices"].dtype)
+    return m
+
+
+def skinning_classes(weights):
+    """Per vertex: 0 = weights on joints 0..15 only, 1 = on both halves, 2 = on joints 16..23 only (the two k-steps of the fused
+    kernel's skinning product: smplpp_amd/csrc/common.h, HB_PERM_OFF)."""
+    import numpy as np
+
+    w = np.asarray(weights)
+    lo, hi = (w[:, :16] != 0).any(axis=1), (w[:, 16:] != 0).any(axis=1)
+    return np.where(hi & lo, 1, np.where(hi, 2, 0))

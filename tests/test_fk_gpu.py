@@ -422,3 +422,35 @@ def test_fk_out_of_range_operands_are_reported(smpl, synth_model):
     far[1, 5] = 0.0
     o = smpl.launch(beta, theta, want=("verts",))  # in range: no error, finite
     assert np.isfinite(o["verts"]).all() and smpl.launchStatus() == 0
+
+
+def test_fk_skinning_class_groups_on_a_part_ordered_numbering(synth_model, oracle_synth):
+    """skin_kernel_h runs a vertex group (64 consecutive vertices) whose skinning weights live in ONE k-step of the blend product —
+    joints 0..15 only, or joints 16..23 only (SMPL's arms) — in an instantiation that issues only that k-step's MFMAs (common.h,
+    HB_PERM_OFF), and deals the groups over the XCD slices by class.  The stand-in's spiral numbering has 11 such groups of 108 and
+    none of the second kind; the SAME body renumbered so that its vertex order follows the parts (as SMPL's does) has 54 + 19.  The
+    renumbered model must match the oracle on ITS numbering, and — the skipped products being exact zeros — give the original
+    numbering's bits, vertex for vertex."""
+    from oracle import cpu
+    from smplpp_amd import model_io
+    from smplpp_amd.smpl import SMPL
+
+    cls = model_io.skinning_classes(synth_model["weights"])
+    order = np.argsort(cls, kind="stable")
+    part = model_io.relabel_vertices(synth_model, order)
+    c = model_io.skinning_classes(part["weights"])
+    groups = [(int((c[t:t + 64] != 2).any()) | 2 * int((c[t:t + 64] != 0).any())) for t in range(0, len(c), 64)]
+    assert groups.count(1) >= 40 and groups.count(2) >= 10 and groups.count(3) >= 10  # all three instantiations run
+    beta, theta = model_io.synthetic_inputs(130, seed=21)  # three frame tiles, the last one partial
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(part)
+    o = s.launch(beta, theta)
+    r = cpu.OracleModel(part).fk(beta, theta)
+    for k in ("verts", "rest", "joints"):
+        assert np.abs(o[k] - r[k]).max() < VERT_TOL, k
+    s0 = SMPL()
+    s0.setDevice("cuda:0")
+    s0.init(synth_model)
+    o0 = s0.launch(beta, theta)
+    assert np.array_equal(o["verts"], o0["verts"][:, order]) and np.array_equal(o["rest"], o0["rest"][:, order])
