@@ -17,6 +17,7 @@
 #include "mesh_device.h"
 #include "staging.h"
 #include "trace.h"
+#include "signal.h"
 
 #include <hip/hip_ext.h>
 
@@ -30,7 +31,8 @@ namespace smplpp_hip
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
               float * xforms44, float * rest, float * poserot, hipStream_t st, int range_slot);
 int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
-                          float * jac, hipStream_t st, int64_t frame_base);
+                          float * jac, hipStream_t st, int64_t frame_base, bool value_like_jac = false, unsigned * sig_flag = nullptr,
+                          unsigned * sig_counter = nullptr, unsigned sig_tick = 0u);
 
 constexpr int TD75 = SMPLPP_THETA_DIM;        // 75
 constexpr int TD44 = SMPLPP_LATENT_POSE_DIM;  // 44
@@ -291,28 +293,6 @@ __device__ unsigned long long g_solve_stamps[64 * 16];
 // so a workgroup only has to wait for its own stores: a device-scope release fence per workgroup would write back the whole
 // L2 of its XCD 256 times per kernel — including the lines of the kernel running beside it (the fused FK kernel went from 17
 // to 28 us that way).
-template<class T>
-__device__ inline void st_agent(T * p, T v)
-{
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline void wg_signal(unsigned * __restrict__ flag, unsigned * __restrict__ counter, unsigned tick)
-{
-  if(!flag) return;
-  // every thread's stores have been acknowledged before the workgroup counts itself in: the wait is explicit (the barrier
-  // alone orders LDS and, outside threadgroup-split mode, is not defined to drain the vector-memory counter)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if(threadIdx.x == 0)
-  {
-    if(__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
-    {
-      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(flag, tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
-
 template<int DMAX, int RCAP, int NGN>
 __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArrays & ta, const float * __restrict__ theta25,
                                              const float * __restrict__ verts_all, const float * __restrict__ rest_all,
@@ -2231,7 +2211,8 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
                                                        int chunk_rows, const int * __restrict__ skip, double * __restrict__ e2_out,
                                                        int * __restrict__ status, int * __restrict__ sticky, double * __restrict__ x_out, int dbg_stop, int m_dim,
                                                        float * __restrict__ theta25, float * __restrict__ theta_copy,
-                                                       unsigned * __restrict__ go_flag, unsigned * __restrict__ go_counter, unsigned go_tick)
+                                                       unsigned * __restrict__ go_flag, unsigned * __restrict__ go_counter, unsigned go_tick,
+                                                       unsigned * __restrict__ done_flag, unsigned * __restrict__ done_counter, unsigned done_tick)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int64_t f = blockIdx.x;
@@ -2315,6 +2296,7 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
       for(int k = tid; k < K * 3; k += 256) pts[tb * 3 + k] = ta.apos[tb * 3 + k];
     if(theta_copy)
       for(int i = tid; i < theta_dim; i += 256) theta_copy[f * theta_dim + i] = theta[f * theta_dim + i];
+    wg_signal(done_flag, done_counter, done_tick); // (every workgroup of the grid counts itself in)
     return;
   }
   __builtin_amdgcn_s_setprio(3); // a latency chain: its few wavefronts issue ahead of the face scan that shares the CU
@@ -2717,7 +2699,11 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
     if(ok)
     {
       t = t + (float)xfull[i];
-      theta[f * theta_dim + i] = t;
+      // (done_flag: the decoder's Jacobian kernel on the side stream reads the new latent behind that flag — write-through, signal.h)
+      if(done_flag)
+        st_agent(&theta[f * theta_dim + i], t);
+      else
+        theta[f * theta_dim + i] = t;
       // VPoser latent layout: the entries that pass through to theta25 (node.cpp:763-771) are kept current here
       if(theta25 && i < 6) theta25[f * TD75 + i] = t;
       if(theta25 && i >= 38) theta25[f * TD75 + 69 + (i - 38)] = t;
@@ -2735,6 +2721,8 @@ __global__ __launch_bounds__(256) void ik_solve_kernel(TaskArrays ta, const doub
   if(x_out)
     for(int i = tid; i < D; i += 256) x_out[f * D + i] = xfull[i];
   SOLVE_STAMP(11);
+  // "this configuration is final": what the capture loops' side stream waits for before it makes the NEXT decoder Jacobian
+  wg_signal(done_flag, done_counter, done_tick);
 }
 
 // node.cpp:970-1001 — re-projection of the K query points of every frame onto that frame's posed mesh.
@@ -3057,8 +3045,18 @@ struct smplpp_ik
   // flag, [16] its workgroup counter, [32] join flag, [48] its counter (one 64-byte line each)
   int * dbg_buf = nullptr;
   unsigned * sig = nullptr;
-  unsigned tick_fork = 0, tick_join = 0;
+  unsigned tick_fork = 0, tick_join = 0, tick_done = 0; // ([64] / [80]: the solve's "configuration final" flag and its counter)
   bool use_flags = false;
+  // Latent layout with few frames (a capture fit's chains: one decoder workgroup per frame, most of the chip idle).  The decoder's
+  // VALUE is all the pose step, the fused kernel and the evaluation's direct rows need; its Jacobian (two thirds of the kernel's
+  // 29 us) only the pull-back behind them.  So when another iteration follows, the side stream — idle once scan + finish are done,
+  // well before the solve ends — waits for the solve's "configuration final" flag and makes the NEXT iteration's Jacobian there
+  // (vposer_jac2_kernel<NF, false>, `out` null, raising the join flag at its end), while the main stream decodes the value with the
+  // kernel's value-only instantiation (<NF, true>: the same bits, 18 us), poses, skins and joins: the Jacobian is there when the
+  // evaluation (which pulls its rows back through it) starts.  Same kernels' arithmetic, another schedule: bit-identical
+  // (tests/test_mocap_gpu.py).  SMPLPP_IK_LATENT_SPLIT=0/1 (read at creation) overrides the n <= 128 rule.
+  bool latent_split = false;
+  bool jac_ahead = false; // the decoder Jacobian of the CURRENT configuration is (being) made on the side stream; the join flag follows it
   // development switches, read ONCE at creation (never in the per-call path): SMPLPP_DEBUG_SYNC, SMPLPP_IK_DBG_STOP,
   // SMPLPP_IK_OVERLAP=0 (re-projection behind the solve on one stream), SMPLPP_SCAN_BLOCKS
   bool dbg_sync = false, overlap_ok = true;
@@ -3115,6 +3113,7 @@ extern "C" int smplpp_ik_set_frame_base(smplpp_ik * s, int64_t frame_base)
 {
   if(!s || frame_base < 0) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_set_frame_base: bad argument");
   s->frame_base = frame_base;
+  s->jac_ahead = false;
   return SMPLPP_OK;
 }
 
@@ -3179,6 +3178,8 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
     // keep their three (2 and 3 measured level).  SMPLPP_SCAN_BLOCKS overrides.
     s->scan_blocks = (n >= 256 && n < 512) ? 2 * n : 1536;
     if((e = getenv("SMPLPP_SCAN_BLOCKS"))) s->scan_blocks = atoll(e);
+    s->latent_split = vposer != nullptr && n <= 128 && s->dbg_stop == 0;
+    if((e = getenv("SMPLPP_IK_LATENT_SPLIT"))) s->latent_split = vposer != nullptr && e[0] != '0';
   }
   const size_t nk = (size_t)n * K;
   const size_t Dmax = TD75 + 2 * K + NB;
@@ -3272,8 +3273,8 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   S_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   S_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   {
-    S_TRY(dalloc(s, &s->sig, 64));
-    S_TRY(hipMemset(s->sig, 0, sizeof(unsigned) * 64));
+    S_TRY(dalloc(s, &s->sig, 128));
+    S_TRY(hipMemset(s->sig, 0, sizeof(unsigned) * 128));
     // stream memory operations are optional in HIP: probe once (flag 0 >= 0 is satisfied at once); SMPLPP_IK_EVENTS=1 keeps events
     const char * e = getenv("SMPLPP_IK_EVENTS");
     if(!(e && e[0] != '0'))
@@ -3281,6 +3282,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
       s->use_flags = hipStreamWaitValue32(s->side, s->sig, 0u, hipStreamWaitValueGte, 0xffffffffu) == hipSuccess;
       (void)hipGetLastError();
     }
+    if(!s->use_flags) s->latent_split = false; // (the hand-overs of that schedule are flags)
   }
   S_TRY(hipDeviceSynchronize());
 #undef S_TRY
@@ -3353,6 +3355,7 @@ extern "C" int smplpp_ik_set_config(smplpp_ik * s, const float * beta, const flo
   if(beta) HIP_TRY(hipMemcpy(s->beta, beta, sizeof(float) * s->n * NB, kind));
   if(theta) HIP_TRY(hipMemcpy(s->theta, theta, sizeof(float) * s->n * s->theta_dim, kind));
   // status bit 1 (smplpp_ik_get_status) reports failures "since the configuration was set": a new configuration starts clean
+  s->jac_ahead = false; // (a Jacobian made ahead belongs to the configuration it was made for)
   HIP_TRY(hipMemset(s->status, 0, sizeof(int) * s->n));
   HIP_TRY(hipMemset(s->sticky, 0, sizeof(int) * s->n));
   if(s->m->range_flag) HIP_TRY(hipMemset(s->m->range_flag + RANGE_INTERNAL, 0, sizeof(int))); // (status bit 3: same lifetime)
@@ -3418,13 +3421,16 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
   const int64_t n = s->n;
   const int K = (int)s->K;
   const float * th25 = s->theta;
+  // latent_split: this configuration's decoder Jacobian is being made on the side stream (smplpp_ik::jac_ahead) — here only the value
+  const bool jac_elsewhere = s->vp && s->jac_ahead;
   {
     TraceRange tr_fwd("forward SMPL"); // node.cpp:752-781 (the VPoser splice is inside that span there too)
     if(s->vp) // node.cpp:761-772
     {
       // the decoder writes its 63 angles straight into theta25[:, 6:69]; the pass-through entries (root translation / rotation,
       // joints 22-23) are kept current by whoever changes the configuration: smplpp_ik_set_config and the solve kernel's update
-      int rc = vposer_forward_device(s->vp, n, s->theta + 6, TD44, s->theta25 + 6, 75, s->vjac, st, s->frame_base);
+      int rc = jac_elsewhere ? vposer_forward_device(s->vp, n, s->theta + 6, TD44, s->theta25 + 6, 75, nullptr, st, s->frame_base, true)
+                             : vposer_forward_device(s->vp, n, s->theta + 6, TD44, s->theta25 + 6, 75, s->vjac, st, s->frame_base);
       if(rc) return rc;
       th25 = s->theta25;
     }
@@ -3442,6 +3448,7 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
       HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
     s->side_pending = false;
   }
+  s->jac_ahead = false; // (consumed by the evaluation below: the join above covers the Jacobian kernel, which raised it)
   const bool deep = m->nlev > 9; // (ik_eval_kernel's two instantiations: see EvalPlan)
   const size_t shmem = sizeof(float) * (deep ? EvalPlan<DMAX, 64, 3>::L_END : EvalPlan<9, 76, 6>::L_END) + L_ANC_BYTES;
   static PerDeviceOnce once_eval[2];
@@ -3502,8 +3509,9 @@ struct SeqHook
   const uint8_t * next_valid = nullptr;  // [n][K]
 };
 
+// more_follows: the caller enqueues another iteration right behind this call's last one (the sequence driver, frame after frame)
 static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optimize_beta_from, int64_t min_valid, hipStream_t st,
-                              const SeqHook * hook = nullptr)
+                              const SeqHook * hook = nullptr, bool more_follows = false)
 {
   int rc = SMPLPP_OK;
   smplpp_model * m = s->m;
@@ -3513,13 +3521,13 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
   HIP_TRY(lds_opt_in(once_solve[1], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<true>), (int)SOLVE_LDS_MAX));
   HIP_TRY(lds_opt_in(once_solve[2], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false, 11>), (int)SOLVE_LDS_MAX));
   HIP_TRY(lds_opt_in(once_solve[3], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false, 5>), (int)SOLVE_LDS_MAX));
-  if(s->use_flags && (s->tick_fork > 0x7fff0000u || s->tick_join > 0x7fff0000u))
+  if(s->use_flags && (s->tick_fork > 0x7fff0000u || s->tick_join > 0x7fff0000u || s->tick_done > 0x7fff0000u))
   {
     // the hand-over flags carry iteration numbers compared with >=: start over long before they could wrap
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipStreamSynchronize(s->side));
-    HIP_TRY(hipMemset(s->sig, 0, sizeof(unsigned) * 64));
-    s->tick_fork = s->tick_join = 0;
+    HIP_TRY(hipMemset(s->sig, 0, sizeof(unsigned) * 128));
+    s->tick_fork = s->tick_join = s->tick_done = 0;
   }
   const bool dbg = s->dbg_sync;
   const int dbg_stop = s->dbg_stop;
@@ -3569,14 +3577,19 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
     float * theta_record = last ? hook->theta_record : nullptr;
     const bool go = beside && s->use_flags; // the side stream's fork: raised by the solve kernel once all its workgroups run
     if(go) s->tick_fork++;
+    // latent_split: the NEXT iteration's decoder Jacobian on the side stream, behind this solve's "configuration final" flag
+    const bool ahead = s->latent_split && go && !opt_beta && (it + 1 < iters || more_follows);
+    if(ahead) s->tick_done++;
+    unsigned * const done_flag = ahead ? s->sig + 64 : (unsigned *)nullptr;
+    unsigned * const done_counter = ahead ? s->sig + 80 : (unsigned *)nullptr;
 #define SOLVE_(DO) ik_solve_kernel<DO><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
     s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
     s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr, theta_record, \
-    go ? s->sig : (unsigned *)nullptr, go ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork)
+    go ? s->sig : (unsigned *)nullptr, go ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork, done_flag, done_counter, s->tick_done)
 #define SOLVE11_(NTR_) ik_solve_kernel<false, NTR_><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
     s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
     s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr, theta_record, \
-    go ? s->sig : (unsigned *)nullptr, go ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork)
+    go ? s->sig : (unsigned *)nullptr, go ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork, done_flag, done_counter, s->tick_done)
     {
       TraceRange tr_solve("solve IK"); // node.cpp:907-943
       if(dual_only)
@@ -3623,15 +3636,23 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
       int fsplit = (s->n < 256) ? (int)(256 / s->n) : 1;
       if(fsplit > K) fsplit = K;
       if(fsplit < 1) fsplit = 1;
-      const bool join_flag = beside && s->use_flags;
-      if(join_flag) s->tick_join++;
+      const bool join_flag = beside && s->use_flags && !ahead; // (ahead: the Jacobian kernel behind the finish kernel raises the join)
+      if(beside && s->use_flags) s->tick_join++;
       hipExtLaunchKernelGGL(proj_finish_kernel, dim3((unsigned)(s->n * fsplit)), dim3(256), 0, pst, nullptr,
-                            (beside && !join_flag) ? s->ev_join : nullptr, 0,
+                            (beside && !s->use_flags) ? s->ev_join : nullptr, 0,
                             view_of(m), s->ta, (const float *)s->verts, qpts, m->F, K, (const int *)s->skip, s->list_cnt, s->list_d,
                             s->list_f, dbg ? dbg_buf : (int *)nullptr, fsplit, join_flag ? s->sig + 32 : (unsigned *)nullptr,
                             join_flag ? s->sig + 48 : (unsigned *)nullptr, s->tick_join, last ? hook->next_tpos : (const float *)nullptr,
                             last ? hook->next_valid : (const uint8_t *)nullptr);
       HIP_TRY(hipGetLastError());
+      if(ahead)
+      {
+        HIP_TRY(hipStreamWaitValue32(s->side, s->sig + 64, s->tick_done, hipStreamWaitValueGte, 0xffffffffu));
+        rc = vposer_forward_device(s->vp, s->n, s->theta + 6, TD44, nullptr, 75, s->vjac, s->side, s->frame_base, false, s->sig + 32,
+                                   s->sig + 48, s->tick_join);
+        if(rc) return rc;
+        s->jac_ahead = true;
+      }
       if(beside) s->side_pending = true;
       if(dbg)
       {
@@ -3760,7 +3781,7 @@ extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * 
       hook.next_valid = vl.d + (t + 1) * nk;
     }
     if(iters > 0)
-      rc = ik_iterate_enqueue(s, iters, enable_qp, -1, min_valid, st, &hook);
+      rc = ik_iterate_enqueue(s, iters, enable_qp, -1, min_valid, st, &hook, /*more_follows=*/t + 1 < T && iters_per_frame > 0);
     else // (no iteration to carry the hook)
     {
       ik_seq_frame_kernel<<<grid, 256, 0, st>>>(hook.next_tpos, hook.next_valid, s->ta.tpos, s->ta.posw, nk, s->theta, hook.theta_record, ntheta);

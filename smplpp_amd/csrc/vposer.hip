@@ -8,6 +8,7 @@
 // the rotation tail with 6-wide dual numbers, so the same branches are taken for value and derivative.
 // Weights are stored transposed ([in][out]) so that consecutive lanes read consecutive outputs.
 #include "staging.h"
+#include "signal.h"
 
 #include <cfloat>
 #include <cmath>
@@ -434,14 +435,20 @@ struct VJ2
   static constexpr int TOTAL = RED + 64 + 64;
 };
 
-template<int NF>
+// VO (round 5): the VALUE path alone — the same MFMAs on the same operands in the same order for the activation columns, so the
+// decoded angles are the bits the full kernel decodes, in about half its time (no tangent MFMAs, no tangent blocks, no chain
+// rule).  The capture loops use it to get theta25 early: the pose step, the fused kernel and the evaluation's direct rows need the
+// value only, and the full kernel (the Jacobian; `out` null) then runs beside them on the side stream (ik_forward_eval).
+// sig_*: the side-stream launch raises the join flag itself (signal.h); its Jacobian is then stored write-through.
+template<int NF, bool VO>
 __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restrict__ z, int64_t z_stride, const float * __restrict__ w0t,
                                                           const float * __restrict__ b0, const float * __restrict__ b1,
                                                           const float * __restrict__ b2, const uint8_t * __restrict__ w1h,
                                                           const uint8_t * __restrict__ w2h, const uint8_t * __restrict__ w0h,
                                                           const float * __restrict__ c10, float sD1, float sD2, float iW1, float iW2,
                                                           float * __restrict__ out, int64_t out_stride, float * __restrict__ jac, int64_t n,
-                                                          int64_t frame_base)
+                                                          int64_t frame_base, unsigned * __restrict__ sig_flag,
+                                                          unsigned * __restrict__ sig_counter, unsigned sig_tick)
 {
   typedef VJ2<NF> L;
   extern __shared__ __attribute__((aligned(16))) unsigned char vl[];
@@ -487,9 +494,12 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
     h0 *= p0 ? 1.0f : 0.01f;
     h1 *= p1 ? 1.0f : 0.01f;
     // row masks in the B fragment's element order: row k is element k % 8 of lane half (k % 16) / 8 in k-step k / 16
-    unsigned short * mk = reinterpret_cast<unsigned short *>(vl + L::MK + q * 1024);
-    mk[(tid >> 4) * 16 + ((tid >> 3) & 1) * 8 + (tid & 7)] = p0 ? 0xffffu : 0u;
-    mk[((tid + 256) >> 4) * 16 + (((tid + 256) >> 3) & 1) * 8 + (tid & 7)] = p1 ? 0xffffu : 0u;
+    if constexpr(!VO)
+    {
+      unsigned short * mk = reinterpret_cast<unsigned short *>(vl + L::MK + q * 1024);
+      mk[(tid >> 4) * 16 + ((tid >> 3) & 1) * 8 + (tid & 7)] = p0 ? 0xffffu : 0u;
+      mk[((tid + 256) >> 4) * 16 + (((tid + 256) >> 3) & 1) * 8 + (tid & 7)] = p1 ? 0xffffu : 0u;
+    }
     sA1[q] = vscale512(h0, h1, red);
     vput_act(vl + L::AF + q * VJ_AF, tid, h0 * sA1[q]);
     vput_act(vl + L::AF + q * VJ_AF, tid + 256, h1 * sA1[q]);
@@ -525,8 +535,11 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
       for(int t = 0; t < 4; t++)
 #pragma unroll
         for(int p = 0; p < 2; p++) st[sidx][t][p] = *reinterpret_cast<const v4fv *>(ap + (size_t)t * (32 * 2048) + ks * 2048 + p * 1024);
-      sb[sidx][0] = *reinterpret_cast<const v4fv *>(bp + ks * 2048);
-      sb[sidx][1] = *reinterpret_cast<const v4fv *>(bp + ks * 2048 + 1024);
+      if constexpr(!VO)
+      {
+        sb[sidx][0] = *reinterpret_cast<const v4fv *>(bp + ks * 2048);
+        sb[sidx][1] = *reinterpret_cast<const v4fv *>(bp + ks * 2048 + 1024);
+      }
     };
     // (every workgroup starts its k loop elsewhere, so that the CUs do not ask the L2s for the same weight lines at the same
     // instant: -2 % per latent IK iteration; by the GLOBAL group, so that sharding moves no bit)
@@ -538,8 +551,11 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
     auto load_lds = [&](int slot, int ks) {
       vah[slot] = *reinterpret_cast<const v4fv *>(avp + ks * avs);
       val[slot] = *reinterpret_cast<const v4fv *>(avp + ks * avs + (avs >> 1));
+      if constexpr(!VO)
+      {
 #pragma unroll
-      for(int q = 0; q < NF; q++) mk[slot][q] = *reinterpret_cast<const u4v *>(vl + L::MK + q * 1024 + ks * 32 + lh * 16);
+        for(int q = 0; q < NF; q++) mk[slot][q] = *reinterpret_cast<const u4v *>(vl + L::MK + q * 1024 + ks * 32 + lh * 16);
+      }
     };
     load_stage(0, rot);
     load_stage(1, (rot + 1) & 31);
@@ -564,7 +580,7 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
           vacc[t] = vmfma(st[u][t][1], vah[u & 1], vacc[t]);
         }
 #pragma unroll
-        for(int q = 0; q < NF; q++)
+        for(int q = 0; q < (VO ? 0 : NF); q++)
         {
           const v4fv bh = __builtin_bit_cast(v4fv, __builtin_bit_cast(u4v, sb[u][0]) & mk[u & 1][q]);
           const v4fv bl = __builtin_bit_cast(v4fv, __builtin_bit_cast(u4v, sb[u][1]) & mk[u & 1][q]);
@@ -613,7 +629,7 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
     // 32 (g & 1) + column in k-step 2 tile + (g >> 1): one 8-byte store per piece
     const float um = 0.99f * iW1 / sD1;
 #pragma unroll
-    for(int t = 0; t < 4; t++)
+    for(int t = 0; t < (VO ? 0 : 4); t++)
 #pragma unroll
       for(int g = 0; g < 4; g++)
       {
@@ -676,7 +692,7 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
       vah[slot] = *reinterpret_cast<const v4fv *>(avp + ks * avs);
       val[slot] = *reinterpret_cast<const v4fv *>(avp + ks * avs + (avs >> 1));
 #pragma unroll
-      for(int q = 0; q < NF; q++)
+      for(int q = 0; q < (VO ? 0 : NF); q++)
       {
         dbh[slot][q] = *reinterpret_cast<const v4fv *>(vl + L::D2 + q * VJ_DF + ks * 2048 + l * 16);
         dbl[slot][q] = *reinterpret_cast<const v4fv *>(vl + L::D2 + q * VJ_DF + ks * 2048 + 1024 + l * 16);
@@ -697,7 +713,7 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
         vacc = vmfma(st[u][0], val[u & 1], vacc);
         vacc = vmfma(st[u][1], vah[u & 1], vacc);
 #pragma unroll
-        for(int q = 0; q < NF; q++)
+        for(int q = 0; q < (VO ? 0 : NF); q++)
         {
           acc[q] = vmfma(st[u][0], dbh[u & 1][q], acc[q]);
           acc[q] = vmfma(st[u][0], dbl[u & 1][q], acc[q]);
@@ -721,7 +737,7 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
       }
     }
 #pragma unroll
-    for(int q = 0; q < NF; q++)
+    for(int q = 0; q < (VO ? 0 : NF); q++)
     {
       float * so = reinterpret_cast<float *>(vl + L::D2 + q * VJ_DF);
 #pragma unroll
@@ -745,10 +761,12 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
     float o6[6], aa[3], jc[3];
     for(int i = 0; i < 6; i++) o6[i] = so[(j * 6 + i) * 33 + 32];
     sixd_to_aa_dir<1>(o6, dir, aa, jc);
-    if(dir == 0 && f0 + q >= 0 && f0 + q < n)
+    if(out && dir == 0 && f0 + q >= 0 && f0 + q < n)
       for(int i = 0; i < 3; i++) out[(f0 + q) * out_stride + j * 3 + i] = aa[i];
-    for(int i = 0; i < 3; i++) sj[j * 18 + i * 6 + dir] = jc[i];
+    if constexpr(!VO)
+      for(int i = 0; i < 3; i++) sj[j * 18 + i * 6 + dir] = jc[i];
   }
+  if constexpr(VO) return;
   __syncthreads();
   VPJ_T(5);
   // one thread per (frame, joint, latent column): the six tangent entries of the column once for the joint's three output rows
@@ -768,10 +786,14 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
       float s = 0.f;
 #pragma unroll
       for(int k = 0; k < 6; k++) s += sj[j * 18 + i * 6 + k] * t6[k];
-      jac[((f0 + q) * 63 + j * 3 + i) * LAT + c] = s;
+      if(sig_flag) // (read on another stream behind the flag: write-through, signal.h)
+        st_agent(&jac[((f0 + q) * 63 + j * 3 + i) * LAT + c], s);
+      else
+        jac[((f0 + q) * 63 + j * 3 + i) * LAT + c] = s;
     }
   }
   VPJ_T(6);
+  wg_signal(sig_flag, sig_counter, sig_tick);
 }
 
 // weights [out][in] -> fp16x2 pieces in MFMA fragment order: [ceil(out/32)][in/16][piece 2][64 lanes][8 fp16]
@@ -808,31 +830,45 @@ __global__ void rotmat_to_aa_kernel(const float * __restrict__ rot, float * __re
   for(int q = 0; q < 3; q++) aa_out[i * 3 + q] = aa[q].v;
 }
 
+// value_like_jac (jac null): the decoded angles by the Jacobian kernel's own value path (vposer_jac2_kernel<NF, true>: bit-identical
+// to what a call WITH jac writes to `out`), not by the exact-fp32 value kernel.  sig_flag / sig_counter / sig_tick (jac non-null): the
+// launch raises that flag when its last workgroup is done and stores the Jacobian write-through (a consumer on another stream).
 int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
-                          float * jac, hipStream_t st, int64_t frame_base)
+                          float * jac, hipStream_t st, int64_t frame_base, bool value_like_jac, unsigned * sig_flag,
+                          unsigned * sig_counter, unsigned sig_tick)
 {
-  if(jac && v->w0h && v->c10)
+  if((jac || value_like_jac) && v->w0h && v->c10)
   {
     // One kernel, two instantiations with the SAME arithmetic per frame: more frames than CUs -> two frames per workgroup share
     // every weight fragment; fewer -> one frame per workgroup.  Either way a frame's bits are a function of the frame and of its
     // GLOBAL index's group (frame_base + local index) / 2 alone: not of the batch size, not of the shard it travels in.
+    const bool vo = !jac;
+    static PerDeviceOnce once[4];
+#define VJ2_(NF_, VO_, GRID_)                                                                                                              \
+  do                                                                                                                                       \
+  {                                                                                                                                        \
+    HIP_TRY(lds_opt_in(once[(NF_ - 1) * 2 + (VO_ ? 1 : 0)], v->device, reinterpret_cast<const void *>(&vposer_jac2_kernel<NF_, VO_>),    \
+                       VJ2<NF_>::TOTAL));                                                                                                  \
+    vposer_jac2_kernel<NF_, VO_><<<dim3((unsigned)(GRID_)), dim3(256), VJ2<NF_>::TOTAL, st>>>(                                             \
+        z, z_stride, v->w0t, v->b0, v->b1, v->b2, v->w1h, v->w2h, v->w0h, v->c10, v->sD1, v->sD2, 1.0f / v->sW1, 1.0f / v->sW2, out,     \
+        out_stride, jac, n, frame_base, sig_flag, sig_counter, sig_tick);                                                                  \
+  } while(0)
     if(n > device_cus(v->device))
     {
-      static PerDeviceOnce once2;
-      HIP_TRY(lds_opt_in(once2, v->device, reinterpret_cast<const void *>(&vposer_jac2_kernel<2>), VJ2<2>::TOTAL));
       const int64_t groups = (frame_base % VJ_GROUP + n + VJ_GROUP - 1) / VJ_GROUP;
-      vposer_jac2_kernel<2><<<dim3((unsigned)groups), dim3(256), VJ2<2>::TOTAL, st>>>(z, z_stride, v->w0t, v->b0, v->b1, v->b2, v->w1h, v->w2h,
-                                                                                    v->w0h, v->c10, v->sD1, v->sD2, 1.0f / v->sW1,
-                                                                                    1.0f / v->sW2, out, out_stride, jac, n, frame_base);
+      if(vo)
+        VJ2_(2, true, groups);
+      else
+        VJ2_(2, false, groups);
     }
     else
     {
-      static PerDeviceOnce once1;
-      HIP_TRY(lds_opt_in(once1, v->device, reinterpret_cast<const void *>(&vposer_jac2_kernel<1>), VJ2<1>::TOTAL));
-      vposer_jac2_kernel<1><<<dim3((unsigned)n), dim3(256), VJ2<1>::TOTAL, st>>>(z, z_stride, v->w0t, v->b0, v->b1, v->b2, v->w1h, v->w2h,
-                                                                               v->w0h, v->c10, v->sD1, v->sD2, 1.0f / v->sW1,
-                                                                               1.0f / v->sW2, out, out_stride, jac, n, frame_base);
+      if(vo)
+        VJ2_(1, true, n);
+      else
+        VJ2_(1, false, n);
     }
+#undef VJ2_
     HIP_TRY(hipGetLastError());
     return SMPLPP_OK;
   }
@@ -971,11 +1007,30 @@ extern "C" int smplpp_vposer_forward_at(smplpp_vposer * v, int64_t n, int64_t fr
   HIP_TRY(zi.init(z, (size_t)n * LAT, space, st));
   HIP_TRY(oo.init(out, (size_t)n * 63, space));
   HIP_TRY(jo.init(jac, (size_t)n * 63 * LAT, space));
-  rc = vposer_forward_device(v, n, zi.d, LAT, oo.d, 63, jo.d, st, frame_base);
+  rc = vposer_forward_device(v, n, zi.d, LAT, oo.d, 63, jo.d, st, frame_base, false, nullptr, nullptr, 0u);
   if(rc) return rc;
   hipError_t e = oo.finish(st);
   if(e == hipSuccess) e = jo.finish(st);
   if(e == hipSuccess && space == SMPLPP_HOST) e = hipStreamSynchronize(st);
+  HIP_TRY(e);
+  return SMPLPP_OK;
+}
+
+// Development / test hook (not part of include/smplpp_hip.h): the decoded angles by the Jacobian kernel's VALUE-ONLY instantiation —
+// what the capture loops use to have theta25 early.  Host pointers.  tests/test_vposer_gpu.py compares it bit for bit with the `out`
+// of a call that also asks for the Jacobian.
+extern "C" int smplpp_debug_vposer_value(smplpp_vposer * v, int64_t n, int64_t frame_base, const float * z, float * out)
+{
+  if(!v || n <= 0 || frame_base < 0 || !z || !out) return fail(SMPLPP_ERR_INVALID, "smplpp_debug_vposer_value: bad argument");
+  HIP_TRY(hipSetDevice(v->device));
+  In<float> zi;
+  Out<float> oo;
+  HIP_TRY(zi.init(z, (size_t)n * LAT, SMPLPP_HOST, nullptr));
+  HIP_TRY(oo.init(out, (size_t)n * 63, SMPLPP_HOST));
+  int rc = vposer_forward_device(v, n, zi.d, LAT, oo.d, 63, nullptr, nullptr, frame_base, true, nullptr, nullptr, 0u);
+  if(rc) return rc;
+  hipError_t e = oo.finish(nullptr);
+  if(e == hipSuccess) e = hipStreamSynchronize(nullptr);
   HIP_TRY(e);
   return SMPLPP_OK;
 }

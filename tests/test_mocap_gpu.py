@@ -575,3 +575,30 @@ def test_body_stage_latent_layout_vs_oracle(smpl, oracle_synth, synth_model, dec
     # the driver call itself reproduces that trajectory
     res = bs.solve(markers, g0)
     assert np.array_equal(res["beta"], prev_beta) and np.isfinite(res["theta"]).all()
+
+
+def test_latent_capture_fit_does_not_depend_on_where_the_decoder_jacobian_is_made(smpl, decoders, monkeypatch):
+    """Round 5: with few chains the latent capture loop makes the NEXT iteration's decoder Jacobian on the side stream, behind the
+    solve's "configuration final" flag, while the main stream decodes the value alone (vposer_jac2_kernel<NF, true>), poses and
+    skins; the join in front of the evaluation covers the Jacobian (smplpp_ik::latent_split).  Same arithmetic, another schedule:
+    300 real capture frames (missing markers, a 0-valid gap, 32 warm-up iterations on frame 0) must give the single-stream bits, for
+    8 chains and for 3 (a shard that starts on an odd global index)."""
+    from smplpp_amd import mocap
+
+    gpu, _ = decoders
+    names, faces, pts, valid = _capture_full()
+    T, K = 300, len(names)
+    w = np.full((K, 3), 1 / 3, np.float32)
+    for R, base in ((8, 0), (3, 5)):
+        rng = np.random.default_rng(17)
+        g0 = np.zeros((R, 44), np.float32)
+        g0[:, 6:38] = rng.normal(0, 0.05, (R, 32))
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("SMPLPP_IK_LATENT_SPLIT", mode)
+            ms = mocap.MocapMotionSolver(smpl, faces, w, restarts=R, vposer=gpu, chain_base=base)
+            res[mode], frames = ms.solve(pts[:T], valid[:T], np.zeros(10, np.float32), g0)
+            assert len(frames) == T and np.isfinite(res[mode]).all()
+        same = (res["0"] == res["1"]).reshape(R, T, -1).all(axis=2)
+        assert same.all(), "R=%d: first differing frame per chain %s" % (R, [int(np.argmin(r)) if not r.all() else -1 for r in same])
+    monkeypatch.delenv("SMPLPP_IK_LATENT_SPLIT")

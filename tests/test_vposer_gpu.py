@@ -272,3 +272,24 @@ def test_latent_ik_trajectory_does_not_depend_on_the_shard(decoders, synth_model
         part = run(lo, hi)
         for a, b in zip(part, full):
             assert np.array_equal(a, b[lo:hi]), (lo, hi)
+
+
+def test_value_only_instantiation_decodes_the_jacobian_kernels_bits(decoders):
+    """vposer_jac2_kernel<NF, true> (round 5): the value path of the Jacobian kernel alone, used by the capture loops to have theta25
+    early while the Jacobian is made beside the pose step and the fused kernel.  The decoded angles must be the SAME BITS a call with
+    the Jacobian writes — in both instantiations (one and two frames per workgroup) and in shards."""
+    import ctypes as C
+
+    from smplpp_amd import _lib
+
+    gpu, _ = decoders
+    L = _lib.load()
+    L.smplpp_debug_vposer_value.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.smplpp_debug_vposer_value.restype = C.c_int
+    rng = np.random.default_rng(41)
+    for n, base in ((5, 0), (64, 0), (64, 7), (300, 0), (513, 128)):
+        z = rng.normal(0, 1.0, (n, 32)).astype(np.float32)
+        out, _jac = gpu.forward(z, want_jac=True, frame_base=base)
+        val = np.full((n, 21, 3), np.nan, np.float32)
+        assert L.smplpp_debug_vposer_value(gpu._h, n, base, z.ctypes.data_as(C.c_void_p), val.ctypes.data_as(C.c_void_p)) == 0, L.smplpp_last_error()
+        assert np.array_equal(val, out), (n, base, float(np.abs(val - out).max()))

@@ -13,11 +13,11 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ev = [int(r["Start_Timestamp"]) for r in rows if "ik_eval_kernel" in r["Kernel_Name"]]
 d = np.diff(np.array(ev[len(ev) // 2:])) / 1e3
 print("eval-to-eval period: median %.1f us, mean %.1f" % (np.median(d), d.mean()))
-for name in ("ik_eval_kernel", "ik_solve_kernel", "vposer_jac2_kernel", "proj_scan_kernel", "proj_finish_kernel", "pose_kernel", "skin_kernel", "ik_seq_frame", "streamOpsWait"):
+for name in ("ik_eval_kernel", "ik_solve_kernel", "vposer_jac2_kernel<1, true>", "vposer_jac2_kernel<1, false>", "proj_scan_kernel", "proj_finish_kernel", "pose_kernel", "skin_kernel", "ik_seq_frame", "streamOpsWait"):
     if not any(name in r["Kernel_Name"] for r in rows): continue
     v = np.array([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if name in r["Kernel_Name"]])
     v = v[len(v) // 2:]
-    print("%-20s median %.1f mean %.1f p90 %.1f" % (name, np.median(v), v.mean(), np.percentile(v, 90)))
+    print("%-30s median %.1f mean %.1f p90 %.1f" % (name, np.median(v), v.mean(), np.percentile(v, 90)))
 tail = rows[-40:-14]
 t0 = int(tail[0]["Start_Timestamp"])
 for r in tail:
