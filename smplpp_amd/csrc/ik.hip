@@ -3516,11 +3516,12 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
   int rc = SMPLPP_OK;
   smplpp_model * m = s->m;
   const int K = (int)s->K;
-  static PerDeviceOnce once_solve[4];
+  static PerDeviceOnce once_solve[5];
   HIP_TRY(lds_opt_in(once_solve[0], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false>), (int)SOLVE_LDS_MAX));
   HIP_TRY(lds_opt_in(once_solve[1], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<true>), (int)SOLVE_LDS_MAX));
   HIP_TRY(lds_opt_in(once_solve[2], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false, 11>), (int)SOLVE_LDS_MAX));
   HIP_TRY(lds_opt_in(once_solve[3], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false, 5>), (int)SOLVE_LDS_MAX));
+  HIP_TRY(lds_opt_in(once_solve[4], m->device, reinterpret_cast<const void *>(&ik_solve_kernel<false, 3>), (int)SOLVE_LDS_MAX));
   if(s->use_flags && (s->tick_fork > 0x7fff0000u || s->tick_join > 0x7fff0000u || s->tick_done > 0x7fff0000u))
   {
     // the hand-over flags carry iteration numbers compared with >=: start over long before they could wrap
@@ -3559,7 +3560,8 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
     // tiles of 16 the register-tiled factorisation covers (176 < m_dim + 1: all-LDS path).  5 (round 4): the motion solve of a capture
     // fit has 75 unknowns that can be free (+ the rhs row = 76 <= 80): 15 register tiles per thread instead of 21 in every rank-4
     // update of its 19 column steps, its own instantiation like 11 (one tile count per instantiation: DESIGN.md §3.3)
-    const int ntr_primal = (m_dim + 1 <= 80) ? 5 : ((m_dim + 1 <= 96 || m_dim + 1 > 176) ? 6 : 11);
+    // (and the same fit in the 44-d latent layout has 44 + 1 <= 48: 6 register tiles per thread in its 11 steps)
+    const int ntr_primal = (m_dim + 1 <= 48) ? 3 : (m_dim + 1 <= 80) ? 5 : ((m_dim + 1 <= 96 || m_dim + 1 > 176) ? 6 : 11);
     // theta is never bound, so the free set keeps at least theta_dim unknowns: with fewer residual rows than that every pass
     // (also every active-set pass of the QP) takes the dual form.  (Decided up here because the kernel's LDS plan depends on the
     // instantiation's tile count: ik_solve_kernel<true> carries the default, 6.)
@@ -3598,6 +3600,8 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
         SOLVE11_(11);
       else if(ntr == 5)
         SOLVE11_(5);
+      else if(ntr == 3)
+        SOLVE11_(3);
       else
         SOLVE_(false);
     }

@@ -1,6 +1,6 @@
 """Development aid: phase timestamps (100 MHz) of the primal ik_solve_kernel in the capture fit (needs a library built with
 -DSMPLPP_SOLVE_STAMPS: tools/build_variant.sh sstamps ik.hip -DSMPLPP_SOLVE_STAMPS ; SMPLPP_HIP_LIB=$PWD/ab/sstamps.so).
-usage: python tools/solve_stamps.py [R]"""
+usage: python tools/solve_stamps.py [R | ik] [latent]"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -33,7 +33,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "ik":  # configs[2]: the dual form (24 r
     sys.exit(0)
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 th0 = np.zeros((R, 25, 3), np.float32)
-ms = mocap.MocapMotionSolver(s, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R)
+vp = None
+if len(sys.argv) > 2 and sys.argv[2] == "latent":  # the 44-d VPoser layout: 44 free unknowns, the prior on the diagonal
+    from smplpp_amd.ik import VPoserDecoder
+    vp = VPoserDecoder(VPoserDecoder.synthetic_params(seed=3))
+    th0 = np.zeros((R, 44), np.float32); th0[:, 6:38] = np.random.default_rng(200).normal(0, 0.05, (R, 32))
+ms = mocap.MocapMotionSolver(s, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R, vposer=vp)
 ms.solve(pts, g["valid"], np.zeros(10, np.float32), th0, max_frames=40)
 L = _lib.load(); buf = (ctypes.c_ulonglong * (64 * 16))()
 L.smplpp_debug_solve_stamps.restype = ctypes.c_int
