@@ -769,6 +769,19 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     }
     lds_barrier(); // (global stores of this phase stay in flight: nothing reads them before the next full barrier)
     if(k_lo == k_begin) EVAL_STAMP(8);
+    // VPoser latent layout: this frame's d(vposer out)/dz [63][32] is requested HERE and dropped into LDS behind B2 — in front of
+    // the first row stores of the group: loads and stores retire through one counter, and a load consumed behind B3's stores waited
+    // for every one of them to be acknowledged (4 k cycles per group)
+    constexpr int VJ_PER = (63 * 32 + EVAL_NT - 1) / EVAL_NT;
+    // (the deep-tree plan's ring-vertex region is too small for it: there it goes into the vertex-normal derivatives' behind B3)
+    constexpr bool SVJ_EARLY = RCAP * RVS >= 63 * 32;
+    static_assert(SVJ_EARLY || NGN * NQ * 9 >= 63 * 32, "a place for the decoder Jacobian");
+    float vjr[VJ_PER];
+    if(Jl_out)
+    {
+#pragma unroll
+      for(int u = 0; u < VJ_PER; u++) vjr[u] = (tid + u * EVAL_NT < 63 * 32) ? vjac[f * 63 * 32 + tid + u * EVAL_NT] : 0.0f;
+    }
 
     if(tid < total) // B1: per ring vertex rest position, blended rotation, blended w
     {
@@ -990,6 +1003,13 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     }
     __syncthreads();
     if(k_lo == k_begin) EVAL_STAMP(10);
+    float * const svj = SVJ_EARLY ? lds + L_RV : &s_dvn[0][0]; // (nothing reads the ring-vertex records behind the barrier above; the next reader of svj is behind B3's)
+    if(SVJ_EARLY && Jl_out)
+    {
+#pragma unroll
+      for(int u = 0; u < VJ_PER; u++)
+        if(tid + u * EVAL_NT < 63 * 32) svj[tid + u * EVAL_NT] = vjr[u];
+    }
     // B3n (tasks with a normal term / offset, up to NGN to a group): the derivative of each of the three vertex normals,
     // one thread per (column, triangle vertex) — the chain n_f -> vn over ~6 adjacent faces is the long part of the
     // kernel for such tasks, and only nq of the 256 threads worked when a column's thread walked all three vertices
@@ -1086,17 +1106,27 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       const int Dl = TD44 + 2 * K + (nq - TD75);
       const int lcol = !Jl_out ? -1 : (q < 6 ? q : (q < 69 ? -1 : (q < TD75 ? TD44 - 6 + (q - 69) : TD44 + 2 * K + (q - TD75))));
       double * Lk = Jl_out ? Jl_out + ((f * K + k) * 4) * (int64_t)Dl : nullptr;
-      float nd = 0.f;
+      float nd = 0.f, rowv4[4];
       for(int x = 0; x < 3; x++)
       {
         float dpos = (w0 * dp[(0 * 3 + x) * NQ + q] + w1 * dp[(1 * 3 + x) * NQ + q]) + w2 * dp[(2 * 3 + x) * NQ + q];
         if(off > 0.0f) dpos += off * dn[x];
-        Jk[(int64_t)x * D + jcol] = (double)(wp * dpos);
-        if(lcol >= 0) Lk[(int64_t)x * Dl + lcol] = (double)(wp * dpos);
+        rowv4[x] = wp * dpos;
+        Jk[(int64_t)x * D + jcol] = (double)rowv4[x];
+        if(lcol >= 0) Lk[(int64_t)x * Dl + lcol] = (double)rowv4[x];
         nd += dn[x] * ta.tnrm[(tb + k) * 3 + x];
       }
-      Jk[(int64_t)3 * D + jcol] = (wn > 0.0f) ? (double)(wn * nd) : 0.0;
-      if(lcol >= 0) Lk[(int64_t)3 * Dl + lcol] = (wn > 0.0f) ? (double)(wn * nd) : 0.0;
+      rowv4[3] = (wn > 0.0f) ? wn * nd : 0.0f;
+      Jk[(int64_t)3 * D + jcol] = (double)rowv4[3];
+      if(lcol >= 0) Lk[(int64_t)3 * Dl + lcol] = (double)rowv4[3];
+      // ... and the 63 body-joint columns stay in LDS for the pull-back: the four row entries (exact floats) IN PLACE of the first four
+      // of the nine dp entries only this thread reads (column q of the task's own ring rows; every read of them is above)
+      if(Jl_out && q >= 6 && q < 69)
+      {
+        float * stg = lds + L_DP + (s_roff[k] * 3) * NQ + q;
+#pragma unroll
+        for(int x = 0; x < 4; x++) stg[x * NQ] = rowv4[x];
+      }
     }
     // phi columns of every task are zero except the task's own two (node.cpp:792, :834-839)
     for(int item = tid; item < (k_hi - k_lo) * 2 * K; item += EVAL_NT)
@@ -1117,6 +1147,55 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     }
     lds_barrier(); // (global stores of this phase stay in flight: nothing reads them before the next full barrier)
     if(k_lo == k_begin) EVAL_STAMP(12);
+    // ---- VPoser latent layout (node.cpp:761-772): the rows of this group over [pos 3 | root 3 | z 32 | aa22 3 | aa23 3 | phi | beta].
+    // Columns 0..5 and 69..74 of J75 pass through (B3 / B4 write them beside the direct rows); columns 6..68 (joints 1..21) are
+    // pulled back HERE through d(vposer out)/dz [63][32] of the frame, from the row entries B3 left in LDS: one (row, latent column)
+    // per thread, the 63 terms in FOUR interleaved partial sums.  (Rounds 2-4: behind all groups, from the rows read back out of
+    // global memory — a store -> load round trip through L2 and a second one for the decoder's Jacobian: 6.4 k cycles of a 50 k-cycle
+    // evaluation at 8 chains; as a kernel of its own 19 us per iteration.)
+    if(Jl_out)
+    {
+      if constexpr(!SVJ_EARLY)
+      {
+#pragma unroll
+        for(int u = 0; u < VJ_PER; u++)
+          if(tid + u * EVAL_NT < 63 * 32) svj[tid + u * EVAL_NT] = vjr[u];
+        lds_barrier();
+      }
+      const int bdim = optimize_beta ? NB : 0, Dl = TD44 + 2 * K + bdim;
+      // rows x latent columns in 16 x 16 tiles on the fp64 matrix pipe (v_mfma_f64_16x16x4_f64; lane l feeds A[l % 16][l / 16] and
+      // B[l / 16][l % 16], receives D[4 r + l / 16][l % 16] in register r: tools/micro/mfma_f64_layout.hip), one tile per wavefront:
+      // a lane converts 2 operands per 16 FMAs (one (row, column) per thread on the vector pipe converted 2 per FMA, and the
+      // conversions, not the FMAs, were its 4 k cycles per group)
+      typedef double d4 __attribute__((ext_vector_type(4)));
+      const int nrw = 4 * (k_hi - k_lo), ntile = ((nrw + 15) >> 4) * 2;
+      const int l = tid & 63, l16 = l & 15, lq = l >> 4;
+      for(int t = tid >> 6; t < ntile; t += EVAL_NT / 64) // (wave-uniform)
+      {
+        const int rt = t >> 1, ct = t & 1, row = 16 * rt + l16;
+        const bool rin = row < nrw;
+        const int kr = k_lo + ((rin ? row : 0) >> 2);
+        const float * jr = lds + L_DP + (s_roff[kr] * 3 + (row & 3)) * NQ + 6 + lq;
+        const float * vj = svj + lq * 32 + 16 * ct + l16;
+        float av[16], bv[16];
+#pragma unroll
+        for(int ks = 0; ks < 16; ks++)
+        {
+          const bool kin = 4 * ks + lq < 63;
+          av[ks] = (rin && kin) ? jr[4 * ks] : 0.0f;
+          bv[ks] = kin ? vj[4 * ks * 32] : 0.0f;
+        }
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for(int ks = 0; ks < 16; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[ks], (double)bv[ks], acc, 0, 0, 0);
+#pragma unroll
+        for(int r = 0; r < 4; r++)
+        {
+          const int orow = 16 * rt + 4 * r + lq;
+          if(orow < nrw) Jl_out[((f * K + k_lo) * 4 + orow) * (int64_t)Dl + 6 + 16 * ct + l16] = acc[r];
+        }
+      }
+    }
     if(tid < 2 * (k_hi - k_lo)) // B4: d/dphi through calcTriangleVertexWeights (vertices detached)
     {
       const int k = k_lo + tid / 2, c = tid % 2;
@@ -1178,53 +1257,6 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     }
     lds_barrier();
     if(k_lo == k_begin) EVAL_STAMP(13);
-  }
-  // ---- VPoser latent layout (node.cpp:761-772): the rows this workgroup wrote, over [pos 3 | root 3 | z 32 | aa22 3 | aa23 3 |
-  // phi | beta]: columns 0..5 and 69..74 of J75 pass through (written by B3 / B4 beside the direct rows), columns 6..68 (joints
-  // 1..21) are pulled back HERE through d(vposer out)/dz [63, 32] of the frame.  (A separate kernel for this cost the loop 19 us per iteration; here it is 768
-  // threads x 63 FMAs behind the rows they follow.)
-  if(Jl_out && k_end > k_begin)
-  {
-    __syncthreads(); // this workgroup's rows of J are complete (its stores have left the wavefronts)
-    const int bdim = optimize_beta ? NB : 0, Dl = TD44 + 2 * K + bdim, nrw = 4 * (k_end - k_begin);
-    float * svj = lds + L_DP;                                       // [63][32]  (the dp and ring-vertex regions are free now)
-    double * sJ = reinterpret_cast<double *>(lds + L_DP + 63 * 32); // [rows of a chunk][63]
-    static_assert((L_DP + 63 * 32) % 2 == 0, "sJ must be 8-byte aligned");
-    constexpr int LJ_CHUNK = ((L_END - L_DP - 63 * 32) / 2) / 63; // rows whose 63 pulled-back columns fit behind the decoder Jacobian
-    static_assert(LJ_CHUNK >= 4, "room for at least one task's rows");
-    const double * Jf = J_out + ((f * K + k_begin) * 4) * (int64_t)D;
-    double * Lf = Jl_out + ((f * K + k_begin) * 4) * (int64_t)Dl;
-    for(int i = tid; i < 63 * 32; i += EVAL_NT) svj[i] = vjac[f * 63 * 32 + i];
-    for(int r0 = 0; r0 < nrw; r0 += LJ_CHUNK)
-    {
-      const int nr = (nrw - r0 < LJ_CHUNK) ? nrw - r0 : LJ_CHUNK;
-      if(r0 > 0) __syncthreads(); // the previous chunk's readers are done with sJ
-      for(int i = tid; i < nr * 63; i += EVAL_NT) sJ[i] = Jf[(int64_t)(r0 + i / 63) * D + 6 + i % 63];
-      __syncthreads();
-      // the 32 latent columns: one (row, column) per thread, the 63 terms in FOUR interleaved partial sums.  (Round 5: as one loop
-      // over all Dl columns with a single 63-term chain per latent entry, the 32 latent columns of a row sat in one wavefront, which
-      // walked dependent fp64 FMAs while the others copied: 16 us of a 57 us evaluation at 64 chains, 4 us at 8.)
-      for(int item = tid; item < nr * 32; item += EVAL_NT)
-      {
-        const int rl = item >> 5, c = item & 31, r = r0 + rl;
-        const double * jr = sJ + rl * 63;
-        const float * vj = svj + c;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-        for(int q = 0; q < 60; q += 4)
-        {
-          s0 += jr[q] * (double)vj[q * 32];
-          s1 += jr[q + 1] * (double)vj[(q + 1) * 32];
-          s2 += jr[q + 2] * (double)vj[(q + 2) * 32];
-          s3 += jr[q + 3] * (double)vj[(q + 3) * 32];
-        }
-        s0 += jr[60] * (double)vj[60 * 32];
-        s1 += jr[61] * (double)vj[61 * 32];
-        s2 += jr[62] * (double)vj[62 * 32];
-        Lf[(int64_t)r * Dl + 6 + c] = (s0 + s1) + (s2 + s3);
-      }
-      // (the columns that pass through — [pos 3 | root 3], [aa22 | aa23], phi, beta — were written with the rows themselves: B3, B4)
-    }
   }
   EVAL_STAMP(7);
 }
