@@ -462,6 +462,18 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
   const int64_t f0 = (NF == VJ_GROUP) ? group * NF - frame_base : (int64_t)blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, l31 = l & 31, lh = l >> 5;
   VPJ_T(0);
+  // One frame per workgroup (few frames: every launch finds its XCD's L2 cold for the weights): what the later phases read from
+  // global memory FIRST is requested in the kernel's first round trip.  With every CU streaming (two frames per workgroup, 512
+  // frames) the same requests lengthened the kernel by 2 us of 43: that instantiation asks where it uses, as before.
+  constexpr bool EARLY = NF == 1;
+  // (the latents first: the wait for them must not stand behind everything requested below — loads retire in order)
+  float zreg = 0.0f;
+  if(EARLY && tid < NF * LAT)
+  {
+    int64_t f = f0 + tid / LAT; // (a workgroup's spare slot repeats a frame of the launch; never stored)
+    f = f < 0 ? 0 : (f < n ? f : n - 1);
+    zreg = z[f * z_stride + tid % LAT];
+  }
   // ---- layer 0 (+ LeakyReLU 0.01), rows tid and tid + 256 of every frame: the 64 weights of the two rows are loaded once
   float w0a[LAT], w0b[LAT];
 #pragma unroll
@@ -470,12 +482,51 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
     w0a[c] = w0t[c * HID + tid];
     w0b[c] = w0t[c * HID + tid + 256];
   }
+  // Everything the later phases read from global memory FIRST is requested here, in the kernel's first round trip: the biases of
+  // layers 0 and 1 and the first three k-steps of layer 1's weight stream.  (Round 5, phase stamps of the one-frame value path: each
+  // of these sat behind a barrier as a cold round trip of ~1.7 k cycles — the XCD's L2 does not keep the weights across launches —,
+  // six of them in a 35 k-cycle kernel.)
+  float bz0 = 0.0f, bz1 = 0.0f, bb0 = 0.0f, bb1 = 0.0f;
+  if constexpr(EARLY)
+  {
+    bz0 = b0[tid];
+    bz1 = b0[tid + 256];
+    bb0 = b1[tid];
+    bb1 = b1[tid + 256];
+  }
+  // (every workgroup starts its k loop elsewhere, so that the CUs do not ask the L2s for the same weight lines at the same
+  // instant: -2 % per latent IK iteration; by the GLOBAL group, so that sharding moves no bit)
+  const int rot = (int)(((unsigned long long)(NF == VJ_GROUP ? group : (frame_base + f0) / VJ_GROUP) * 5ull) & 31ull);
+  const uint8_t * const ap1 = w1h + (size_t)(4 * wave) * (32 * 2048) + l * 16;
+  const uint8_t * const bp1 = w0h + l * 16;
+  v4fv st[4][4][2], sb[4][2];
+  auto load_stage = [&](int sidx, int ks) {
+#pragma unroll
+    for(int t = 0; t < 4; t++)
+#pragma unroll
+      for(int p = 0; p < 2; p++) st[sidx][t][p] = *reinterpret_cast<const v4fv *>(ap1 + (size_t)t * (32 * 2048) + ks * 2048 + p * 1024);
+    if constexpr(!VO)
+    {
+      sb[sidx][0] = *reinterpret_cast<const v4fv *>(bp1 + ks * 2048);
+      sb[sidx][1] = *reinterpret_cast<const v4fv *>(bp1 + ks * 2048 + 1024);
+    }
+  };
+  if constexpr(EARLY)
+  {
+    load_stage(0, rot);
+    load_stage(1, (rot + 1) & 31);
+    load_stage(2, (rot + 2) & 31);
+  }
   if(tid >= 128 && tid < 144) reinterpret_cast<float *>(vl + L::RED + 64)[tid - 128] = 0.0f;
   if(tid < NF * LAT)
   {
-    int64_t f = f0 + tid / LAT; // (a workgroup's spare slot repeats a frame of the launch; never stored)
-    f = f < 0 ? 0 : (f < n ? f : n - 1);
-    reinterpret_cast<float *>(vl + L::SZ)[tid] = z[f * z_stride + tid % LAT];
+    if constexpr(!EARLY)
+    {
+      int64_t f = f0 + tid / LAT;
+      f = f < 0 ? 0 : (f < n ? f : n - 1);
+      zreg = z[f * z_stride + tid % LAT];
+    }
+    reinterpret_cast<float *>(vl + L::SZ)[tid] = zreg;
   }
   __syncthreads();
   float sA1[NF];
@@ -483,7 +534,7 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
   for(int q = 0; q < NF; q++)
   {
     const float * sz = reinterpret_cast<const float *>(vl + L::SZ) + q * LAT;
-    float h0 = b0[tid], h1 = b0[tid + 256];
+    float h0 = EARLY ? bz0 : b0[tid], h1 = EARLY ? bz1 : b0[tid + 256];
 #pragma unroll
     for(int c = 0; c < LAT; c++)
     {
@@ -506,6 +557,8 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
   }
   __syncthreads();
   VPJ_T(1);
+  v4fv st2[8][2]; // layer 2's weight ring
+  float bias2[16];
   // ---- layer 1: wavefront w owns the row tiles 4w .. 4w + 3 of EVERY frame; per k-step 8 W1 fragments and 2 W0 fragments from
   // L2 (prefetched three k-steps ahead), per frame a mask and 2 activation fragments from LDS, 12 MFMAs + 48 v_dot2
   {
@@ -527,23 +580,6 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
     // this lane's slice of the value tile: column l31 = frame (a zeroed slot of LDS for the columns beyond the frames)
     const unsigned char * const avp = (l31 < NF) ? vl + L::AF + l31 * VJ_AF + lh * 16 : vl + L::RED + 64;
     const int avs = (l31 < NF) ? 64 : 0;
-    const uint8_t * ap = w1h + (size_t)(4 * wave) * (32 * 2048) + l * 16;
-    const uint8_t * bp = w0h + l * 16;
-    v4fv st[4][4][2], sb[4][2];
-    auto load_stage = [&](int sidx, int ks) {
-#pragma unroll
-      for(int t = 0; t < 4; t++)
-#pragma unroll
-        for(int p = 0; p < 2; p++) st[sidx][t][p] = *reinterpret_cast<const v4fv *>(ap + (size_t)t * (32 * 2048) + ks * 2048 + p * 1024);
-      if constexpr(!VO)
-      {
-        sb[sidx][0] = *reinterpret_cast<const v4fv *>(bp + ks * 2048);
-        sb[sidx][1] = *reinterpret_cast<const v4fv *>(bp + ks * 2048 + 1024);
-      }
-    };
-    // (every workgroup starts its k loop elsewhere, so that the CUs do not ask the L2s for the same weight lines at the same
-    // instant: -2 % per latent IK iteration; by the GLOBAL group, so that sharding moves no bit)
-    const int rot = (int)(((unsigned long long)(NF == VJ_GROUP ? group : (frame_base + f0) / VJ_GROUP) * 5ull) & 31ull);
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     // LDS operands of a k-step (value tile pieces, one row mask per frame), read one k-step ahead into a second register set
     v4fv vah[2], val[2];
@@ -557,10 +593,13 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
         for(int q = 0; q < NF; q++) mk[slot][q] = *reinterpret_cast<const u4v *>(vl + L::MK + q * 1024 + ks * 32 + lh * 16);
       }
     };
-    load_stage(0, rot);
-    load_stage(1, (rot + 1) & 31);
-    load_stage(2, (rot + 2) & 31);
-    load_lds(0, rot);
+    if constexpr(!EARLY)
+    {
+      load_stage(0, rot);
+      load_stage(1, (rot + 1) & 31);
+      load_stage(2, (rot + 2) & 31);
+    }
+    load_lds(0, rot); // (weight stages 0..2 of the one-frame instantiation: requested at the kernel's start)
     for(int k4 = 0; k4 < 32; k4 += 4)
     {
 #pragma unroll
@@ -595,6 +634,24 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
       }
     }
     VPJ_T(2);
+    // layer 2's first seven k-steps of weights and its bias are requested HERE, in front of layer 1's epilogue (two barriers and the
+    // activation pass away from their first use)
+    const uint8_t * const ap2 = w2h + (size_t)wave * (32 * 2048) + l * 16;
+    auto load_ring2 = [&]() {
+#pragma unroll
+      for(int s3 = 0; s3 < 7; s3++)
+      {
+        st2[s3][0] = *reinterpret_cast<const v4fv *>(ap2 + s3 * 2048);
+        st2[s3][1] = *reinterpret_cast<const v4fv *>(ap2 + s3 * 2048 + 1024);
+      }
+#pragma unroll
+      for(int r = 0; r < 16; r++)
+      {
+        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        bias2[r] = b2[row < OUT6 ? row : 0];
+      }
+    };
+    if constexpr(EARLY) load_ring2();
     // the raw row sums of this wavefront's 128 rows sit in the lanes of column q < NF (frame q), rows (r & 3) + 8 (r >> 2) + 4 lh:
     // dropped into LDS as they are; bias, LeakyReLU and slope by all threads, two rows each, behind the barrier
     if(l31 < NF)
@@ -608,7 +665,11 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
     }
     __syncthreads();
     {
-      const float bb0 = b1[tid], bb1 = b1[tid + 256];
+      if constexpr(!EARLY)
+      {
+        bb0 = b1[tid];
+        bb1 = b1[tid + 256];
+      }
 #pragma unroll
       for(int q = 0; q < NF; q++)
       {
@@ -634,9 +695,12 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
       for(int g = 0; g < 4; g++)
       {
         const int tile = 4 * wave + t, row0 = 32 * tile + 8 * g + 4 * lh;
+        // (C10 lies in this epilogue's order — [tile][g][lh][column][4 rows] — so that a lane's four rows are ONE 16-byte load and a
+        // wavefront's request 1 KiB in a row: 16 loads per lane instead of 64 strided ones)
+        const v4fv c4 = *reinterpret_cast<const v4fv *>(c10 + ((((size_t)tile * 4 + g) * 2 + lh) * 32 + l31) * 4);
         float cc[4];
 #pragma unroll
-        for(int i = 0; i < 4; i++) cc[i] = 0.01f * c10[(row0 + i) * LAT + l31];
+        for(int i = 0; i < 4; i++) cc[i] = 0.01f * c4[i];
 #pragma unroll
         for(int q = 0; q < NF; q++)
         {
@@ -679,13 +743,23 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
     const unsigned char * const avp = (l31 < NF) ? vl + L::AF + l31 * VJ_AF + lh * 16 : vl + L::RED + 64;
     const int avs = (l31 < NF) ? 64 : 0;
     const uint8_t * ap = w2h + (size_t)wave * (32 * 2048) + l * 16;
-    // (nine MFMAs per k-step: three k-steps of lead are 900 cycles, less than an L2 round trip under load — seven here)
-    v4fv st[8][2];
-#pragma unroll
-    for(int s3 = 0; s3 < 7; s3++)
+    // (nine MFMAs per k-step: three k-steps of lead are 900 cycles, less than an L2 round trip under load — seven here; the first
+    // seven were requested behind the layer-1 loop)
+    auto & st = st2;
+    if constexpr(!EARLY)
     {
-      st[s3][0] = *reinterpret_cast<const v4fv *>(ap + s3 * 2048);
-      st[s3][1] = *reinterpret_cast<const v4fv *>(ap + s3 * 2048 + 1024);
+#pragma unroll
+      for(int s3 = 0; s3 < 7; s3++)
+      {
+        st2[s3][0] = *reinterpret_cast<const v4fv *>(ap + s3 * 2048);
+        st2[s3][1] = *reinterpret_cast<const v4fv *>(ap + s3 * 2048 + 1024);
+      }
+#pragma unroll
+      for(int r = 0; r < 16; r++)
+      {
+        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        bias2[r] = b2[row < OUT6 ? row : 0];
+      }
     }
     v4fv vah[2], val[2], dbh[2][NF], dbl[2][NF];
     auto load_lds = [&](int slot, int ks) {
@@ -733,7 +807,7 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
       for(int r = 0; r < 16; r++)
       {
         const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if(row < OUT6) so[row * 33 + 32] = vacc[r] * iv2 + b2[row];
+        if(row < OUT6) so[row * 33 + 32] = vacc[r] * iv2 + bias2[r];
       }
     }
 #pragma unroll
@@ -766,7 +840,12 @@ __global__ __launch_bounds__(256) void vposer_jac2_kernel(const float * __restri
     if constexpr(!VO)
       for(int i = 0; i < 3; i++) sj[j * 18 + i * 6 + dir] = jc[i];
   }
-  if constexpr(VO) return;
+  if constexpr(VO)
+  {
+    VPJ_T(5);
+    VPJ_T(6);
+    return;
+  }
   __syncthreads();
   VPJ_T(5);
   // one thread per (frame, joint, latent column): the six tangent entries of the column once for the joint's three output rows
@@ -972,7 +1051,8 @@ extern "C" int smplpp_vposer_create(int device, const float * w0, const float * 
         {
           double sum = 0.0;
           for(int k = 0; k < HID; k++) sum += (double)w1[(size_t)r * HID + k] * (double)w0[(size_t)k * LAT + cc];
-          c[(size_t)r * LAT + cc] = (float)sum;
+          // the layer-1 epilogue's order: row r = 32 tile + 8 g + 4 lh + i of column cc at [tile][g][lh][cc][i]
+          c[((((size_t)(r >> 5) * 4 + ((r >> 3) & 3)) * 2 + ((r >> 2) & 1)) * 32 + cc) * 4 + (r & 3)] = (float)sum;
         }
       e = hipMalloc((void **)&v->c10, sizeof(float) * c.size());
       if(e == hipSuccess) e = hipMemcpy(v->c10, c.data(), sizeof(float) * c.size(), hipMemcpyHostToDevice);

@@ -1,4 +1,4 @@
-"""Development aid: phase stamps of vposer_jac_kernel (variant built with -DVPJ_STAMP). usage: SMPLPP_HIP_LIB=$PWD/ab/vpj.so python tools/vpj_stamps.py [frames]"""
+"""Development aid: phase stamps of vposer_jac_kernel (variant built with -DVPJ_STAMP). usage: SMPLPP_HIP_LIB=$PWD/ab/vpj.so python tools/vpj_stamps.py [frames] [value]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,8 +7,14 @@ from smplpp_amd.ik import VPoserDecoder
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 vp = VPoserDecoder(VPoserDecoder.synthetic_params(seed=3), device=0)
 z = np.random.default_rng(0).normal(0, 0.3, (n, 32)).astype(np.float32)
-for _ in range(5): vp.forward(z, want_jac=True)
 L = _lib.load()
+if len(sys.argv) > 2 and sys.argv[2] == "value":  # the value-only instantiation (the capture loops' main stream)
+    out = np.zeros((n, 63), np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.smplpp_debug_vposer_value.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, fp, fp]
+    for _ in range(5): assert L.smplpp_debug_vposer_value(vp._h, n, 0, z.ctypes.data_as(fp), out.ctypes.data_as(fp)) == 0
+else:
+    for _ in range(5): vp.forward(z, want_jac=True)
 buf = (ctypes.c_ulonglong * 16)()
 L.smplpp_debug_vpj_stamps.restype = ctypes.c_int
 assert L.smplpp_debug_vpj_stamps(buf) == 0
