@@ -430,6 +430,18 @@ def main():
             "finite": bool(np.isfinite(thv).all()) if R > 0 else True,
             "workload": "same sequence with the 44-d VPoser layout the reference forces on capture solves (D = 126), synthetic decoder weights",
         }
+        if world == 1 and args.mocap_restarts >= 8:  # the latent layout's share of the 8-GPU split, like per_frame_us_at_8_chains above
+            T8 = min(nfr, 600)
+            msv8 = mocap.MocapMotionSolver(smpl, mfaces, np.full((Km, 3), 1 / 3, np.float32), restarts=8, vposer=vp)
+            gv8 = np.ascontiguousarray(gv0_all[:8])
+            msv8.solve(pts[:T8], mvalid[:T8], np.zeros(10, np.float32), gv8, max_frames=2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            msv8.solve(pts[:T8], mvalid[:T8], np.zeros(10, np.float32), gv8)
+            torch.cuda.synchronize()
+            t8 = time.perf_counter() - t1
+            mocap_leg["vposer_latent"]["per_frame_us_at_8_chains"] = t8 / (mocap.MocapMotionSolver.WARMUP_ITERS + T8 - 1) * 1e6
+            del msv8
 
         Kv = 6
         vlo, vhi = D.shard_range(args.vposer_frames, rank, world)

@@ -28,6 +28,8 @@ def test_bench_prints_one_contract_line():
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert d["ik"]["value"] > 0 and d["mocap"]["finite"] and d["vposer_ik"]["value"] > 0
+    # one GPU's share of the 8-GPU capture split, in both layouts
+    assert d["mocap"]["per_frame_us_at_8_chains"] > 0 and d["mocap"]["vposer_latent"]["per_frame_us_at_8_chains"] > 0
     assert 0 < rf["step_hbm_frac"] <= rf["hbm"]["frac"] and "frames_below_1e-3" in d["vposer_ik"]
     # burst-proof figure (a long run after the contract's region) and the operand-exact (bf16x3) figure in the same line
     cold = d["cold_start"]
