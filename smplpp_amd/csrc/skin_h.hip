@@ -570,6 +570,13 @@ static hipError_t launch_h(const smplpp_model * m, int64_t n, const float * thet
   int nbx = device_cus(m->device) / 8;
   if(nbx > per_xcd_items) nbx = per_xcd_items;
   if(nbx < 1) nbx = 1;
+  // ... and no more than the longest workgroup's item count needs: 56 items per XCD (256 frames) are two rounds on 32 workgroups and
+  // on 28 — the four CUs per XCD left alone are where the IK loops' side stream (face scan, finish kernel) runs beside this kernel,
+  // whose workgroups share a CU with nothing (1024 frames: 224 items, seven rounds on 32: unchanged)
+  {
+    const int rounds = (per_xcd_items + nbx - 1) / nbx;
+    nbx = (per_xcd_items + rounds - 1) / rounds;
+  }
   const bool wr = rest != nullptr;
   static PerDeviceOnce once[2];
   {
