@@ -23,6 +23,7 @@ Also reported in the same line:
                 library is absent — timed on this box's host cores on a bounded sample (rank 0, N = 1 only);
   final_gather_ms  (N > 1) the gather of the results to rank 0 (grouped point-to-point sends over RCCL), the path's only exchange;
   sustained     the same FK step over a 2000-launch run (steady clocks); exact_form: the step with operand-exact (bf16x3) arithmetic.
+  pipelined     the sustained run with its steps alternating between two model handles on two streams (a double-buffered caller).
 """
 from __future__ import annotations
 
@@ -218,6 +219,7 @@ def main():
                     help="extra untimed launches in front of the warm-up (profiling runs only: after idle the chip needs ~400 launches "
                          "= 25 ms of load to reach its steady clocks; the contract's region is never pre-rolled by default)")
     ap.add_argument("--sustained-steps", type=int, default=2000, help="launches of the long run reported as `sustained` (0 = skip)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-handle / two-stream leg reported as `pipelined`")
     ap.add_argument("--no-exact-form", action="store_true", help="skip the operand-exact (bf16x3) leg reported as `exact_form`")
     ap.add_argument("--profile-steps", type=int, default=40, help="launches of the separate loop that times the fused kernel with HIP events")
     ap.add_argument("--model", default=os.environ.get("SMPLPP_MODEL"),
@@ -493,6 +495,32 @@ def main():
                      "value": world * n * args.sustained_steps / sus_t, "unit": "FK evals/s",
                      "note": "the same step over a long run behind the contract's region: the steady-clock figure (after idle the chip "
                              "needs ~25 ms of load to ramp up; a 20-step region right after start-up is timed during that ramp)"}
+    # the same steps as a caller streaming batches would issue them: two model handles (each its own workspace and output buffer) on two
+    # streams, steps alternating between them, so that the pose step, launch, prologue and tail of one step run in the shadow of the
+    # other's fused kernel.  Same kernels, same outputs (tools/fk_two_streams.py compares them); reported BESIDE `value`, never as it.
+    pipelined = None
+    if args.sustained_steps > 0 and not args.no_pipelined:
+        smpl2 = SMPL()
+        smpl2.setDevice("cuda:%d" % local)
+        smpl2.init(model)
+        out2 = {"verts": torch.empty((n, V, 3), dtype=torch.float32, device="cuda")}
+        lanes = [(smpl, out, torch.cuda.Stream()), (smpl2, out2, torch.cuda.Stream())]
+
+        def piped(steps):
+            def work():
+                for i in range(steps):
+                    eng, o, st = lanes[i % 2]
+                    with torch.cuda.stream(st):
+                        eng.launch(beta, theta, want=("verts",), out=o)
+            return region(work)
+        piped(args.warmup + 100)
+        pt = piped(args.sustained_steps)["max"]
+        pipelined = {"launches": args.sustained_steps, "ms_per_step": pt / args.sustained_steps * 1e3,
+                     "value": world * n * args.sustained_steps / pt, "unit": "FK evals/s", "handles": 2, "streams": 2,
+                     "note": "the `sustained` run with its steps alternating between two model handles on two streams (a double-buffered "
+                             "caller): throughput of the same kernels when one step's pose / launch / tail hides behind the other's "
+                             "fused kernel; a step's latency is unchanged. Not the headline."}
+        del smpl2, out2, lanes
     # the same step with operand-exact arithmetic: the bf16x3 form carries every fp32 operand as three bf16 pieces (24
     # significant bits = fp32's own), so its products are the reference's fp32 products; fp32 accumulate in both forms
     exact = None
@@ -587,6 +615,8 @@ def main():
                                   "up; `value` is timed behind the IK legs (a chip that has been busy), `sustained` over a long run"}
     if sustained is not None:
         line["sustained"] = sustained
+    if pipelined is not None:
+        line["pipelined"] = pipelined
     if exact is not None:
         ex_ms = exact["t"] / exact["steps"] * 1e3
         line["exact_form"] = {

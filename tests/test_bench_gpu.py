@@ -34,6 +34,8 @@ def test_bench_prints_one_contract_line():
     # burst-proof figure (a long run after the contract's region) and the operand-exact (bf16x3) figure in the same line
     cold = d["cold_start"]
     assert cold["ms_per_step"] > 0 and cold["value"] > 1e4
+    pip_ = d["pipelined"]  # two handles on two streams: the same kernels, reported beside the headline
+    assert pip_["handles"] == 2 and pip_["value"] > 1e4 and pip_["ms_per_step"] > 0
     sus = d["sustained"]
     assert sus["launches"] >= 2000 and sus["ms_per_step"] > 0 and sus["value"] > 1e4
     ex = d["exact_form"]
