@@ -3094,6 +3094,7 @@ struct smplpp_ik
   bool dbg_sync = false, overlap_ok = true;
   int dbg_stop = 0;
   int64_t scan_blocks = 1536;
+  int scan_form = -1; // development switch SMPLPP_SCAN_FORM (read at creation): 0 forces the K > 8 instantiations of the face scan
   float * vbuf[2] = {nullptr, nullptr};
   int vcur = 0;
 };
@@ -3209,7 +3210,9 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
     // many short ones: configs[2] 89.2 -> 85.0 us per iteration in three alternating pairs on one box (6 chunks before); 512 frames
     // keep their three (2 and 3 measured level).  SMPLPP_SCAN_BLOCKS overrides.
     s->scan_blocks = (n >= 256 && n < 512) ? 2 * n : 1536;
+    if(n >= 512 && K <= 8 && (m->F + 767) / 768 <= 32) s->scan_blocks = n * ((m->F + 767) / 768); // (chunks of at most 768 faces: the 80-register instantiation, below)
     if((e = getenv("SMPLPP_SCAN_BLOCKS"))) s->scan_blocks = atoll(e);
+    if((e = getenv("SMPLPP_SCAN_FORM"))) s->scan_form = atoi(e);
     s->latent_split = vposer != nullptr && n <= 128 && s->dbg_stop == 0;
     if((e = getenv("SMPLPP_IK_LATENT_SPLIT"))) s->latent_split = vposer != nullptr && e[0] != '0';
   }
@@ -3660,7 +3663,13 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
 #define SCAN_(KPR, NBT_) proj_scan_kernel<KPR, NBT_><<<sg, dim3(256), 0, pst>>>(view_of(m), s->ta, s->verts, qpts, hint, m->F, K, chunks, s->skip, \
                                                                    s->list_cnt, s->list_d, s->list_f, dbg_stop)
       const bool small_chunk = (m->F + chunks - 1) / chunks <= 3 * 256; // (a thread then meets at most three faces)
-      if(K <= 4) SCAN_(2, CP_BATCH);
+      // K <= 8 with 512 frames and more (configs[4]): the K > 8 instantiation on chunks of at most 768 faces — 80 registers, six
+      // wavefronts per SIMD instead of three — is the faster one beside the decoder, whose workgroups wait for the scan's to drain
+      // (44.8 against 51.6 us, the latent loop -4 %); at 256 frames the queries-in-registers form stays ahead (81.5 against 84.2 us)
+      const bool many = s->scan_form < 0 ? (s->n >= 512 && small_chunk) : s->scan_form == 0;
+      if(K <= 8 && many && small_chunk) SCAN_(0, 3);
+      else if(K <= 8 && many) SCAN_(0, CP_BATCH);
+      else if(K <= 4) SCAN_(2, CP_BATCH);
       else if(K <= 8) SCAN_(4, CP_BATCH);
       else if(small_chunk) SCAN_(0, 3);
       else SCAN_(0, CP_BATCH);
