@@ -142,6 +142,49 @@ def test_latent_ik_eval_and_step(decoders, synth_model, oracle_synth, golden_ik_
     assert np.isfinite(e2).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [20, 25])
+def test_latent_jacobian_many_position_only_tasks_in_one_group(decoders, synth_model, oracle_synth, K):
+    """The pull-back through d(vposer)/dz runs inside the evaluation's task groups as 16 x 16 tiles on the fp64 matrix pipe, one per
+    wavefront (csrc/ik.hip, phase B behind B3).  A group of position-only tasks holds up to 25 of them: 100 rows = 7 row tiles x 2
+    column tiles, more than the workgroup has wavefronts — the tile loop's second pass.  Rows against the oracle's J75 pulled back
+    through the torch decoder's Jacobian (node.cpp:761-772), entry by entry."""
+    from oracle import cpu
+    from smplpp_amd.ik import IkSolver, reference_task_faces
+    from smplpp_amd.smpl import SMPL
+
+    gpu, ref = decoders
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(synth_model)
+    n = 2
+    rng = np.random.default_rng(80 + K)
+    faces = rng.choice(synth_model["face_indices"].shape[0], K, replace=False).astype(np.int64)
+    tp = rng.normal(0, 0.3, (n, K, 3)).astype(np.float32)
+    g44 = np.zeros((n, 44), np.float32)
+    g44[:, 3:6] = rng.normal(0, 0.05, (n, 3))
+    g44[:, 6:38] = rng.normal(0, 0.7, (n, 32))
+    g44[:, 38:] = rng.normal(0, 0.05, (n, 6))
+    sol = IkSolver(s, n, K, vposer=gpu)
+    sol.setTasks(face_idx=faces, target_pos=tp, phi_limit=np.zeros(K), normal_task_weight=np.zeros(K))
+    sol.setConfig(np.zeros((n, 10), np.float32), g44)
+    e, J = sol.eval()
+    assert J.shape == (n, 4 * K, 44 + 2 * K)
+    vout, vjac = ref.forward_with_jacobian(g44[:, 6:38])
+    import latent_oracle as LO
+
+    for f in range(n):
+        ts = cpu.TaskSet(faces, tp[f], phi_limit=np.zeros(K), normal_task_weight=np.zeros(K))
+        r = oracle_synth.ik_eval(np.zeros(10, np.float32), LO.splice(g44[f], vout[f]), ts)
+        J75 = r["J"]
+        Jl = np.concatenate([J75[:, :6], J75[:, 6:69] @ vjac[f].reshape(63, 32).astype(np.float64), J75[:, 69:75], J75[:, 75:]], axis=1)
+        assert np.abs(r["e"] - e[f]).max() < 5e-6
+        assert np.abs(Jl - J[f]).max() < 1e-3 * max(1.0, np.abs(Jl).max()), (K, f, np.abs(Jl - J[f]).max())
+        # the latent block on its own: every (row, latent column), not only the largest entries
+        blk = np.abs(Jl[:, 6:38] - J[f][:, 6:38])
+        assert blk.max() < 2e-4 * max(1.0, np.abs(Jl[:, 6:38]).max()), (K, f, blk.max())
+
+
 def test_latent_ik_config4_size_512_frames_50_iterations(decoders, synth_model, oracle_synth):
     """BASELINE.json configs[4] at its stated size on one GPU: 512 frames x 6 position targets x 50 iterations over the 44-d
     VPoser layout (decoder in the loop, prior of node.cpp:895-904).  Frames are re-synchronised with the CPU restatement at
