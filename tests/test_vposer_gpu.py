@@ -185,6 +185,57 @@ def test_latent_jacobian_many_position_only_tasks_in_one_group(decoders, synth_m
         assert blk.max() < 2e-4 * max(1.0, np.abs(Jl[:, 6:38]).max()), (K, f, blk.max())
 
 
+@pytest.mark.gpu
+def test_latent_jacobian_on_a_deep_tree(decoders, synth_model):
+    """A kinematic tree of 12 levels runs the evaluation in its second instantiation (EvalPlan<12, 64, 3>), whose ring-vertex region
+    is too small for the decoder's Jacobian: there the pull-back takes it from the vertex-normal derivatives' LDS behind B3 instead
+    (csrc/ik.hip SVJ_EARLY).  Position + normal rows with offsets, the latent rows against the oracle's J75 pulled back through
+    the torch decoder's Jacobian."""
+    from oracle import cpu
+    from smplpp_amd.ik import IkSolver
+    from smplpp_amd.smpl import SMPL
+    import latent_oracle as LO
+
+    gpu, ref = decoders
+    md = dict(synth_model)
+    kt = md["kinematic_tree"].copy()
+    kt[0] = np.array([-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 0, 12, 13, 14, 0, 16, 17, 18, 3, 20, 21, 22], np.int64)
+    kt[0, 0] = 4294967295
+    md["kinematic_tree"] = kt
+    s = SMPL()
+    s.setDevice("cuda:0")
+    s.init(md)
+    o = cpu.OracleModel(md)
+    rng = np.random.default_rng(93)
+    n, K = 2, 7
+    faces = rng.integers(0, 13776, (n, K))
+    tp = rng.normal(0, 0.4, (n, K, 3)).astype(np.float32)
+    tn = rng.normal(0, 1, (n, K, 3)).astype(np.float32)
+    tn /= np.linalg.norm(tn, axis=2, keepdims=True)
+    bary = rng.dirichlet(np.ones(3), (n, K)).astype(np.float32)
+    g44 = np.zeros((n, 44), np.float32)
+    g44[:, 3:6] = rng.normal(0, 0.05, (n, 3))
+    g44[:, 6:38] = rng.normal(0, 0.5, (n, 32))
+    g44[:, 38:] = rng.normal(0, 0.05, (n, 6))
+    sol = IkSolver(s, n, K, vposer=gpu)
+    sol.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, vertex_weights=bary, phi_limit=np.zeros((n, K)),
+                 normal_offset=np.full((n, K), 0.015), normal_task_weight=np.full((n, K), 1.0))
+    sol.setConfig(np.zeros((n, 10), np.float32), g44)
+    e, J = sol.eval()
+    vout, vjac = ref.forward_with_jacobian(g44[:, 6:38])
+    for f in range(n):
+        ts = cpu.TaskSet(faces[f], tp[f], tn[f], vertex_weights=bary[f], phi_limit=np.zeros(K), normal_offset=np.full(K, 0.015))
+        ts.normal_task_weight[:] = 1.0
+        r = o.ik_eval(np.zeros(10, np.float32), LO.splice(g44[f], vout[f]), ts)
+        J75 = r["J"]
+        Jl = np.concatenate([J75[:, :6], J75[:, 6:69] @ vjac[f].reshape(63, 32).astype(np.float64), J75[:, 69:75], J75[:, 75:]], axis=1)
+        de = np.abs(r["e"] - e[f]).reshape(K, 4)
+        assert de[:, :3].max() < 5e-6 and de[:, 3].max() < 1e-4
+        dJ = np.abs(Jl - J[f]).reshape(K, 4, -1)
+        scale = max(1.0, np.abs(Jl).max())
+        assert dJ[:, :3].max() < 1e-4 * scale and dJ[:, 3].max() < 6e-4 * scale, (f, dJ[:, :3].max(), dJ[:, 3].max())
+
+
 def test_latent_ik_config4_size_512_frames_50_iterations(decoders, synth_model, oracle_synth):
     """BASELINE.json configs[4] at its stated size on one GPU: 512 frames x 6 position targets x 50 iterations over the 44-d
     VPoser layout (decoder in the loop, prior of node.cpp:895-904).  Frames are re-synchronised with the CPU restatement at
