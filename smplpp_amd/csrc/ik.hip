@@ -319,6 +319,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   const int part = (int)(blockIdx.x % tsplit);
 
   const int tid = threadIdx.x;
+  if(dbg_stop == 19) return; // (timing experiments only: the launch itself — 5.7 us of the kernel's 24 at 8 chains, tools/eval_stops.sh)
   EVAL_STAMP(0);
   // this thread's entries of the chain-derivative table (dealt round-robin by smplpp_ik_create from the tree: the live ones fill the
   // first slots): joint | parent << 5 | column slot << 10 | row << 16 | (the column's joint is the joint itself) << 18; -1: none
