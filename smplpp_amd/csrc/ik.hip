@@ -3593,6 +3593,10 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
     // the packed system is sized for the unknowns that CAN be free: a pinned phi (zero limit, node.cpp:567,699) never is,
     // which leaves 75 of the 157 unknowns of a 41-marker motion solve and room for its 164 Jacobian rows in two chunks
     const int m_dim = D - ((!phi_live || s->phi_locked) ? 2 * K : 0);
+    // the box of node.cpp:911-929 bounds phi and d beta only: with every phi pinned and beta fixed (each motion-stage solve) no
+    // variable has a finite bound, the QP's optimum IS the LLT solution (x = 0 + 1.0 (x_llt - 0): the same bits), and the kernel
+    // takes its LLT exit instead of a ratio test and a bound check that cannot find anything (six barriers)
+    const int qp_k = (enable_qp && !((!phi_live || s->phi_locked) && beta_dim == 0)) ? 1 : 0;
     // tiles of 16 the register-tiled factorisation covers (176 < m_dim + 1: all-LDS path).  5 (round 4): the motion solve of a capture
     // fit has 75 unknowns that can be free (+ the rhs row = 76 <= 80): 15 register tiles per thread instead of 21 in every rank-4
     // update of its 19 column steps, its own instantiation like 11 (one tile count per instantiation: DESIGN.md §3.3)
@@ -3621,11 +3625,11 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
     unsigned * const done_flag = ahead ? s->sig + 64 : (unsigned *)nullptr;
     unsigned * const done_counter = ahead ? s->sig + 80 : (unsigned *)nullptr;
 #define SOLVE_(DO) ik_solve_kernel<DO><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
-    s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
+    s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, qp_k, \
     s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr, theta_record, \
     go ? s->sig : (unsigned *)nullptr, go ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork, done_flag, done_counter, s->tick_done)
 #define SOLVE11_(NTR_) ik_solve_kernel<false, NTR_><<<dim3((unsigned)s->n), dim3(256), solve_shmem, st>>>(                                              \
-    s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, enable_qp, \
+    s->ta, s->e, s->vp ? s->Jl : s->J, s->theta, s->beta, beside ? nullptr : s->pts, K, s->theta_dim, beta_dim, phi_live, qp_k, \
     s->vp ? 1 : 0, chunk_rows, s->skip, s->e2, s->status, s->sticky, s->xout, dbg_stop, m_dim, s->vp ? s->theta25 : (float *)nullptr, theta_record, \
     go ? s->sig : (unsigned *)nullptr, go ? s->sig + 16 : (unsigned *)nullptr, s->tick_fork, done_flag, done_counter, s->tick_done)
     {
