@@ -22,6 +22,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 
 struct smplpp_vposer;
@@ -3088,6 +3089,7 @@ struct smplpp_ik
   // kernel's value-only instantiation (<NF, true>: the same bits, 18 us), poses, skins and joins: the Jacobian is there when the
   // evaluation (which pulls its rows back through it) starts.  Same kernels' arithmetic, another schedule: bit-identical
   // (tests/test_mocap_gpu.py).  SMPLPP_IK_LATENT_SPLIT=0/1 (read at creation) overrides the n <= 128 rule.
+  double last_enqueue_us = 0.0; // host time of the last smplpp_ik_solve_sequence's enqueue loop
   bool latent_split = false;
   bool jac_ahead = false; // the decoder Jacobian of the CURRENT configuration is (being) made on the side stream; the join flag follows it
   // development switches, read ONCE at creation (never in the per-call path): SMPLPP_DEBUG_SYNC, SMPLPP_IK_DBG_STOP,
@@ -3797,6 +3799,14 @@ __global__ void ik_seq_frame_kernel(const float * __restrict__ tpos_t, const uin
   if(theta_prev_out && i < ntheta) theta_prev_out[i] = theta[i];
 }
 
+// Development hook (not part of include/smplpp_hip.h): host microseconds the last smplpp_ik_solve_sequence spent enqueueing.
+extern "C" int smplpp_debug_ik_enqueue_us(smplpp_ik * s, double * out)
+{
+  if(!s || !out) return fail(SMPLPP_ERR_INVALID, "smplpp_debug_ik_enqueue_us: bad argument");
+  *out = s->last_enqueue_us;
+  return SMPLPP_OK;
+}
+
 extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * target_pos, const uint8_t * valid, int warmup_iters,
                                         int iters_per_frame, int enable_qp, int64_t min_valid, float * theta_out, int space, void * stream)
 {
@@ -3820,6 +3830,7 @@ extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * 
   // kernel of its own between one frame's solve and the next frame's pose step
   ik_seq_frame_kernel<<<grid, 256, 0, st>>>(tp.d, vl.d, s->ta.tpos, s->ta.posw, nk, nullptr, nullptr, 0);
   HIP_TRY(hipGetLastError());
+  const auto enq_t0 = std::chrono::steady_clock::now();
   for(int64_t t = 0; t < T; t++)
   {
     const int iters = t == 0 ? warmup_iters : iters_per_frame;
@@ -3840,6 +3851,9 @@ extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * 
     if(rc) break;
   }
   const int jrc = ik_join(s, st);
+  // (development figure, smplpp_debug_ik_enqueue_us: what the HOST spent handing the T frames' launches to the two streams — when
+  // it approaches the frames' time on the GPU, the chains wait for the host)
+  s->last_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - enq_t0).count();
   if(rc) return rc;
   if(jrc) return jrc;
   HIP_TRY(th.finish(st));

@@ -28,4 +28,12 @@ torch.cuda.synchronize(); t = time.perf_counter()
 th, fr = ms.solve(pts, valid, np.zeros(10, np.float32), th0)
 torch.cuda.synchronize(); dt = time.perf_counter() - t
 iters = mocap.MocapMotionSolver.WARMUP_ITERS + T - 1
+import ctypes
+from smplpp_amd import _lib
+eq = ctypes.c_double(0.0)
+L = _lib.load()
+if hasattr(L, "smplpp_debug_ik_enqueue_us"):
+    L.smplpp_debug_ik_enqueue_us.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+    L.smplpp_debug_ik_enqueue_us(ms.solver._h, ctypes.byref(eq))
+    print("host enqueue: %.1f ms = %.1f us per iteration" % (eq.value / 1e3, eq.value / (mocap.MocapMotionSolver.WARMUP_ITERS + T - 1)))
 print(("latent layout, " if latent else "") + "R=%d: %d frames (%d iterations) in %.1f ms -> %.0f solved frames/s, %.1f us per iteration" % (R, T, iters, dt * 1e3, R * T / dt, dt / iters * 1e6))
