@@ -217,6 +217,19 @@ public:
     return theta;
   }
 
+  // the same loop for ONE capture shared by all n chains (restarts): targetPos [T,K,3], valid [T,K] (smplpp_ik_solve_sequence_shared)
+  std::vector<float> solveSequenceShared(int64_t T, const std::vector<float> & targetPos, const std::vector<uint8_t> & valid,
+                                         int warmupIters = 32, int itersPerFrame = 1, bool enableQp = true, int64_t minValid = 0)
+  {
+    if((int64_t)targetPos.size() != T * K_ * 3 || (int64_t)valid.size() != T * K_)
+      throw Exception("node", "solveSequenceShared: targetPos must be [T,K,3] and valid [T,K]");
+    std::vector<float> theta((size_t)(T * n_ * thetaDim()));
+    check(smplpp_ik_solve_sequence_shared(s_, T, targetPos.data(), valid.data(), warmupIters, itersPerFrame, enableQp ? 1 : 0, minValid,
+                                          theta.data(), SMPLPP_HOST, nullptr),
+          "node");
+    return theta;
+  }
+
   // per-task state after the last evaluation / re-projection (what the reference reads back through IkTask fields and
   // calcActualPos / calcActualNormal, node/node.cpp:803-814, 958, 997-998): faceIdx [n,K], vertexWeights [n,K,3],
   // tangents [n,K,3,2], actualPos [n,K,3], actualNormal [n,K,3]

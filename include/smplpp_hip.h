@@ -180,6 +180,12 @@ int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int optimize_beta
  * theta_out [T,n,theta_dim]. */
 int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * target_pos, const uint8_t * valid, int warmup_iters,
                              int iters_per_frame, int enable_qp, int64_t min_valid, float * theta_out, int space, void * stream);
+/* The same loop when every chain fits the SAME capture — the multi-restart fit the reference runs by hand (one sample_walk.c3d, many
+ * initial poses; node/node.cpp:1369-1407 once per restart): target_pos [T,K,3] and valid [T,K] are given once and handed to all n
+ * chains by the frame switch on the device; theta_out [T,n,theta_dim] as above. Results are those of smplpp_ik_solve_sequence with
+ * the targets repeated n times, bit for bit. */
+int smplpp_ik_solve_sequence_shared(smplpp_ik * s, int64_t T, const float * target_pos, const uint8_t * valid, int warmup_iters,
+                                    int iters_per_frame, int enable_qp, int64_t min_valid, float * theta_out, int space, void * stream);
 /* Vertices of the last forward inside the solver [n,V,3] (SMPL::getVertex after the loop's launch). */
 int smplpp_ik_get_vertices(smplpp_ik * s, float * verts, int space, void * stream);
 /* Outcome of the solves so far, per frame: bit 0 = the LAST solve failed with the reference's "LLT has numerical issue!"

@@ -80,6 +80,7 @@ def load():
         "smplpp_ik_eval": [vp, C.c_int, vp, vp, C.c_int, vp],
         "smplpp_ik_iterate": [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, C.c_int, vp],
         "smplpp_ik_solve_sequence": [vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, C.c_int, vp],
+        "smplpp_ik_solve_sequence_shared": [vp, C.c_int64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, C.c_int, vp],
         "smplpp_ik_get_vertices": [vp, vp, C.c_int, vp],
         "smplpp_ik_get_status": [vp, vp, C.c_int, vp],
         "smplpp_gather": [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp],

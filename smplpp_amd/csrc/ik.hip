@@ -2992,7 +2992,8 @@ __global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArra
                                                            const float * __restrict__ list_d, const int * __restrict__ list_f,
                                                            int * __restrict__ dbg, int tsplit, unsigned * __restrict__ sig_flag,
                                                            unsigned * __restrict__ sig_counter, unsigned sig_tick,
-                                                           const float * __restrict__ next_tpos, const uint8_t * __restrict__ next_valid)
+                                                           const float * __restrict__ next_tpos, const uint8_t * __restrict__ next_valid,
+                                                           int next_shared)
 {
   if(next_tpos) // the sequence driver's frame switch (SeqHook): the evaluation that read the old targets is over, the next one
                 // waits for this kernel; the solve running beside it takes its row list from ta.roww, not from posw
@@ -3002,12 +3003,12 @@ __global__ __launch_bounds__(256) void proj_finish_kernel(ModelView mv, TaskArra
     const int k = part * per_part + (int)threadIdx.x;
     if((int)threadIdx.x < per_part && k < K)
     {
-      const int64_t i = f * K + k;
-      const bool v = next_valid[i] != 0;
+      const int64_t i = f * K + k, j = next_shared ? (int64_t)k : i; // (shared: one capture for every chain, [K] per frame of the sequence)
+      const bool v = next_valid[j] != 0;
       // write-through like everything else a kernel of the other stream reads behind the flag (wg_signal drains this
       // workgroup's stores to its XCD's L2, not to memory; the next evaluation's workgroups sit on other XCDs)
       st_agent(&ta.posw[i], v ? 1.0f : 0.0f);
-      for(int x = 0; x < 3; x++) st_agent(&ta.tpos[i * 3 + x], v ? next_tpos[i * 3 + x] : 0.0f);
+      for(int x = 0; x < 3; x++) st_agent(&ta.tpos[i * 3 + x], v ? next_tpos[j * 3 + x] : 0.0f);
     }
   }
   proj_finish_body(mv, ta, verts_all, pts, F, K, skip, list_cnt, list_d, list_f, dbg, tsplit);
@@ -3545,6 +3546,7 @@ struct SeqHook
   float * theta_record = nullptr;        // [n][theta_dim]
   const float * next_tpos = nullptr;     // [n][K][3]
   const uint8_t * next_valid = nullptr;  // [n][K]
+  int shared = 0;                        // next_tpos / next_valid are [K] / [K][3]: one capture for every chain
 };
 
 // more_follows: the caller enqueues another iteration right behind this call's last one (the sequence driver, frame after frame)
@@ -3695,7 +3697,7 @@ static int ik_iterate_enqueue(smplpp_ik * s, int iters, int enable_qp, int optim
                             view_of(m), s->ta, (const float *)s->verts, qpts, m->F, K, (const int *)s->skip, s->list_cnt, s->list_d,
                             s->list_f, dbg ? dbg_buf : (int *)nullptr, fsplit, join_flag ? s->sig + 32 : (unsigned *)nullptr,
                             join_flag ? s->sig + 48 : (unsigned *)nullptr, s->tick_join, last ? hook->next_tpos : (const float *)nullptr,
-                            last ? hook->next_valid : (const uint8_t *)nullptr);
+                            last ? hook->next_valid : (const uint8_t *)nullptr, last ? hook->shared : 0);
       HIP_TRY(hipGetLastError());
       if(ahead)
       {
@@ -3787,14 +3789,15 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
 // `iters_per_frame` on every later one, warm-started; nothing returns to the host between frames.
 __global__ void ik_seq_frame_kernel(const float * __restrict__ tpos_t, const uint8_t * __restrict__ valid_t, float * __restrict__ tpos,
                                     float * __restrict__ posw, int64_t nk, const float * __restrict__ theta, float * __restrict__ theta_prev_out,
-                                    int64_t ntheta)
+                                    int64_t ntheta, int64_t shared_K)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(tpos_t && i < nk)
   {
-    const bool v = valid_t[i] != 0;
+    const int64_t j = shared_K > 0 ? i % shared_K : i; // (shared_K: the targets are one capture's [K] for every chain)
+    const bool v = valid_t[j] != 0;
     posw[i] = v ? 1.0f : 0.0f;
-    for(int x = 0; x < 3; x++) tpos[i * 3 + x] = v ? tpos_t[i * 3 + x] : 0.0f;
+    for(int x = 0; x < 3; x++) tpos[i * 3 + x] = v ? tpos_t[j * 3 + x] : 0.0f;
   }
   if(theta_prev_out && i < ntheta) theta_prev_out[i] = theta[i];
 }
@@ -3807,8 +3810,8 @@ extern "C" int smplpp_debug_ik_enqueue_us(smplpp_ik * s, double * out)
   return SMPLPP_OK;
 }
 
-extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * target_pos, const uint8_t * valid, int warmup_iters,
-                                        int iters_per_frame, int enable_qp, int64_t min_valid, float * theta_out, int space, void * stream)
+static int ik_solve_sequence_impl(smplpp_ik * s, int64_t T, const float * target_pos, const uint8_t * valid, bool shared, int warmup_iters,
+                                  int iters_per_frame, int enable_qp, int64_t min_valid, float * theta_out, int space, void * stream)
 {
   if(!s || T <= 0 || !target_pos || !valid || !theta_out || warmup_iters < 0 || iters_per_frame < 0)
     return fail(SMPLPP_ERR_INVALID, "smplpp_ik_solve_sequence: bad argument");
@@ -3817,18 +3820,19 @@ extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * 
   HIP_TRY(hipSetDevice(s->m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t nk = s->n * s->K, ntheta = s->n * s->theta_dim;
+  const int64_t tk = shared ? s->K : nk; // targets per frame of the sequence as the caller holds them
   In<float> tp;
   In<uint8_t> vl;
   Out<float> th;
-  HIP_TRY(tp.init(target_pos, (size_t)(T * nk * 3), space, st));
-  HIP_TRY(vl.init(valid, (size_t)(T * nk), space, st));
+  HIP_TRY(tp.init(target_pos, (size_t)(T * tk * 3), space, st));
+  HIP_TRY(vl.init(valid, (size_t)(T * tk), space, st));
   HIP_TRY(th.init(theta_out, (size_t)(T * ntheta), space));
   HIP_TRY(hipMemsetAsync(s->sticky, 0, sizeof(int) * s->n, st));
   const int64_t cnt = nk > ntheta ? nk : ntheta;
   const dim3 grid((unsigned)((cnt + 255) / 256));
   // frame 0's targets go in here; every later switch and every frame's record ride on the iterations themselves (SeqHook): no
   // kernel of its own between one frame's solve and the next frame's pose step
-  ik_seq_frame_kernel<<<grid, 256, 0, st>>>(tp.d, vl.d, s->ta.tpos, s->ta.posw, nk, nullptr, nullptr, 0);
+  ik_seq_frame_kernel<<<grid, 256, 0, st>>>(tp.d, vl.d, s->ta.tpos, s->ta.posw, nk, nullptr, nullptr, 0, shared ? s->K : 0);
   HIP_TRY(hipGetLastError());
   const auto enq_t0 = std::chrono::steady_clock::now();
   for(int64_t t = 0; t < T; t++)
@@ -3838,14 +3842,16 @@ extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * 
     hook.theta_record = th.d + t * ntheta;
     if(t + 1 < T)
     {
-      hook.next_tpos = tp.d + (t + 1) * nk * 3;
-      hook.next_valid = vl.d + (t + 1) * nk;
+      hook.next_tpos = tp.d + (t + 1) * tk * 3;
+      hook.next_valid = vl.d + (t + 1) * tk;
+      hook.shared = shared ? 1 : 0;
     }
     if(iters > 0)
       rc = ik_iterate_enqueue(s, iters, enable_qp, -1, min_valid, st, &hook, /*more_follows=*/t + 1 < T && iters_per_frame > 0);
     else // (no iteration to carry the hook)
     {
-      ik_seq_frame_kernel<<<grid, 256, 0, st>>>(hook.next_tpos, hook.next_valid, s->ta.tpos, s->ta.posw, nk, s->theta, hook.theta_record, ntheta);
+      ik_seq_frame_kernel<<<grid, 256, 0, st>>>(hook.next_tpos, hook.next_valid, s->ta.tpos, s->ta.posw, nk, s->theta, hook.theta_record, ntheta,
+                                                shared ? s->K : 0);
       HIP_TRY(hipGetLastError());
     }
     if(rc) break;
@@ -3864,6 +3870,22 @@ extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * 
     if((rc = ik_check_status(s, s->sticky))) return rc;
   }
   return SMPLPP_OK;
+}
+
+extern "C" int smplpp_ik_solve_sequence(smplpp_ik * s, int64_t T, const float * target_pos, const uint8_t * valid, int warmup_iters,
+                                        int iters_per_frame, int enable_qp, int64_t min_valid, float * theta_out, int space, void * stream)
+{
+  return ik_solve_sequence_impl(s, T, target_pos, valid, false, warmup_iters, iters_per_frame, enable_qp, min_valid, theta_out, space, stream);
+}
+
+// The same loop when every chain fits the SAME capture (the multi-restart fit: BASELINE configs[3], 64 restarts x one sequence):
+// target_pos [T,K,3] and valid [T,K] once, handed to all n chains by the frame switch on the device — the caller neither builds nor
+// uploads n copies (100 MB for 64 restarts of sample_walk.c3d; 83 ms of host work in front of 0.39 s of GPU work).
+extern "C" int smplpp_ik_solve_sequence_shared(smplpp_ik * s, int64_t T, const float * target_pos, const uint8_t * valid, int warmup_iters,
+                                               int iters_per_frame, int enable_qp, int64_t min_valid, float * theta_out, int space,
+                                               void * stream)
+{
+  return ik_solve_sequence_impl(s, T, target_pos, valid, true, warmup_iters, iters_per_frame, enable_qp, min_valid, theta_out, space, stream);
 }
 
 // Per-frame outcome of the solves so far: flags[f] bit 0 = the last solve of frame f failed ("LLT has numerical issue!",

@@ -247,14 +247,19 @@ class IkSolver:
 
     # ---- node.cpp:1369-1407 (+ :681-700): the frame loop of solveMocapMotion without a host round trip per frame
     def solveSequence(self, target_pos, valid, warmup_iters=32, iters_per_frame=1, enable_qp=True, min_valid=0):
-        """target_pos [T,n,K,3] float32, valid [T,n,K] bool -> theta [T,n,theta_dim] after every frame."""
+        """target_pos [T,n,K,3] float32, valid [T,n,K] bool -> theta [T,n,theta_dim] after every frame.  target_pos [T,K,3] with valid
+        [T,K]: ONE capture for all n chains (smplpp_ik_solve_sequence_shared: the targets are repeated on the device, not here)."""
         tp = np.ascontiguousarray(target_pos, np.float32)
         vl = np.ascontiguousarray(valid, np.uint8)
         T = tp.shape[0]
-        assert tp.shape == (T, self.n, self.K, 3) and vl.shape == (T, self.n, self.K)
+        shared = tp.ndim == 3
+        if shared:
+            assert tp.shape == (T, self.K, 3) and vl.shape == (T, self.K)
+        else:
+            assert tp.shape == (T, self.n, self.K, 3) and vl.shape == (T, self.n, self.K)
         out = np.empty((T, self.n, self.theta_dim), np.float32)
-        check(_lib.load().smplpp_ik_solve_sequence(self._h, T, _ptr(tp), _ptr(vl), int(warmup_iters), int(iters_per_frame),
-                                                   int(enable_qp), int(min_valid), _ptr(out), HOST, None))
+        fn = _lib.load().smplpp_ik_solve_sequence_shared if shared else _lib.load().smplpp_ik_solve_sequence
+        check(fn(self._h, T, _ptr(tp), _ptr(vl), int(warmup_iters), int(iters_per_frame), int(enable_qp), int(min_valid), _ptr(out), HOST, None))
         return out
 
     def getVertices(self):

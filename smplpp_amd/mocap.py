@@ -207,7 +207,18 @@ class MocapMotionSolver:
         R, K = self.R, self.K
         markers = np.asarray(markers, np.float32)
         valid = np.asarray(valid, bool)
-        if markers.ndim == 3:
+        shared = markers.ndim == 3  # one capture for every restart: its targets are repeated on the device, not here
+        if shared and not host_loop:
+            T = markers.shape[0]
+            frames = list(range(0, T, frame_interval))
+            if max_frames is not None:
+                frames = frames[:max_frames]
+            self.solver.setConfig(np.broadcast_to(np.asarray(beta, np.float32), (R, 10)).copy(), theta0)
+            v = np.ascontiguousarray(valid[frames])  # [Ts,K]
+            tp = np.where(v[..., None], markers[frames], 0.0).astype(np.float32)  # node.cpp:681-690
+            th = self.solver.solveSequence(tp, v, warmup_iters=self.WARMUP_ITERS, iters_per_frame=1, enable_qp=True, min_valid=K // 2)
+            return th.transpose(1, 0, 2), frames  # (a view: [R,Ts,theta_dim] without a second pass over the result)
+        if shared:
             markers = np.broadcast_to(markers, (R,) + markers.shape)
             valid = np.broadcast_to(valid, (R,) + valid.shape)
         T = markers.shape[1]

@@ -195,6 +195,32 @@ def test_device_frame_loop_matches_host_driven_loop(smpl, synth_model):
     assert np.abs(out[1][0][2, 6] - out[1][0][2, 5]).max() == 0
 
 
+def test_one_capture_shared_by_all_chains_equals_its_copies(smpl, synth_model):
+    """smplpp_ik_solve_sequence_shared: the multi-restart fit (every chain fits the same capture, BASELINE configs[3]) takes the
+    targets [T,K,3] once and repeats them on the device — the same trajectories, bit for bit, as smplpp_ik_solve_sequence fed R
+    copies; with missing markers and a skipped frame, in both layouts' direct form and through MocapMotionSolver's own switch."""
+    from smplpp_amd import mocap
+
+    T, K, R = 14, 41, 5
+    names, faces, hid, markers = _synthetic_sequence(smpl, synth_model, T, K, seed=5)
+    valid = np.ones((T, K), bool)
+    valid[3, :5] = False
+    valid[7, : K - 8] = False  # every chain skips frame 7
+    rng = np.random.default_rng(4)
+    theta0 = np.tile(hid[0], (R, 1, 1)) + rng.normal(0, 0.03, (R, 25, 3)).astype(np.float32)
+    ms = mocap.MocapMotionSolver(smpl, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R)
+    th_shared, frames = ms.solve(markers, valid, np.zeros(10, np.float32), theta0)  # [T,K,3]: the shared form
+    faces_shared = ms.solver.getTasks()["face_idx"]
+    ms2 = mocap.MocapMotionSolver(smpl, faces, np.full((K, 3), 1 / 3, np.float32), restarts=R)
+    th_copies, _ = ms2.solve(np.broadcast_to(markers, (R,) + markers.shape).copy(), np.broadcast_to(valid, (R,) + valid.shape).copy(),
+                             np.zeros(10, np.float32), theta0)
+    assert th_shared.shape == th_copies.shape == (R, T, 25 * 3) and np.isfinite(th_shared).all()
+    assert np.array_equal(np.ascontiguousarray(th_shared), th_copies)
+    assert np.array_equal(faces_shared, ms2.solver.getTasks()["face_idx"])
+    assert np.abs(th_shared[:, 7] - th_shared[:, 6]).max() == 0  # the skipped frame keeps the configuration
+    assert np.abs(th_shared[0] - th_shared[1]).max() > 0  # the chains differ (their initial poses do)
+
+
 def test_latent_capture_fit_device_loop_matches_host_loop(smpl, synth_model):
     """The reference forces VPoser + QP on in every capture solve (node.cpp:316-322): 44-d layout (D = 44 + 2K), decoder
     inside the loop, synthetic decoder weights. Device frame loop == host-driven loop, and the fit follows the markers."""
