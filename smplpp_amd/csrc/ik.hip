@@ -3090,7 +3090,7 @@ struct smplpp_ik
   // kernel's value-only instantiation (<NF, true>: the same bits, 18 us), poses, skins and joins: the Jacobian is there when the
   // evaluation (which pulls its rows back through it) starts.  Same kernels' arithmetic, another schedule: bit-identical
   // (tests/test_mocap_gpu.py).  SMPLPP_IK_LATENT_SPLIT=0/1 (read at creation) overrides the n <= 128 rule.
-  double last_enqueue_us = 0.0; // host time of the last smplpp_ik_solve_sequence's enqueue loop
+  double last_enqueue_us = 0.0; // host time of the last smplpp_ik_solve_sequence's / smplpp_ik_iterate's enqueue loop
   bool latent_split = false;
   bool jac_ahead = false; // the decoder Jacobian of the CURRENT configuration is (being) made on the side stream; the join flag follows it
   // development switches, read ONCE at creation (never in the per-call path): SMPLPP_DEBUG_SYNC, SMPLPP_IK_DBG_STOP,
@@ -3763,7 +3763,9 @@ extern "C" int smplpp_ik_iterate(smplpp_ik * s, int iters, int enable_qp, int op
   if(rc) return rc;
   HIP_TRY(hipSetDevice(s->m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const auto enq_t0 = std::chrono::steady_clock::now();
   rc = ik_iterate_enqueue(s, iters, enable_qp, optimize_beta_from, min_valid, st);
+  s->last_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - enq_t0).count();
   if(rc)
   {
     (void)ik_join(s, st);
@@ -3802,7 +3804,7 @@ __global__ void ik_seq_frame_kernel(const float * __restrict__ tpos_t, const uin
   if(theta_prev_out && i < ntheta) theta_prev_out[i] = theta[i];
 }
 
-// Development hook (not part of include/smplpp_hip.h): host microseconds the last smplpp_ik_solve_sequence spent enqueueing.
+// Development hook (not part of include/smplpp_hip.h): host microseconds the last smplpp_ik_solve_sequence / smplpp_ik_iterate spent enqueueing.
 extern "C" int smplpp_debug_ik_enqueue_us(smplpp_ik * s, double * out)
 {
   if(!s || !out) return fail(SMPLPP_ERR_INVALID, "smplpp_debug_ik_enqueue_us: bad argument");

@@ -26,3 +26,9 @@ for rep in range(5):
     torch.cuda.synchronize(); dt = time.perf_counter() - t
     best = min(best, dt)
 print("IK 256x6x50: %.1f us per iteration-batch, %.2f M it/s, converged %d" % (best / 50 * 1e6, n * 50 / best / 1e6, int((e2 < 1e-3).sum())))
+import ctypes
+from smplpp_amd import _lib
+_eq = ctypes.c_double(0.0); _L = _lib.load()
+_L.smplpp_debug_ik_enqueue_us.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+_L.smplpp_debug_ik_enqueue_us(sol._h, ctypes.byref(_eq))
+print("host enqueue of the last call: %.1f us per iteration" % (_eq.value / 50))

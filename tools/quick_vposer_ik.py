@@ -25,3 +25,9 @@ for rep in range(4):
     e2 = sol.iterate(iters)
     torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
 print("VPoser IK %dx%dx%d: %.1f us per iteration-batch, %.2f M it/s" % (n, K, iters, best / iters * 1e6, n * iters / best / 1e6))
+import ctypes
+from smplpp_amd import _lib
+_eq = ctypes.c_double(0.0); _L = _lib.load()
+_L.smplpp_debug_ik_enqueue_us.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+_L.smplpp_debug_ik_enqueue_us(sol._h, ctypes.byref(_eq))
+print("host enqueue of the last call: %.1f us per iteration" % (_eq.value / iters))
