@@ -399,7 +399,8 @@ def main():
         mocap_leg["chains_per_rank"] = D.shard_sizes(args.mocap_restarts, world)
         mocap_leg["scaling_note"] = ("a chain is serial along the sequence (node.cpp:1369-1407: one warm-started iteration per frame), so N GPUs "
                                      "shorten this leg only by the shorter per-frame period of 64 / N chains in lock step — its floor is %d "
-                                     "iterations x per_frame_us_at_8_chains, about 1.5x for 8x the hardware; the leg scales in RESTARTS "
+                                     "iterations x per_frame_us_at_8_chains (on this line: 64-chain period / 8-chain period, about 1.25x for 8x "
+                                     "the hardware); the leg scales in RESTARTS "
                                      "(more chains per GPU at the same period), not in time" % iters)
         # one GPU's share of the 8-GPU split (64 restarts -> 8 chains per GPU): the serial per-frame period the 8-GPU number is made of
         # (chains of a frame sequence cannot be parallelised along the sequence: node.cpp:1369-1407), measured here on ONE GPU
