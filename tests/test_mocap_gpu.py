@@ -395,6 +395,31 @@ def test_chain_bits_do_not_depend_on_how_many_chains_run_beside_it(smpl):
         assert same.all(), "chains %d..%d: first differing frame per chain %s" % (lo, hi, [int(np.argmin(r)) if not r.all() else -1 for r in same])
 
 
+def test_latent_chain_bits_do_not_depend_on_how_many_chains_run_beside_it(smpl, decoders):
+    """The same property in the 44-d VPoser layout the reference forces on capture solves — the configuration the 8-GPU split of
+    configs[3] actually runs.  Besides the task splits, the 8-chain shards and the 64-chain fit differ in how the decoder is
+    scheduled (its Jacobian one iteration ahead on the side stream in both, but one / eight workgroups' worth of frames per
+    launch) and the shards decode with frame_base = chain_base (the k-loop rotation is a function of the GLOBAL chain index)."""
+    from smplpp_amd import mocap
+
+    gpu, _ = decoders
+    names, faces, pts, valid = _capture_full()
+    T = 200
+    K = len(names)
+    R = 64
+    rng = np.random.default_rng(201)
+    g0 = np.zeros((R, 44), np.float32)
+    g0[:, 6:38] = rng.normal(0, 0.05, (R, 32))
+    w = np.full((K, 3), 1 / 3, np.float32)
+    full, frames = mocap.MocapMotionSolver(smpl, faces, w, restarts=R, vposer=gpu).solve(pts[:T], valid[:T], np.zeros(10, np.float32), g0)
+    assert np.isfinite(full).all() and len(frames) == T
+    for lo, hi in [(0, 8), (24, 32), (57, 64)]:  # (an odd chain_base: the shard starts inside a rotation group)
+        part, _ = mocap.MocapMotionSolver(smpl, faces, w, restarts=hi - lo, chain_base=lo, vposer=gpu).solve(
+            pts[:T], valid[:T], np.zeros(10, np.float32), np.ascontiguousarray(g0[lo:hi]))
+        same = (np.ascontiguousarray(part) == full[lo:hi]).reshape(hi - lo, T, -1).all(axis=2)
+        assert same.all(), "chains %d..%d: first differing frame per chain %s" % (lo, hi, [int(np.argmin(r)) if not r.all() else -1 for r in same])
+
+
 def test_real_capture_frames_step_by_step_vs_oracle(smpl, oracle_synth):
     """single IK steps on REAL capture frames (41 markers 15 mm off the skin, box QP on, phi pinned — the
     motion stage's settings, node.cpp:553-567, 699, 316-322) against oracle.ik_solve from the engine's own synchronised state
