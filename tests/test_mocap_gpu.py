@@ -221,6 +221,39 @@ def test_one_capture_shared_by_all_chains_equals_its_copies(smpl, synth_model):
     assert np.abs(th_shared[0] - th_shared[1]).max() > 0  # the chains differ (their initial poses do)
 
 
+def test_sequence_without_iterations_per_frame_records_the_warm_up_pose(smpl, synth_model):
+    """iters_per_frame = 0 (the reference before ikIter passes 30: node.cpp:1369-1407 advances the frame only then): frames after the
+    first change the targets but run no iteration — the frame switch is then a kernel of its own (ik_seq_frame_kernel), in the shared
+    and the per-chain form alike — and every recorded configuration is the warm-up's."""
+    from smplpp_amd.ik import IkSolver
+
+    T, K, R = 5, 41, 3
+    names, faces, hid, markers = _synthetic_sequence(smpl, synth_model, T, K, seed=6)
+    valid = np.ones((T, K), bool)
+    valid[2, :7] = False
+    rng = np.random.default_rng(5)
+    theta0 = np.tile(hid[0], (R, 1, 1)) + rng.normal(0, 0.03, (R, 25, 3)).astype(np.float32)
+    outs = []
+    for shared in (True, False):
+        sol = IkSolver(smpl, R, K)
+        sol.setTasks(face_idx=faces, vertex_weights=np.full((K, 3), 1 / 3, np.float32), phi_limit=np.zeros(K),
+                     normal_offset=np.full(K, 0.015), normal_task_weight=np.zeros(K))
+        sol.setConfig(np.zeros((R, 10), np.float32), theta0)
+        tp = np.where(valid[..., None], markers, 0.0).astype(np.float32)
+        if shared:
+            th = sol.solveSequence(tp, valid, warmup_iters=6, iters_per_frame=0, enable_qp=True, min_valid=K // 2)
+        else:
+            th = sol.solveSequence(np.ascontiguousarray(np.broadcast_to(tp[:, None], (T, R, K, 3))),
+                                   np.ascontiguousarray(np.broadcast_to(valid[:, None], (T, R, K))), warmup_iters=6, iters_per_frame=0,
+                                   enable_qp=True, min_valid=K // 2)
+        t = sol.getTasks()
+        outs.append((th, t["face_idx"]))
+        assert np.isfinite(th).all() and np.abs(th[0] - theta0.reshape(R, -1)).max() > 1e-4  # the warm-up moved
+        for f in range(1, T):
+            assert np.array_equal(th[f], th[0])  # no iteration, no motion
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_latent_capture_fit_device_loop_matches_host_loop(smpl, synth_model):
     """The reference forces VPoser + QP on in every capture solve (node.cpp:316-322): 44-d layout (D = 44 + 2K), decoder
     inside the loop, synthetic decoder weights. Device frame loop == host-driven loop, and the fit follows the markers."""
