@@ -75,7 +75,18 @@ __host__ __device__ inline void split_bf16x3(float x, uint16_t & p0, uint16_t & 
   p2 = bf16_rn_bits(r2);
 }
 
-// ---- fp16x2 form of the fused kernel (skin_h.hip, the default): every fp32 operand value x is carried as TWO fp16
+// ---- bf16x3 form, round 6 (skin_e.hip, "e" = exact: the form smplpp_fk runs by default).  Same pieces and fragment order as B3 /
+// A3 above; what changes is who holds what: the A fragments of a frame tile live in registers, the relative transforms of the tile
+// stay in LDS for a whole run of vertex groups, and only the basis streams — one 20 KiB image per k-step through a ring of four:
+//   B3e [ceil(V/64)][EB_KS][20 KiB]: pieces 0..17 = [vh 2][coordinate x 3][piece s 3][64 lanes][8 bf16] (as a k-step of B3), then
+//        2 KiB that make the image five 1 KiB DMA pieces per wavefront and carry the group's skinning tables:
+//        k-step 0: jofs[64][4] int32 (byte offset of the joint's 3x4 inside a frame's G' record) | jw[64][4] fp32
+//        k-step 1: winv[64] fp32 = 1 / sum_j W[v, j]            k-step 2 (models with 5..8 weights): jofs[64][4..7] | jw[64][4..7]
+constexpr int EB_KS = 14;
+constexpr int EB_IMG = 20 * 1024;
+constexpr int EB_TAB_OFF = 18 * 1024;
+
+// ---- fp16x2 form of the fused kernel (skin_h.hip; the IK loops' internal launches): every fp32 operand value x is carried as TWO fp16
 // pieces of s.x (s a power of two chosen per operand so that the pieces stay in fp16's normal range):
 // hi = fp16(s x), lo = fp16(s x - hi), |s x - hi - lo| <= 2^-22 |s x|; a product is the three MFMAs
 // lo.hi + hi.lo + hi.hi (the dropped lo.lo term is < 2^-22 |a||b|).  All arrays are in MFMA fragment order for
@@ -209,7 +220,9 @@ struct smplpp_model
   uint8_t * B2h = nullptr;     // bases + skinning weights as fp16x2 pieces in MFMA fragment order (layout above)
   float sB = 1.0f, sG = 1.0f;  // power-of-two scales of the basis operand and of the relative transforms (fp16 range)
   int * range_flag = nullptr;  // device words [RANGE_SLOTS]: bit 0 = a launch of the fp16x2 form met an operand outside fp16's range
-  char form = 'h';             // fused-kernel form (SMPLPP_SKIN, read once at model creation): h | b | p | v
+  uint8_t * B3e = nullptr;     // bases + skinning tables of the exact form, one 20 KiB image per (vertex group, k-step) (layout above, EB_*)
+  char form = 'e';             // fused-kernel form of smplpp_fk (SMPLPP_SKIN, read once at model creation): e | h | b | p | v
+  char form_ik = 'h';          // ... of the IK / VPoser loops' internal launches (h unless SMPLPP_SKIN chose one form for everything)
   uint8_t * wIdx = nullptr;    // [VGn*32][maxw]
   float * wVal = nullptr;      // [VGn*32][maxw]
   float * wSum = nullptr;      // [VGn*32]  sum_j W[v,j] in ascending j (the blended homogeneous w)

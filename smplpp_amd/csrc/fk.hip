@@ -244,6 +244,7 @@ hipError_t launch_skin_persistent(const smplpp_model * m, int64_t n, const float
                                   float * rest, hipStream_t st); // skin_p.hip (fp32 MFMA, one wave/SIMD, epilogue in the MFMA shadow)
 hipError_t launch_skin_bf16x3(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st); // skin_b.hip
 hipError_t launch_skin_f16x2(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st);  // skin_h.hip
+hipError_t launch_skin_exact(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st);  // skin_e.hip
 
 // Device-pointer FK (enqueue only).  Used by smplpp_fk and by the IK solver.
 // The pose step's arguments for the model's workspace (form h: with_ops adds the fused kernel's operand images; the other forms
@@ -278,26 +279,31 @@ PoseArgs fk_pose_args(smplpp_model * m, int64_t n, const float * beta, const flo
   return pa;
 }
 
+// Form of the fused kernel a launch runs (decided once per launch, here, for both halves of the forward pass).  m->form (from
+// SMPLPP_SKIN at model creation; default e) is what smplpp_fk runs: e (skin_e.hip) carries every fp32 operand exactly (bf16x3
+// pieces, six MFMA products per fp32 product, fp32 VALU skinning) — the reference's arithmetic; h (skin_h.hip): fp16x2 pieces,
+// 22-bit operands, skinning on the matrix pipe too; b (skin_b.hip): round 1's bf16x3 kernel; p (skin_p.hip): fp32 MFMA; v: the
+// first form.  The IK / VPoser loops' internal launches (range_slot RANGE_INTERNAL: intermediate iterates whose mesh feeds the
+// residual's few vertices and the re-projection's face scan) run m->form_ik: h unless SMPLPP_SKIN chose a form for everything.
+// p (32-bit output offsets) falls back to v for outputs of 2 GiB and more.
+static char launch_form(const smplpp_model * m, int64_t n, int range_slot)
+{
+  char form = range_slot == RANGE_INTERNAL ? m->form_ik : m->form;
+  if(form == 'p' && n * m->V * 12 >= 0x7fffff00LL) form = 'v';
+  return form;
+}
+
 // range_slot: which word of the model's range status a launch of the fp16x2 form reports to (common.h RANGE_*): enqueue-only user
 // launches, host-space user launches and the IK / VPoser loops' internal launches each have their own, so that an intermediate IK
 // iterate outside the range does not turn a later, in-range smplpp_fk into an error
-// The two halves of the forward pass, for callers that place them on different streams (the IK loops: the evaluation computes the
-// few vertices it reads itself, so only the re-projection's face scan needs the posed mesh and the fused kernel can run beside the
-// solve).  fk_pose_device: pose step (joints, relative transforms, the fused kernel's operand images when `with_ops`) into the
-// model's workspace; fk_skin_device: the fused kernel of the model's form from that workspace.  `theta` of the skin half is read
-// for the root translation only (theta[f, 0, :], stride 75).
-int fk_pose_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * joints, float * xforms44, float * poserot,
-                   hipStream_t st, int range_slot, bool with_ops)
+// Pose step of a launch of form `form`: joints, relative transforms and the fused kernel's operand images (when `with_ops`) into
+// the model's workspace.
+static int fk_pose_device(smplpp_model * m, char form, int64_t n, const float * beta, const float * theta, float * joints, float * xforms44,
+                          float * poserot, hipStream_t st, int range_slot, bool with_ops)
 {
   Workspace & ws = m->ws;
-  // Form of the fused kernel (m->form, from SMPLPP_SKIN at model creation): h (default,
-  // skin_h.hip): fp16x2 operand pieces on the f16 matrix pipe, skinning on the matrix pipe too; b (skin_b.hip): bf16x3
-  // pieces, VALU skinning in MFMA shadows; p (skin_p.hip): exact fp32 MFMA; v (skin_kernel above): the first form.
-  // b needs <= 8 weights per vertex; p (32-bit output offsets) falls back to v for outputs of 2 GiB and more.
-  char form = m->form; // (model creation already turned b / p into v for models with more than 8 weights per vertex)
-  if(form == 'p' && n * m->V * 12 >= 0x7fffff00LL) form = 'v';
   const int64_t n64 = ((n + 63) / 64) * 64;
-  HIP_TRY(ws.Gp.reserve(sizeof(float) * (size_t)n64 * NJ * 12)); // b / p stage whole frame tiles of G' (padding never stored)
+  HIP_TRY(ws.Gp.reserve(sizeof(float) * (size_t)n64 * NJ * 12)); // e / b / p stage whole frame tiles of G' (padding never stored)
   if(form == 'h')
   {
     HIP_TRY(ws.A2h.reserve((size_t)(n64 / 64) * HB_KS * HB_A_BYTES));
@@ -306,11 +312,11 @@ int fk_pose_device(smplpp_model * m, int64_t n, const float * beta, const float 
     pa.range_flag = m->range_flag + range_slot;
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(pa);
   }
-  else if(form == 'b')
+  else if(form == 'e' || form == 'b')
   {
     HIP_TRY(ws.A3.reserve((size_t)(n64 / 64) * BB_KS * BB_A_BYTES));
     PoseArgs pa = fk_pose_args(m, n, beta, theta, joints, poserot, xforms44, false);
-    pa.A3 = ws.A3.as<uint16_t>();
+    pa.A3 = with_ops ? ws.A3.as<uint16_t>() : nullptr;
     pa.gscale = 1.0f;
     pa.range_flag = nullptr;
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(pa);
@@ -337,11 +343,11 @@ int fk_pose_device(smplpp_model * m, int64_t n, const float * beta, const float 
   return SMPLPP_OK;
 }
 
-int fk_skin_device(smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st)
+// The fused kernel of form `form` from the workspace the pose step filled.  `theta` is read for the root translation only
+// (theta[f, 0, :], stride 75).
+static int fk_skin_device(smplpp_model * m, char form, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st)
 {
   Workspace & ws = m->ws;
-  char form = m->form;
-  if(form == 'p' && n * m->V * 12 >= 0x7fffff00LL) form = 'v';
   if(verts || rest)
   {
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -359,7 +365,9 @@ int fk_skin_device(smplpp_model * m, int64_t n, const float * theta, float * ver
       m->prof_events.push_back(e1);
       HIP_TRY(hipEventRecord(e0, st));
     }
-    if(form == 'h')
+    if(form == 'e')
+      HIP_TRY(launch_skin_exact(m, n, theta, verts, rest, st));
+    else if(form == 'h')
       HIP_TRY(launch_skin_f16x2(m, n, theta, verts, rest, st));
     else if(form == 'b')
       HIP_TRY(launch_skin_bf16x3(m, n, theta, verts, rest, st));
@@ -377,9 +385,10 @@ int fk_skin_device(smplpp_model * m, int64_t n, const float * theta, float * ver
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
               float * xforms44, float * rest, float * poserot, hipStream_t st, int range_slot)
 {
-  int rc = fk_pose_device(m, n, beta, theta, joints, xforms44, poserot, st, range_slot, verts || rest);
+  const char form = launch_form(m, n, range_slot);
+  int rc = fk_pose_device(m, form, n, beta, theta, joints, xforms44, poserot, st, range_slot, verts || rest);
   if(rc) return rc;
-  return fk_skin_device(m, n, theta, verts, rest, st);
+  return fk_skin_device(m, form, n, theta, verts, rest, st);
 }
 } // namespace smplpp_hip
 

@@ -3911,7 +3911,7 @@ extern "C" int smplpp_ik_get_status(smplpp_ik * s, int32_t * flags, int space, v
   // set_config (one word per model — which frame is not recorded, so every frame of the batch carries it; such a frame's vertices
   // are not finite and its solve then fails on its own)
   int internal = 0;
-  if(s->m->range_flag && s->m->form == 'h') HIP_TRY(hipMemcpy(&internal, s->m->range_flag + RANGE_INTERNAL, sizeof(int), hipMemcpyDeviceToHost));
+  if(s->m->range_flag && s->m->form_ik == 'h') HIP_TRY(hipMemcpy(&internal, s->m->range_flag + RANGE_INTERNAL, sizeof(int), hipMemcpyDeviceToHost));
   std::vector<int32_t> h((size_t)s->n);
   for(int64_t f = 0; f < s->n; f++)
     h[(size_t)f] = (a[(size_t)f] == 1 ? 1 : 0) | ((b[(size_t)f] & 1) ? 2 : 0) | (b[(size_t)f] & 4) | ((internal & 1) ? 8 : 0);

@@ -93,6 +93,48 @@ __global__ void relayout_basis_bf16x3_kernel(const float * __restrict__ Bm, int6
   }
 }
 
+// B3e <- Bm as bf16x3 pieces in MFMA fragment order, one 20 KiB image per (vertex group, k-step) (layout: common.h, EB_*).  One
+// thread per (vertex group, k-step, vertex half and coordinate, lane): 8 consecutive k of one column, its three pieces.
+__global__ void relayout_basis_exact_kernel(const float * __restrict__ Bm, int64_t ldB, int64_t V, int64_t nvg, uint8_t * __restrict__ B3e)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // ((vg * KS + ks) * 6 + vh * 3 + x) * 64 + lane
+  if(i >= nvg * EB_KS * 6 * 64) return;
+  const int lane = (int)(i % 64), h = lane >> 5, r = lane & 31;
+  const int vx = (int)((i / 64) % 6), vh = vx / 3, x = vx % 3;
+  const int ks = (int)((i / (64 * 6)) % EB_KS);
+  const int64_t vg = i / (64 * 6 * EB_KS);
+  const int64_t v = vg * 64 + vh * 32 + r;
+  uint16_t pc[3][8];
+  for(int j = 0; j < 8; j++)
+  {
+    const int k = ks * 16 + 8 * h + j;
+    const float val = (v < V && k < KP) ? Bm[(int64_t)k * ldB + bcol(v, x)] : 0.0f;
+    split_bf16x3(val, pc[0][j], pc[1][j], pc[2][j]);
+  }
+  for(int s = 0; s < 3; s++)
+  {
+    uint16_t * dst = reinterpret_cast<uint16_t *>(B3e + (vg * EB_KS + ks) * (int64_t)EB_IMG) + ((int64_t)(vx * 3 + s) * 64 + lane) * 8;
+    for(int j = 0; j < 8; j++) dst[j] = pc[s][j];
+  }
+}
+// the skinning tables of a vertex group, in the 2 KiB behind the fragments of its first k-steps (one thread per vertex slot)
+__global__ void skin_tables_exact_kernel(const uint8_t * __restrict__ wIdx, const float * __restrict__ wVal, const float * __restrict__ wSum,
+                                         int maxw, int64_t V, int64_t nvg, uint8_t * __restrict__ B3e)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= nvg * 64) return;
+  const int64_t vg = i / 64, v = i;
+  const int c = (int)(i % 64);
+  uint8_t * g = B3e + vg * (int64_t)(EB_KS * EB_IMG);
+  for(int q = 0; q < maxw && q < 8; q++)
+  {
+    uint8_t * tab = g + (q < 4 ? 0 : 2) * EB_IMG + EB_TAB_OFF;
+    reinterpret_cast<int32_t *>(tab)[c * 4 + (q & 3)] = v < V ? (int32_t)wIdx[v * maxw + q] * 48 : 0;
+    reinterpret_cast<float *>(tab + 1024)[c * 4 + (q & 3)] = v < V ? wVal[v * maxw + q] : 0.0f;
+  }
+  reinterpret_cast<float *>(g + EB_IMG + EB_TAB_OFF)[c] = v < V ? 1.0f / wSum[v] : 0.0f;
+}
+
 // B2h <- Bm and the skinning weights as fp16x2 pieces in MFMA fragment order (layout: common.h).  One thread per 16-byte
 // chunk pair (hi, lo): slots 0..13: ((vg * 15 + ks) * 6 + vh * 3 + x) * 64 + lane; slot 14: weights, cw, padding.
 // hperm [nvg * 64]: the vertex in each slot of each group (-1: none), gflags [nvg]: the group's k-step flags (common.h, HB_PERM_OFF).
@@ -244,7 +286,7 @@ extern "C" int smplpp_model_destroy(smplpp_model * m)
   (void)hipSetDevice(m->device);
   for(hipEvent_t e : m->prof_events) (void)hipEventDestroy(e);
   m->prof_events.clear();
-  void * ptrs[] = {m->Bm, m->B3, m->B2h, m->range_flag, m->lvl, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->JSp, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm, m->faceRing, m->faceMap, m->anc};
+  void * ptrs[] = {m->Bm, m->B3, m->B3e, m->B2h, m->range_flag, m->lvl, m->wIdx, m->wVal, m->wSum, m->J0, m->JS, m->JSp, m->parent, m->faces, m->adjOff, m->adjFace, m->Wdense, m->Pvm, m->Svm, m->faceRing, m->faceMap, m->anc};
   for(void * p : ptrs)
     if(p) (void)hipFree(p);
   Workspace & w = m->ws;
@@ -298,13 +340,21 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   } while(0)
 
   // --- blend bases -> Bm, regressor fold (device side; the raw arrays are only needed transiently) ---
-  // Form of the fused kernel: read once, here (SMPLPP_SKIN = h | b | p | v; default h).  Only the operand layouts the
-  // chosen form needs stay resident.
+  // Form of the fused kernel: read once, here.  Default: smplpp_fk runs e (skin_e.hip: fp32-exact operands, the reference's
+  // arithmetic) and the IK / VPoser loops' internal launches h (skin_h.hip: fp16x2 operands, 3e-7 m); SMPLPP_SKIN = e | h | b | p | v
+  // puts every launch on that form.  Only the operand layouts the chosen forms need stay resident.
   {
     const char * form_env = getenv("SMPLPP_SKIN");
-    const char f = form_env ? form_env[0] : 'h';
-    m->form = (f == 'b' || f == 'p' || f == 'v') ? f : 'h';
+    const char f = form_env ? form_env[0] : 0;
+    if(f == 'e' || f == 'h' || f == 'b' || f == 'p' || f == 'v')
+      m->form = m->form_ik = f;
+    else
+    {
+      m->form = 'e';
+      m->form_ik = 'h';
+    }
   }
+  auto uses = [&](char f) { return m->form == f || m->form_ik == f; };
   // (the vertex-major uploads are owned by the handle from the start, so a failure below frees them with it)
   TRY_OR_FREE(upload(&m->Pvm, P, (size_t)V * 3 * NP)); // kept: vertex-major copies serve the sparse IK Jacobian (contiguous 2.5 KB per vertex)
   TRY_OR_FREE(upload(&m->Svm, S, (size_t)V * 3 * NB));
@@ -339,9 +389,13 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   m->VGPn = (V + 63) / 64;
   // the split-operand kernels address their basis images with 32-bit buffer offsets: a mesh whose image would reach 2 GiB
   // (more than ~745k vertices for h, ~410k for b) takes the first form (64-bit addressing) from creation on
-  if(m->form == 'h' && (int64_t)m->VGPn * HB_SLOTS * HB_IMG > 0x7fffff00LL) m->form = 'v';
-  if(m->form == 'b' && (int64_t)m->VGPn * BB_KS * BB_B_BYTES > 0x7fffff00LL) m->form = 'v';
-  if(m->form == 'b')
+  for(char * f : {&m->form, &m->form_ik})
+  {
+    if(*f == 'h' && (int64_t)m->VGPn * HB_SLOTS * HB_IMG > 0x7fffff00LL) *f = 'v';
+    if(*f == 'e' && (int64_t)m->VGPn * EB_KS * EB_IMG > 0x7fffff00LL) *f = 'v';
+    if(*f == 'b' && (int64_t)m->VGPn * BB_KS * BB_B_BYTES > 0x7fffff00LL) *f = 'v';
+  }
+  if(uses('b') || uses('e')) // (e falls back to b for models with 5..8 weights per vertex: decided below, once they are counted)
   {
     TRY_TMP(hipMalloc((void **)&m->B3, (size_t)m->VGPn * BB_KS * BB_B_BYTES));
     const int64_t cnt = m->VGPn * BB_KS * 6 * 64;
@@ -391,7 +445,24 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   TRY_OR_FREE(upload(&m->wVal, hVal.data(), hVal.size()));
   TRY_OR_FREE(upload(&m->wSum, hSum.data(), hSum.size()));
   TRY_OR_FREE(upload(&m->Wdense, W, (size_t)V * NJ));
-  if(m->form == 'h')
+  // e keeps at most 4 weights per vertex in registers, b and p at most 8: a model with more takes the next form from here on
+  // (decided once, so that the layouts kept below are the ones the launches will read)
+  for(char * f : {&m->form, &m->form_ik})
+  {
+    if(*f == 'e' && m->maxw > 4) *f = 'b';
+    if(m->maxw > 8 && (*f == 'b' || *f == 'p')) *f = 'v';
+  }
+  if(uses('e'))
+  {
+    TRY_OR_FREE(hipMalloc((void **)&m->B3e, (size_t)m->VGPn * EB_KS * EB_IMG));
+    TRY_OR_FREE(hipMemset(m->B3e, 0, (size_t)m->VGPn * EB_KS * EB_IMG));
+    const int64_t cnt = m->VGPn * EB_KS * 6 * 64;
+    relayout_basis_exact_kernel<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256)>>>(m->Bm, m->ldB, V, m->VGPn, m->B3e);
+    skin_tables_exact_kernel<<<dim3((unsigned)((m->VGPn * 64 + 255) / 256)), dim3(256)>>>(m->wIdx, m->wVal, m->wSum, m->maxw, V, m->VGPn, m->B3e);
+    TRY_OR_FREE(hipGetLastError());
+    TRY_OR_FREE(hipDeviceSynchronize());
+  }
+  if(uses('h'))
   {
     // fp16x2 operands: power-of-two scales that put the largest basis entry / a generous bound of the relative
     // translations (16 x the template's extent) just under fp16's range, so that both pieces of every value that matters
@@ -484,15 +555,12 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
     dFlags.release();
     TRY_OR_FREE(le);
   }
-  // b and p keep at most 8 weights per vertex in registers: a model with more takes the first form from here on (decided
-  // once, so that the layouts kept below are the ones the launches will read)
-  if(m->maxw > 8 && (m->form == 'b' || m->form == 'p')) m->form = 'v';
-  if(m->form != 'b' && m->B3)
+  if(!uses('b') && m->B3)
   {
     (void)hipFree(m->B3);
     m->B3 = nullptr;
   }
-  if(m->form == 'h' || m->form == 'b')
+  if(!uses('p') && !uses('v'))
   {
     (void)hipFree(m->Bm); // only the fp32-MFMA forms read the K-major fp32 basis
     m->Bm = nullptr;
