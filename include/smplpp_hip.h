@@ -79,12 +79,16 @@ int smplpp_model_info(const smplpp_model * m, int64_t * vertex_num, int64_t * fa
  *   joints [n,24,3]     SMPL::getRestJoint       (:457-471)
  *   xforms [n,24,4,4]   WorldTransformation::getTransformation (relative transforms G')
  *   rest   [n,V,3]      SMPL::getRestShape
- * Two kernels: pose/chain, then the fused blend-shape GEMM + linear blend skinning. */
+ * Two kernels: pose/chain, then the fused blend-shape GEMM + linear blend skinning.  The fused kernel computes in the reference's
+ * arithmetic (every fp32 operand of the contraction carried exactly, as three bf16 pieces on the matrix pipe; fp32 accumulate; the
+ * skinning in fp32 FMAs: src/BlendShape.cpp:762-765, src/LinearBlendSkinning.cpp:463-467).  SMPLPP_SKIN in the environment of
+ * smplpp_model_create selects another form for every launch on the model: h (fp16x2 operand pieces, 22 bits, 3e-7 m: the form
+ * the IK loops' internal forward passes use by default), b (round 1's bf16x3 kernel), p / v (fp32 MFMA). */
 int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
               float * xforms, float * rest, int space, void * stream);
-/* Input range of the default fused kernel (fp16x2 operand pieces): |beta| < 1023 and relative transforms whose
+/* Input range of the fp16x2 form (SMPLPP_SKIN=h): |beta| < 1023 and relative transforms whose
  * translations stay within 16 x the template's extent (65504 / sG).  Outside it the operand pieces overflow fp16 and the
- * vertices of the frame are not finite, where the reference (and the forms SMPLPP_SKIN=b|p|v) stay finite.  A launch that
+ * vertices of the frame are not finite, where the reference and the default form (and SMPLPP_SKIN=b|p|v) stay finite.  A launch that
  * meets such an operand sets bit 0 of the model's status word: a host-space smplpp_fk returns SMPLPP_ERR_NUMERIC itself;
  * an enqueue-only (device-space) caller reads it here — the call synchronises `stream`, returns the word and clears it. */
 int smplpp_fk_status(smplpp_model * m, int * bits, void * stream);

@@ -45,12 +45,23 @@ constexpr int E_NDMA = 5;                            // ring DMAs per wavefront 
 constexpr int E_PITCH = 13;                          // slots between epilogue rows (a row takes 14: its last overlaps the next's first)
 constexpr int E_ROW0 = 12;                           // first epilogue slot
 constexpr int E_ROW_END = E_ROW0 + 15 * E_PITCH + 13; // 220: last epilogue slot
-constexpr int E_RD_AHEAD = 4;                        // slots between a joint's LDS reads and their use
-constexpr int E_ROOT_P = 9;                          // row slot that reads the root translation (used in slot 13)
+#ifndef SKINE_RD_AHEAD
+#define SKINE_RD_AHEAD 6
+#endif
+constexpr int E_RD_AHEAD = SKINE_RD_AHEAD;           // slots between a matrix row's LDS read and the FMA group that uses it
+constexpr int E_ROOT_P = 2;                          // row slot that reads the root translation (first used in slot 9)
 constexpr int E_GCHUNKS = E_G_BYTES / (256 * 16);    // 18 DMAs of 1 KiB per wavefront
 constexpr int E_GDMA0 = 12 * E_SLOTS + E_BAR + 1;    // 223: first slot of the G' DMAs of a run's first item (one per slot)
+constexpr int E_A_PRE = 4;                           // k-steps of A fragments the frame tile set-up loads; a run's first item loads the
+constexpr int E_A_SLOT = 13;                         // fragments of k-step KS + 4 in slot 13 of k-step KS (three plain loads)
 #ifndef SKINE_ABL
 #define SKINE_ABL 0 // timing ablations (development only; results are wrong when non-zero): 1 no epilogue, 2 no ring DMA, 4 no MFMA, 8 no barrier, 16 no fragment reads, 32 no stores, 512 per-workgroup timestamps
+#endif
+#ifndef SKINE_STORE_AUX
+#define SKINE_STORE_AUX 0 // cache policy of the output stores (bit 0 sc0, bit 1 nt, bit 4 sc1)
+#endif
+#ifndef SKINE_DMA_AUX
+#define SKINE_DMA_AUX 0 // cache policy of the ring DMAs
 #endif
 #ifndef SKINE_LGKM
 #define SKINE_LGKM 1 // 1: the k-step barriers let the epilogue's youngest LDS reads stay in flight (counted lgkmcnt); 0: lgkmcnt(0)
@@ -82,6 +93,7 @@ constexpr int e_vmem_after_dma(int S, bool hp, bool rest)
 {
   int c = 0;
   if(!hp && S >= E_GDMA0 && S < E_GDMA0 + E_GCHUNKS) c += 1; // G' DMA (a run's first item)
+  if(!hp && S % E_SLOTS == E_A_SLOT && S / E_SLOTS + E_A_PRE < EB_KS) c += 3; // A fragments of k-step KS + 4 (a run's first item)
   if(hp && S >= E_ROW0)
     for(int rr = 0; rr < 16; rr++)
     {
@@ -114,27 +126,18 @@ constexpr int e_barrier_vmcnt(int ks, bool hp, bool rest)
   for(int S = 0; S < ks * E_SLOTS + E_BAR; S++) c += e_vmem_ops(S, hp, rest);
   return c < 63 ? c : 63;
 }
-// LDS instructions the epilogue of the previous item issues in slot S (joint matrices: 3 ds_read_b128 per joint, issued
-// E_RD_AHEAD slots early; root translation: 1)
+// LDS instructions the epilogue of the previous item issues in slot S (one matrix row of one joint, E_RD_AHEAD slots ahead of the
+// group that multiplies it; the root translation of a row)
 constexpr int e_epilogue_lds_ops(int S, int maxw)
 {
+  (void)maxw;
   int c = 0;
-  const int s2 = S + E_RD_AHEAD - E_ROW0;
-  if(s2 >= 0 && s2 <= 15 * E_PITCH + 12)
+  for(int rr = 0; rr < 16; rr++)
   {
-    const int r = s2 / E_PITCH < 16 ? s2 / E_PITCH : 15;
-    for(int rr = r; rr >= 0 && rr >= r - 1; rr--) // a slot can belong to row rr (slots 0..12) and to row rr - 1 (slot 13)
-    {
-      const int p = s2 - rr * E_PITCH;
-      if(p < 0 || p > 13) continue;
-      for(int j = 0; j < maxw; j++)
-        if(p == (3 * j) / (maxw / 4)) c += 3;
-    }
+    const int d = S - (E_ROW0 + rr * E_PITCH); // row slot of row rr
+    if(d + E_RD_AHEAD - 1 >= 0 && d + E_RD_AHEAD - 1 < 12) c += 1; // the read of group d + E_RD_AHEAD - 1
+    if(d == E_ROOT_P) c += 1;                                      // root translation
   }
-  const int s1 = S - E_ROW0;
-  if(s1 >= 0)
-    for(int rr = 0; rr < 16; rr++)
-      if(s1 - rr * E_PITCH == E_ROOT_P) c += 1;
   return c;
 }
 // last slot of k-step ks - 1 that reads the image the barrier of k-step ks frees (the image of k-step ks): the nine fragment reads
@@ -158,10 +161,10 @@ constexpr int e_barrier_lgkm(int ks, bool hp, int maxw)
 }
 static_assert(E_LDS_TOTAL <= 160 * 1024, "LDS plan");
 static_assert(E_ROW_END < 12 * E_SLOTS + E_BAR, "the rows end before the slots a run's first item uses for its G' DMAs");
-static_assert(E_ROW0 - E_RD_AHEAD > E_BAR, "the first G' read of an item follows the barrier that publishes the tile");
+static_assert(E_ROW0 + 1 - E_RD_AHEAD > E_BAR, "the first G' read of an item follows the barrier that publishes the tile");
 static_assert(E_GDMA0 + E_GCHUNKS <= E_NSLOT, "the G' DMAs fit the item");
-static_assert(e_barrier_vmcnt(0, true, false) == 5 && e_barrier_vmcnt(1, false, false) == 10 && e_barrier_vmcnt(3, false, false) == 10 &&
-                  e_barrier_vmcnt(13, false, false) == 10 + 17 && e_barrier_vmcnt(5, true, false) == 10 + 4,
+static_assert(e_barrier_vmcnt(0, true, false) == 5 && e_barrier_vmcnt(1, false, false) == 10 + 3 && e_barrier_vmcnt(3, false, false) == 10 + 9 && e_barrier_vmcnt(3, true, false) == 10 + 3 &&
+                  e_barrier_vmcnt(13, false, false) == 10 + 17 && e_barrier_vmcnt(5, true, false) == 10 + 4 && e_barrier_vmcnt(5, false, false) == 10 + 9,
               "window bookkeeping");
 
 template<int LGKM, int VM>
@@ -179,7 +182,11 @@ __device__ __forceinline__ void e_full_barrier()
 }
 #define ESB() __builtin_amdgcn_sched_barrier(0)
 #if SKINE_ABL & 512
-__device__ unsigned long long g_ewg_times[256 * 4];
+__device__ unsigned long long g_ewg_times[256 * 8];
+#endif
+#if SKINE_ABL & 256
+// slot timestamps (development only): wavefront 0 of workgroup 0 stamps the cycle counter at every slot of its first 8 items
+__device__ unsigned long long g_eslot_times[8 * 256];
 #endif
 
 template<int MAXW, bool WANT_REST>
@@ -201,6 +208,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
   if(i0 >= i1) return; // whole workgroup leaves
 #if SKINE_ABL & 512
   const unsigned long long t_start = __builtin_amdgcn_s_memtime(), r_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t_first = 0, t_last = 0, t_drain0 = 0, t_run2 = 0;
 #endif
 
   const int frameB = (int)(V * 12);
@@ -225,6 +233,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
   const unsigned char * const gLane = lds + (wf * 32 + 4 * half) * (NJ * 48);      // G' of accumulator row R: + rowc(R) * 1152
   const v4f * const rootLane = reinterpret_cast<const v4f *>(lds + E_LDS_ROOT) + (wf * 32 + 4 * half); // + rowc(R)
 
+#if SKINE_ABL & 256
+  int dbg_item = 0;
+#endif
   f32x16 acc[3], accp[3];
   v4f areg[EB_KS][3]; // [k-step][piece]: this wavefront's 32 frames, loaded once per run
   v4f bfr[2][3][3];   // B fragments by k-step parity, [coordinate][piece]; a k-step's nine are read during the one before
@@ -256,9 +267,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
     constexpr int I = decltype(itag)::value;
     if constexpr(SKINE_ABL & 2) return;
     if constexpr(I < 4)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(lds + dst + wave * (E_NDMA * 1024)), 16, voffDma, vgBase + ks * EB_IMG, I * 1024, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(lds + dst + wave * (E_NDMA * 1024)), 16, voffDma, vgBase + ks * EB_IMG, I * 1024, SKINE_DMA_AUX);
     else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(lds + dst + wave * (E_NDMA * 1024) + 4096), 16, voffDma, vgBase + ks * EB_IMG + 4096, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(lds + dst + wave * (E_NDMA * 1024) + 4096), 16, voffDma, vgBase + ks * EB_IMG + 4096, 0, SKINE_DMA_AUX);
   };
   auto read_tables = [&](const unsigned char * img0) { // skinning tables of a group, from the image of its k-step 0
     const v4i jo = *reinterpret_cast<const v4i *>(img0 + tabLane);
@@ -284,8 +295,10 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
     if constexpr(FIRST)
       estatic_for<E_NDMA>([&](auto ii) { dma(ii, vgF, 0, imgS[0]); });
     const uint8_t * ap = A3 + ((int64_t)ft * EB_KS * 2 + wf) * 3072 + lane * 16;
+    // (the first four k-steps only: every CU starts at the same time and what a workgroup pulls before its first MFMA is served at
+    // ~20 B/clk; the run's first item loads the rest, three fragments per k-step, four k-steps ahead of their first use)
 #pragma unroll
-    for(int ks = 0; ks < EB_KS; ks++)
+    for(int ks = 0; ks < E_A_PRE; ks++)
 #pragma unroll
       for(int s = 0; s < 3; s++) areg[ks][s] = *reinterpret_cast<const v4f *>(ap + ks * BB_A_BYTES + s * 1024);
     if constexpr(FIRST)
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
         constexpr int D = decltype(dd)::value + 1;
         estatic_for<E_NDMA>([&](auto ii) { dma(ii, vgF, D, imgS[D]); });
       });
-      e_barrier<0, EB_KS * 3 + (E_R - 1) * E_NDMA>(); // behind k-step 0: the A loads and k-steps 1..3 may stay in flight
+      e_barrier<0, E_A_PRE * 3 + (E_R - 1) * E_NDMA>(); // behind k-step 0: the A loads and k-steps 1..3 may stay in flight
 #pragma unroll
       for(int q = 0; q < 9; q++) bfr[0][q / 3][q % 3] = *reinterpret_cast<const v4f *>(imgV[0] + q * 1024);
       read_tables(lds + imgS[0]);
@@ -321,70 +334,54 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
       }
     }
 
-    // epilogue state (row R of the previous item lives in rxyz[R & 1]: the last slot of a row is the first of the next)
-    float rxyz[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    float rt0 = 0.f, rt1 = 0.f, rt2 = 0.f, hx = 0.f, hy = 0.f;
+    // epilogue state.  Row R of the previous item takes row slots P = 0..13 at a pitch of 13 (its last slot is the next row's
+    // first).  P = 1..12: one FMA group each — group g = P - 1 is matrix row g / 4 of joint g % 4, four FMAs against the 16 bytes
+    // one ds_read_b128 fetched E_RD_AHEAD slots earlier (ONE LDS read and at most six vector instructions per slot: a slot with
+    // three reads or ten dependent instructions ran three MFMA times); h = M [rest; 1] follows each matrix row as it completes, in
+    // the reference's order ((x + y) + z) + w, one instruction per slot; the store sits alone in slot 13.
+    static_assert(MAXW == 4, "row schedule of four weights per vertex");
+    float rt0 = 0.f, rt1 = 0.f, rt2 = 0.f, tx = 0.f, ty = 0.f, ox = 0.f, oy = 0.f;
     v4f m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0, m2 = m0;
-    constexpr int NSET = 4;        // register sets of joint matrices in flight (a set is re-read after its last use)
-    constexpr int GPS = MAXW / 4;  // FMA groups (4 FMAs: one joint, one matrix row) per slot
-    v4f gq[NSET][3];
+    constexpr int NSET = E_RD_AHEAD + 2; // register sets of matrix rows in flight (E_RD_AHEAD + 1 are: read that many slots ahead of their use),
+                                         // taken in the order of the reads: set (12 R + G) mod NSET
+    v4f gq[NSET];
 
-    // LDS reads of the joints of row R2 that belong to row slot P2 (issued E_RD_AHEAD slots early)
-    auto read_piece = [&](auto r2tag, auto p2tag) {
-      constexpr int R2 = decltype(r2tag)::value, P2 = decltype(p2tag)::value;
+    // the LDS read of group G of row R2
+    auto read_group = [&](auto r2tag, auto gtag) {
+      constexpr int R2 = decltype(r2tag)::value, G = decltype(gtag)::value;
       constexpr int ROWC2 = (R2 & 3) + 8 * (R2 >> 2);
-#pragma unroll
-      for(int j = 0; j < MAXW; j++)
-        if(P2 == (3 * j) / GPS)
-        {
-          const unsigned char * gj = gLane + ROWC2 * (NJ * 48) + prev.jofs[j];
-          gq[j % NSET][0] = *reinterpret_cast<const v4f *>(gj);
-          gq[j % NSET][1] = *reinterpret_cast<const v4f *>(gj + 16);
-          gq[j % NSET][2] = *reinterpret_cast<const v4f *>(gj + 32);
-        }
+      gq[(R2 * 12 + G) % NSET] = *reinterpret_cast<const v4f *>(gLane + ROWC2 * (NJ * 48) + (G / 4) * 16 + prev.jofs[G % 4]);
     };
     // slot P (0..13) of row R of the previous item
     auto row_piece = [&](auto rtag, auto ptag) {
       constexpr int R = decltype(rtag)::value, P = decltype(ptag)::value;
       constexpr int ROWC = (R & 3) + 8 * (R >> 2); // + 4 * half: accumulator row -> frame in the wavefront's 32
-      float & rx = rxyz[R & 1][0];
-      float & ry = rxyz[R & 1][1];
-      float & rz = rxyz[R & 1][2];
-      if constexpr(P == 0)
+      const float rx = accp[0][R], ry = accp[1][R], rz = accp[2][R];
+      if constexpr(P == 0 && WANT_REST)
       {
-        rx = accp[0][R];
-        ry = accp[1][R];
-        rz = accp[2][R];
-        if constexpr(WANT_REST)
-        {
-          v3f ov = {rx, ry, rz};
-          if constexpr(!(SKINE_ABL & 32)) __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsR, prev.voff, prev.sb + ROWC * frameB, 0);
-        }
+        v3f ov = {rx, ry, rz};
+        if constexpr(!(SKINE_ABL & 32)) __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsR, prev.voff, prev.sb + ROWC * frameB, 0);
       }
       if constexpr(P >= 1 && P <= 12)
       {
         // scalar FMAs on purpose: packed f32 VALU beside MFMAs is an anti-lever (MI355X_MICROARCH.md, cycle constants)
-#pragma unroll
-        for(int g = (P - 1) * GPS; g < P * GPS; g++)
+        constexpr int G = P - 1, J = G % 4, MR = G / 4;
+        const float w = prev.jw[J];
+        const v4f gm = gq[(R * 12 + G) % NSET];
+        v4f & mm = (MR == 0 ? m0 : (MR == 1 ? m1 : m2));
+        if constexpr(J == 0)
         {
-          const int j = g / 3, row = g % 3;
-          const float w = prev.jw[j];
-          const v4f gm = gq[j % NSET][row];
-          v4f & mm = (row == 0 ? m0 : (row == 1 ? m1 : m2));
-          if(j == 0)
-          {
-            mm.x = w * gm.x;
-            mm.y = w * gm.y;
-            mm.z = w * gm.z;
-            mm.w = w * gm.w;
-          }
-          else
-          {
-            mm.x = __builtin_fmaf(w, gm.x, mm.x);
-            mm.y = __builtin_fmaf(w, gm.y, mm.y);
-            mm.z = __builtin_fmaf(w, gm.z, mm.z);
-            mm.w = __builtin_fmaf(w, gm.w, mm.w);
-          }
+          mm.x = w * gm.x;
+          mm.y = w * gm.y;
+          mm.z = w * gm.z;
+          mm.w = w * gm.w;
+        }
+        else
+        {
+          mm.x = __builtin_fmaf(w, gm.x, mm.x);
+          mm.y = __builtin_fmaf(w, gm.y, mm.y);
+          mm.z = __builtin_fmaf(w, gm.z, mm.z);
+          mm.w = __builtin_fmaf(w, gm.w, mm.w);
         }
       }
       if constexpr(P == E_ROOT_P)
@@ -394,26 +391,38 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
         rt1 = rt.y;
         rt2 = rt.z;
       }
-      if constexpr(P == 12 && MAXW == 4)
+      // h = M [rest; 1], cart = h / sum_j W + root (src/LinearBlendSkinning.cpp:465-475, 545-550)
+      // (x . M0 + y . M1 with the second product rounded and the first fused: what the compiler makes of skin_b.hip's expression —
+      // tools/fk_e_check.py compares the two kernels bit for bit)
+      if constexpr(P == 5) tx = m0.y * ry;
+      if constexpr(P == 6) tx = __builtin_fmaf(m0.x, rx, tx);
+      if constexpr(P == 7) tx = __builtin_fmaf(m0.z, rz, tx);
+      if constexpr(P == 8) tx = tx + m0.w;
+      if constexpr(P == 9)
       {
-        hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
-        hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
+        ox = __builtin_fmaf(tx, prev.winv, rt0);
+        ty = m1.y * ry;
+      }
+      if constexpr(P == 10) ty = __builtin_fmaf(m1.x, rx, ty);
+      if constexpr(P == 11) ty = __builtin_fmaf(m1.z, rz, ty);
+      if constexpr(P == 12)
+      {
+        ty = ty + m1.w;
+        oy = __builtin_fmaf(ty, prev.winv, rt1);
       }
       if constexpr(P == 13)
       {
-        if constexpr(MAXW != 4)
-        {
-          hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
-          hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
-        }
-        const float hz = ((m2.x * rx + m2.y * ry) + m2.z * rz) + m2.w;
+        float tz = m2.y * ry;
+        tz = __builtin_fmaf(m2.x, rx, tz);
+        tz = __builtin_fmaf(m2.z, rz, tz);
+        tz = tz + m2.w;
         // write-once output; the descriptor's range check drops frames >= n and vertex-less lanes.
         // (An MFMA always follows before the next VALU write: see the store hazard note at the drain.)
-        v3f ov = {hx * prev.winv + rt0, hy * prev.winv + rt1, hz * prev.winv + rt2};
+        v3f ov = {ox, oy, __builtin_fmaf(tz, prev.winv, rt2)};
         if constexpr(SKINE_ABL & 32)
           asm volatile("" ::"v"(ov.x), "v"(ov.y), "v"(ov.z));
         else
-          __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsV, prev.voff, prev.sb + ROWC * frameB, 0);
+          __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsV, prev.voff, prev.sb + ROWC * frameB, SKINE_STORE_AUX);
       }
     };
 
@@ -422,6 +431,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
       constexpr int KS = S / E_SLOTS, M = S % E_SLOTS;
       constexpr int X = M / 6, Q = M % 6;
       constexpr int AP = KS & 1, IMG = KS % E_R, IMGN = (KS + 1) % E_R;
+#if SKINE_ABL & 256
+      if(blockIdx.x == 0 && tid == 0 && dbg_item < 8) g_eslot_times[dbg_item * 256 + S] = __builtin_readcyclecounter();
+#endif
       if constexpr(SKINE_ABL & 4)
       {
         if constexpr(KS == 0 && Q == 0) acc[X] = zero16;
@@ -464,6 +476,13 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
         constexpr int KN = KS + E_R;
         dma(std::integral_constant<int, M - E_BAR - 1>{}, KN < EB_KS ? Bcur : Bnext, KN < EB_KS ? KN : KN - EB_KS, imgS[IMG]);
       }
+      // ---- A fragments of k-step KS + 4 (a run's first item; the tile set-up loaded k-steps 0..3)
+      if constexpr(!HP && M == E_A_SLOT && KS + E_A_PRE < EB_KS)
+      {
+        const uint8_t * ap = A3 + ((int64_t)ft * EB_KS * 2 + wf) * 3072 + lane * 16 + (KS + E_A_PRE) * BB_A_BYTES;
+#pragma unroll
+        for(int s = 0; s < 3; s++) areg[KS + E_A_PRE][s] = *reinterpret_cast<const v4f *>(ap + s * 1024);
+      }
       // ---- G' tile of a new run: HBM -> LDS by DMA, slots 223..240; published by the first barrier of the next item (or the drain)
       if constexpr(!HP && S >= E_GDMA0 && S < E_GDMA0 + E_GCHUNKS)
       {
@@ -473,15 +492,10 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
 
       if constexpr(EPI)
       {
-        // ---- joint matrices of the rows to come (LDS reads E_RD_AHEAD slots early)
-        constexpr int S2 = S + E_RD_AHEAD - E_ROW0;
-        if constexpr(S2 >= 0 && S2 <= 15 * E_PITCH + 12)
-        {
-          constexpr int R2 = S2 / E_PITCH < 16 ? S2 / E_PITCH : 15;
-          if constexpr(S2 - R2 * E_PITCH <= 13) read_piece(std::integral_constant<int, R2>{}, std::integral_constant<int, S2 - R2 * E_PITCH>{});
-          if constexpr(R2 >= 1 && S2 - (R2 - 1) * E_PITCH <= 13)
-            read_piece(std::integral_constant<int, R2 - 1>{}, std::integral_constant<int, S2 - (R2 - 1) * E_PITCH>{});
-        }
+        // ---- the matrix row a group E_RD_AHEAD slots ahead will multiply (one LDS read per slot)
+        constexpr int S2 = S + E_RD_AHEAD - E_ROW0 - 1;
+        if constexpr(S2 >= 0 && S2 / E_PITCH < 16 && S2 % E_PITCH < 12)
+          read_group(std::integral_constant<int, S2 / E_PITCH>{}, std::integral_constant<int, S2 % E_PITCH>{});
         // ---- this slot's piece(s) of the rows in progress (finishing slot of row R - 1 first, then the opening slot of row R)
         constexpr int S1 = S - E_ROW0;
         if constexpr(S1 >= 0 && S1 <= E_ROW_END - E_ROW0)
@@ -495,6 +509,10 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
     });
 
     // the current item becomes the previous one; the images rotate (14 k-steps per item, 14 mod 4 = 2)
+#if SKINE_ABL & 256
+    if(blockIdx.x == 0 && tid == 0 && dbg_item < 8) g_eslot_times[dbg_item * 256 + 252] = __builtin_readcyclecounter();
+    dbg_item++;
+#endif
 #pragma unroll
     for(int x = 0; x < 3; x++) accp[x] = acc[x];
     prev = cur;
@@ -511,9 +529,21 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
   // ---- the epilogue of a run's last item with nothing to hide behind (the G' tile may still be on its way: a run of one item)
   auto drain = [&]() {
     e_full_barrier();
+    // the twelve matrix rows of accumulator row R + 1 are requested before row R is computed (two register sets)
+    v4f gd[2][12], rtd[2];
+    auto request = [&](auto rtag) {
+      constexpr int R = decltype(rtag)::value;
+      constexpr int ROWC = (R & 3) + 8 * (R >> 2);
+      rtd[R & 1] = rootLane[ROWC];
+#pragma unroll
+      for(int g = 0; g < 12; g++) gd[R & 1][g] = *reinterpret_cast<const v4f *>(gLane + ROWC * (NJ * 48) + (g / 4) * 16 + prev.jofs[g % 4]);
+    };
+    request(std::integral_constant<int, 0>{});
     estatic_for<16>([&](auto rr) {
       constexpr int R = decltype(rr)::value;
       constexpr int ROWC = (R & 3) + 8 * (R >> 2);
+      const v4f rt = rtd[R & 1];
+      if constexpr(R + 1 < 16) request(std::integral_constant<int, R + 1>{});
       const float rx = accp[0][R], ry = accp[1][R], rz = accp[2][R];
       if constexpr(WANT_REST)
       {
@@ -523,32 +553,40 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
         asm volatile("s_nop 1");
         ESB();
       }
-      v4f m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0, m2 = m0;
+      float m[3][4];
 #pragma unroll
-      for(int i = 0; i < MAXW; i++)
+      for(int g = 0; g < 12; g++)
       {
-        const unsigned char * gj = gLane + ROWC * (NJ * 48) + prev.jofs[i];
-        const v4f g0 = *reinterpret_cast<const v4f *>(gj), g1 = *reinterpret_cast<const v4f *>(gj + 16), g2 = *reinterpret_cast<const v4f *>(gj + 32);
-        const float w = prev.jw[i];
-        if(i == 0)
+        const float w = prev.jw[g % 4];
+        const v4f gm = gd[R & 1][g];
+        float * mm = m[g / 4];
+        if(g % 4 == 0)
         {
-          m0 = w * g0;
-          m1 = w * g1;
-          m2 = w * g2;
+          mm[0] = w * gm.x;
+          mm[1] = w * gm.y;
+          mm[2] = w * gm.z;
+          mm[3] = w * gm.w;
         }
         else
         {
-          m0 = v4f{__builtin_fmaf(w, g0.x, m0.x), __builtin_fmaf(w, g0.y, m0.y), __builtin_fmaf(w, g0.z, m0.z), __builtin_fmaf(w, g0.w, m0.w)};
-          m1 = v4f{__builtin_fmaf(w, g1.x, m1.x), __builtin_fmaf(w, g1.y, m1.y), __builtin_fmaf(w, g1.z, m1.z), __builtin_fmaf(w, g1.w, m1.w)};
-          m2 = v4f{__builtin_fmaf(w, g2.x, m2.x), __builtin_fmaf(w, g2.y, m2.y), __builtin_fmaf(w, g2.z, m2.z), __builtin_fmaf(w, g2.w, m2.w)};
+          mm[0] = __builtin_fmaf(w, gm.x, mm[0]);
+          mm[1] = __builtin_fmaf(w, gm.y, mm[1]);
+          mm[2] = __builtin_fmaf(w, gm.z, mm[2]);
+          mm[3] = __builtin_fmaf(w, gm.w, mm[3]);
         }
       }
-      const float hx = ((m0.x * rx + m0.y * ry) + m0.z * rz) + m0.w;
-      const float hy = ((m1.x * rx + m1.y * ry) + m1.z * rz) + m1.w;
-      const float hz = ((m2.x * rx + m2.y * ry) + m2.z * rz) + m2.w;
-      const v4f rt = rootLane[ROWC];
-      v3f ov = {hx * prev.winv + rt.x, hy * prev.winv + rt.y, hz * prev.winv + rt.z};
-      __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsV, prev.voff, prev.sb + ROWC * frameB, 0);
+      // (the slot stream's operations in the slot stream's order: tools/fk_e_check.py compares the two paths bit for bit)
+      float t[3];
+#pragma unroll
+      for(int c = 0; c < 3; c++)
+      {
+        t[c] = m[c][1] * ry;
+        t[c] = __builtin_fmaf(m[c][0], rx, t[c]);
+        t[c] = __builtin_fmaf(m[c][2], rz, t[c]);
+        t[c] = t[c] + m[c][3];
+      }
+      v3f ov = {__builtin_fmaf(t[0], prev.winv, rt.x), __builtin_fmaf(t[1], prev.winv, rt.y), __builtin_fmaf(t[2], prev.winv, rt.z)};
+      __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, ov), rsV, prev.voff, prev.sb + ROWC * frameB, SKINE_STORE_AUX);
       // HAZARD (measured on gfx950, see skin_b.hip): keep one instruction between a 96-bit buffer store and the next VALU write
       // to its data registers
       ESB();
@@ -564,6 +602,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
     const int iend = (ft + 1) * nvx < i1 ? (ft + 1) * nvx : i1;
     if(i != i0)
     {
+#if SKINE_ABL & 512
+      t_drain0 = __builtin_amdgcn_s_memtime();
+#endif
       drain();
       load_frame_tile(ft, std::false_type{});
     }
@@ -571,6 +612,9 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
       load_frame_tile(ft, std::true_type{});
     // item k of the run: vertex group vgk; the item after it: the next group, the XCD's first one when the frame tile ends there,
     // the same one when the workgroup's items end there (its prefetches land in images nobody reads)
+#if SKINE_ABL & 512
+    if(i == i0) t_first = __builtin_amdgcn_s_memtime(); else t_run2 = __builtin_amdgcn_s_memtime();
+#endif
     int vgk = vg0 + (i - ft * nvx);
     auto next_vg = [&](int k, int vgc) { return k + 1 < i1 ? (vgc + 1 < vg1 ? vgc + 1 : vg0) : vgc; };
     do_item(ft, vgk, next_vg(i, vgk), std::false_type{});
@@ -581,14 +625,21 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
     }
     i = iend;
   }
+#if SKINE_ABL & 512
+  t_last = __builtin_amdgcn_s_memtime();
+#endif
   drain();
 #if SKINE_ABL & 512
   if(tid == 0 && blockIdx.x < 256)
   {
-    g_ewg_times[blockIdx.x * 4 + 0] = r_start;
-    g_ewg_times[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-    g_ewg_times[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime() - t_start;
-    g_ewg_times[blockIdx.x * 4 + 3] = (unsigned long long)(i1 - i0);
+    g_ewg_times[blockIdx.x * 8 + 0] = r_start;
+    g_ewg_times[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    g_ewg_times[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime() - t_start;
+    g_ewg_times[blockIdx.x * 8 + 3] = (unsigned long long)(i1 - i0);
+    g_ewg_times[blockIdx.x * 8 + 4] = t_first - t_start;                          // prologue
+    g_ewg_times[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime() - t_last;      // final drain
+    g_ewg_times[blockIdx.x * 8 + 6] = t_run2 ? t_run2 - t_drain0 : 0;             // drain + set-up between two runs
+    g_ewg_times[blockIdx.x * 8 + 7] = t_last - t_first;                           // first item .. last item (incl. a run change)
   }
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the last prefetches land before the wavefront ends
@@ -621,10 +672,16 @@ static hipError_t launch_e(const smplpp_model * m, int64_t n, const float * thet
   return hipGetLastError();
 }
 
+#if SKINE_ABL & 256
+extern "C" int smplpp_debug_eslot_times(unsigned long long * out)
+{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(smplpp_hip::g_eslot_times), sizeof(unsigned long long) * 8 * 256);
+}
+#endif
 #if SKINE_ABL & 512
 extern "C" int smplpp_debug_ewg_times(unsigned long long * out)
 {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(smplpp_hip::g_ewg_times), sizeof(unsigned long long) * 256 * 4);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(smplpp_hip::g_ewg_times), sizeof(unsigned long long) * 256 * 8);
 }
 #endif
 // A3 / Gp must hold whole 64-frame tiles (padding content is irrelevant: the rows it feeds are never stored)

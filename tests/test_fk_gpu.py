@@ -92,11 +92,11 @@ def test_fk_batch1024_properties_and_sample(smpl, oracle_synth):
     assert np.isfinite(o).all()
 
 
-@pytest.mark.parametrize("form", ["h", "b", "p", "v"])
+@pytest.mark.parametrize("form", ["e", "h", "b", "p", "v"])
 def test_fk_dense_weights_and_ragged_vertex_count(form, monkeypatch):
     """61-vertex model with all 24 skinning weights non-zero (dense path) — golden from the reference build.  Under every
-    SMPLPP_SKIN: h takes dense weights as they are; b and p (at most 8 weights per vertex) must hand such a model to the
-    first form when it is CREATED, with the operand layout that form reads kept resident."""
+    SMPLPP_SKIN: h takes dense weights as they are; e (at most 4 weights per vertex), b and p (at most 8) must hand such a
+    model to the first form when it is CREATED, with the operand layout that form reads kept resident."""
     from smplpp_amd import model_io
     from smplpp_amd.smpl import SMPL
 
@@ -111,11 +111,12 @@ def test_fk_dense_weights_and_ragged_vertex_count(form, monkeypatch):
         assert np.abs(o[k] - g[k]).max() < VERT_TOL, k
 
 
-@pytest.mark.parametrize("form", ["h", "b", "p"])
+@pytest.mark.parametrize("form", ["e", "h", "b", "p"])
 def test_fk_eight_weights_per_vertex(synth_model, form, monkeypatch):
-    """Models with 5..8 skinning weights per vertex: the default form (h) skins on the matrix pipe with dense weights,
-    the b / p forms take their MAXW = 8 instantiations (real SMPL has at most 4); ragged frame counts exercise partial
-    frame tiles and the single-item / multi-item paths.  (The form is read from SMPLPP_SKIN when a model is created.)"""
+    """Models with 5..8 skinning weights per vertex: h skins on the matrix pipe with dense weights, the b / p forms take their
+    MAXW = 8 instantiations, and the default form (e: four weights per vertex in registers) hands such a model to b when it is
+    created (real SMPL has at most 4); ragged frame counts exercise partial frame tiles and the single-item / multi-item
+    paths.  (The form is read from SMPLPP_SKIN when a model is created.)"""
     from smplpp_amd.smpl import SMPL
     from oracle.cpu import OracleModel
 
@@ -168,6 +169,28 @@ def test_fk_small_sparse_models(V):
         r = o.fk(beta, theta)
         for k in ("verts", "rest", "joints"):
             assert np.abs(g[k] - r[k]).max() < VERT_TOL, (V, n, k)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 1100])
+def test_fk_exact_form_reproduces_round1_kernel_bits(synth_model, n, monkeypatch):
+    """skin_kernel_e (the default) issues skin_kernel_b's piece products and skinning operations in skin_kernel_b's order from a
+    different skeleton (A fragments in registers, the tile's transforms resident in LDS over a run of vertex groups, a four-image
+    ring, skinning tables inside the basis images): the two must agree bit for bit at every batch size — single frames, partial
+    tiles, workgroups whose runs cross frame tiles (257, 1100) — with and without `rest`."""
+    from smplpp_amd import model_io
+    from smplpp_amd.smpl import SMPL
+
+    eng = {}
+    for form in ("e", "b"):
+        monkeypatch.setenv("SMPLPP_SKIN", form)
+        eng[form] = SMPL()
+        eng[form].setDevice("cuda:0")
+        eng[form].init(synth_model)
+    beta, theta = model_io.synthetic_inputs(n, seed=5 + n)
+    oe, ob = eng["e"].launch(beta, theta), eng["b"].launch(beta, theta)
+    assert np.isfinite(oe["verts"]).all()
+    assert np.array_equal(oe["verts"], ob["verts"]) and np.array_equal(oe["rest"], ob["rest"])
+    assert np.array_equal(eng["e"].launch(beta, theta, want=("verts",))["verts"], ob["verts"])
 
 
 def test_fk_workgroups_spanning_frame_tiles(smpl, oracle_synth):
@@ -242,10 +265,11 @@ def test_fk_writes_only_its_frames(smpl, n):
 
 
 def test_fk_split_operand_forms_are_fp32_exact(synth_model, oracle_synth, monkeypatch):
-    """The default fused kernel (h, skin_h.hip) carries every fp32 operand as two fp16 pieces on the f16 matrix pipe and
-    skins on the matrix pipe; b (skin_b.hip) uses three bf16 pieces. Their error against the fp64-accumulating oracle must
-    be of the same size as that of the exact fp32-MFMA form (p, skin_p.hip), far inside the 1e-5 m parity bar, on shaped
-    vertices and skinned vertices alike."""
+    """The default fused kernel (e, skin_e.hip) and round 1's b (skin_b.hip) carry every fp32 operand as three bf16 pieces
+    (fp32's 24 bits, six MFMA products) and skin in fp32 on the vector ALU; h (skin_h.hip) carries two fp16 pieces on the f16
+    matrix pipe and skins there too.  Their error against the fp64-accumulating oracle must be of the same size as that of the
+    exact fp32-MFMA form (p, skin_p.hip), far inside the 1e-5 m parity bar, on shaped vertices and skinned vertices alike;
+    and e, which issues b's piece products and b's skinning operations in b's order, must reproduce b's bits."""
     from smplpp_amd import model_io
     from smplpp_amd.smpl import SMPL
 
@@ -253,22 +277,26 @@ def test_fk_split_operand_forms_are_fp32_exact(synth_model, oracle_synth, monkey
     beta = (beta * 3.0).astype(np.float32)  # large shape coefficients: stresses the low pieces
     r = oracle_synth.fk(beta, theta)
     err = {}
-    for form in ("h", "b", "p"):
+    outs = {}
+    for form in ("e", "h", "b", "p"):
         monkeypatch.setenv("SMPLPP_SKIN", form)
         s = SMPL()
         s.setDevice("cuda:0")
         s.init(synth_model)
         o = s.launch(beta, theta)
+        outs[form] = o
         err[form] = {k: float(np.abs(o[k] - r[k]).max()) for k in ("verts", "rest")}
     monkeypatch.delenv("SMPLPP_SKIN")
-    for form in ("h", "b"):
+    assert np.array_equal(outs["e"]["verts"], outs["b"]["verts"]) and np.array_equal(outs["e"]["rest"], outs["b"]["rest"])
+    for form in ("e", "h", "b"):
         for k in ("verts", "rest"):
             assert err[form][k] < 2e-6, err
             assert err[form][k] <= 3.0 * err["p"][k] + 2e-7, err
 
 
-def test_fk_fp16x2_at_real_smpl_magnitudes(synth_model):
-    """Error budget of the fp16x2 operands where it is tightest: posedirs up to 5e-2 (25x the synthetic model's, the
+@pytest.mark.parametrize("form", ["h", "e"])
+def test_fk_fp16x2_at_real_smpl_magnitudes(synth_model, form, monkeypatch):
+    """Error budget of the fp16x2 operands (h; and the exact form e beside it) where it is tightest: posedirs up to 5e-2 (25x the synthetic model's, the
     size of real SMPL's largest entries), |beta| = 3, rotations up to ~1.5 rad, root translations of several metres.
     Reference: float64 numpy restatement of rest = T + S.beta + P.c and of the skinning, from the fp32 joints / relative
     transforms the engine itself returns (those stages are covered by the golden tests)."""
@@ -278,6 +306,7 @@ def test_fk_fp16x2_at_real_smpl_magnitudes(synth_model):
     md = {k: v.copy() for k, v in synth_model.items()}
     rng = np.random.default_rng(77)
     md["pose_blend_shapes"] = np.clip(rng.normal(0, 5e-2 / 3, md["pose_blend_shapes"].shape), -5e-2, 5e-2).astype(np.float32)
+    monkeypatch.setenv("SMPLPP_SKIN", form)
     s = SMPL()
     s.setDevice("cuda:0")
     s.init(md)
@@ -400,19 +429,30 @@ def test_whole_mesh_vertex_normals_and_sweep_grid(smpl, oracle_synth, synth_mode
     assert np.abs(g["winding"] - np.round(g["winding"])).max() < 0.5 + 1e-6  # (a posed synthetic body may self-intersect: winding 2)
 
 
-def test_fk_out_of_range_operands_are_reported(smpl, synth_model):
-    """The default fused kernel carries its operands as fp16 pieces of scaled values (|beta| < 1023, transforms within 16 x the
-    template's extent): outside that range the reference stays finite and this form does not, so the launch must SAY so — a
-    host-space call returns SMPLPP_ERR_NUMERIC, an enqueue-only caller finds bit 0 in smplpp_fk_status — and the next
-    in-range launch is clean again."""
+def test_fk_out_of_range_operands_are_reported(smpl, synth_model, oracle_synth, monkeypatch):
+    """The fp16x2 form (SMPLPP_SKIN=h) carries its operands as fp16 pieces of scaled values (|beta| < 1023, transforms within
+    16 x the template's extent): outside that range the reference stays finite and that form does not, so the launch must SAY so
+    — a host-space call returns SMPLPP_ERR_NUMERIC, an enqueue-only caller finds bit 0 in smplpp_fk_status — and the next
+    in-range launch is clean again.  The default form (e: bf16 pieces, fp32's exponent range) has no such range: it follows the
+    reference there."""
     import torch
     from smplpp_amd import model_io
     from smplpp_amd._lib import SmplppError
+    from smplpp_amd.smpl import SMPL
 
     beta, theta = model_io.synthetic_inputs(5, seed=3)
-    assert smpl.launchStatus() == 0
     bad = beta.copy()
     bad[3, 2] = 2000.0
+    o = smpl.launch(bad, theta, want=("verts",))  # the default form: finite, and the oracle's vertices
+    r = oracle_synth.fk(bad, theta)
+    assert np.isfinite(o["verts"]).all() and smpl.launchStatus() == 0
+    assert np.abs(o["verts"] - r["verts"]).max() < 1e-3  # vertices tens of metres away: fp32 at that size
+    monkeypatch.setenv("SMPLPP_SKIN", "h")
+    smpl = SMPL()
+    smpl.setDevice("cuda:0")
+    smpl.init(synth_model)
+    monkeypatch.delenv("SMPLPP_SKIN")
+    assert smpl.launchStatus() == 0
     with pytest.raises(SmplppError) as ei:
         smpl.launch(bad, theta, want=("verts",))
     assert ei.value.code == 3
@@ -424,7 +464,7 @@ def test_fk_out_of_range_operands_are_reported(smpl, synth_model):
     assert np.isfinite(o["verts"]).all() and smpl.launchStatus() == 0
 
 
-def test_fk_skinning_class_groups_on_a_part_ordered_numbering(synth_model, oracle_synth):
+def test_fk_skinning_class_groups_on_a_part_ordered_numbering(synth_model, oracle_synth, monkeypatch):
     """skin_kernel_h runs a vertex group (64 consecutive vertices) whose skinning weights live in ONE k-step of the blend product —
     joints 0..15 only, or joints 16..23 only (SMPL's arms) — in an instantiation that issues only that k-step's MFMAs (common.h,
     HB_PERM_OFF), and deals the groups over the XCD slices by class.  The stand-in's spiral numbering has 11 such groups of 108 and
@@ -435,6 +475,7 @@ def test_fk_skinning_class_groups_on_a_part_ordered_numbering(synth_model, oracl
     from smplpp_amd import model_io
     from smplpp_amd.smpl import SMPL
 
+    monkeypatch.setenv("SMPLPP_SKIN", "h")
     cls = model_io.skinning_classes(synth_model["weights"])
     order = np.argsort(cls, kind="stable")
     part = model_io.relabel_vertices(synth_model, order)
