@@ -13,11 +13,16 @@ namespace smplpp
 class IkTask
 {
 public:
-  IkTask(const std::shared_ptr<smplpp::SMPL> & smpl, int64_t faceIdx) : smpl_(smpl), faceIdx_(faceIdx) {}
-  IkTask(const std::shared_ptr<smplpp::SMPL> & smpl, int64_t faceIdx, const std::vector<float> & targetPos,
-         const std::vector<float> & targetNormal)
-  : smpl_(smpl), faceIdx_(faceIdx), targetPos_(targetPos), targetNormal_(targetNormal)
+  // include/smplpp/IkTask.h:20-34 of the reference: (smpl, faceIdx) and (smpl, faceIdx, targetPos, targetNormal) with
+  // tensors of three elements
+  IkTask(const std::shared_ptr<smplpp::SMPL> & smpl, int64_t faceIdx) : smpl_(smpl), faceIdx_(faceIdx)
   {
+    targetNormal_.index_put_({2}, 1.0); // src/IkTask.cpp:11-15: target position 0, target normal +Z
+  }
+  IkTask(const std::shared_ptr<smplpp::SMPL> & smpl, int64_t faceIdx, Tensor targetPos, Tensor targetNormal)
+  : smpl_(smpl), faceIdx_(faceIdx), targetPos_(std::move(targetPos)), targetNormal_(std::move(targetNormal))
+  {
+    if(targetPos_.numel() != 3 || targetNormal_.numel() != 3) throw Exception("IkTask", "targetPos / targetNormal must hold three elements");
   }
 
   // ---- the four methods of the reference class (include/smplpp/IkTask.h:33-49, src/IkTask.cpp:33-86), on the vertices of
@@ -40,17 +45,19 @@ public:
     normalize(t2);
     for(int x = 0; x < 3; x++)
     {
-      tangents_[(size_t)x * 2 + 0] = t1[x];
-      tangents_[(size_t)x * 2 + 1] = t2[x];
+      tangents_.data[(size_t)x * 2 + 0] = t1[x];
+      tangents_.data[(size_t)x * 2 + 1] = t2[x];
     }
   }
   // Vertex weights such that actualPos + tangents . phi is the weighted sum of the face vertices (src/IkTask.cpp:50-58,
   // calcTriangleVertexWeights: toolbox/GeometryUtils.h:42-52)
-  void calcVertexWeights(const std::vector<float> & actualPos)
+  void calcVertexWeights(const Tensor & actualPos)
   {
+    if(actualPos.numel() != 3) throw Exception("IkTask", "calcVertexWeights: a point of three elements");
     float v[3][3], pos[3], w[3];
     faceVertices(v);
-    for(int x = 0; x < 3; x++) pos[x] = actualPos[(size_t)x] + tangents_[(size_t)x * 2] * phi_[0] + tangents_[(size_t)x * 2 + 1] * phi_[1];
+    for(int x = 0; x < 3; x++)
+      pos[x] = (float)actualPos.at(x) + tangents_.data[(size_t)x * 2] * phi_.data[0] + tangents_.data[(size_t)x * 2 + 1] * phi_.data[1];
     for(int i = 0; i < 3; i++)
     {
       float a[3], b[3], c[3];
@@ -63,54 +70,57 @@ public:
       w[i] = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
     }
     const float sum = w[0] + w[1] + w[2];
-    for(int i = 0; i < 3; i++) vertexWeights_[(size_t)i] = w[i] / sum;
+    for(int i = 0; i < 3; i++) vertexWeights_.data[(size_t)i] = w[i] / sum;
   }
   // Position of the task point (src/IkTask.cpp:60-72)
-  std::vector<float> calcActualPos() const
+  Tensor calcActualPos() const
   {
     float v[3][3];
     faceVertices(v);
-    std::vector<float> p(3, 0.0f);
+    Tensor p({3});
     for(int x = 0; x < 3; x++)
-      for(int i = 0; i < 3; i++) p[(size_t)x] += v[i][x] * vertexWeights_[(size_t)i];
+      for(int i = 0; i < 3; i++) p.data[(size_t)x] += v[i][x] * vertexWeights_.data[(size_t)i];
     if(normalOffset_ > 0.0)
     {
-      const std::vector<float> n = calcActualNormal();
-      for(int x = 0; x < 3; x++) p[(size_t)x] += (float)normalOffset_ * n[(size_t)x];
+      const Tensor n = calcActualNormal();
+      for(int x = 0; x < 3; x++) p.data[(size_t)x] += (float)normalOffset_ * n.data[(size_t)x];
     }
     return p;
   }
   // Unit normal of the task point: the weighted vertex normals of the face (src/IkTask.cpp:74-86)
-  std::vector<float> calcActualNormal() const
+  Tensor calcActualNormal() const
   {
-    const std::vector<int32_t> fv = smpl_->getFaceIndexRaw(faceIdx_);
+    const Tensor fv = smpl_->getFaceIndexRaw(faceIdx_).to(kCPU) - 1;
     float n[3] = {0.f, 0.f, 0.f};
     for(int i = 0; i < 3; i++)
     {
-      const Tensor vn = smpl_->calcVertexNormal((int64_t)fv[(size_t)i] - 1);
-      for(int x = 0; x < 3; x++) n[x] += vertexWeights_[(size_t)i] * vn.data[(size_t)x];
+      const Tensor vn = smpl_->calcVertexNormal(fv.idata[(size_t)i]);
+      for(int x = 0; x < 3; x++) n[x] += vertexWeights_.data[(size_t)i] * vn.data[(size_t)x];
     }
     normalize(n);
-    return {n[0], n[1], n[2]};
+    Tensor r({3});
+    for(int x = 0; x < 3; x++) r.data[(size_t)x] = n[x];
+    return r;
   }
 
+  // public fields of the reference class, same names, types and defaults (include/smplpp/IkTask.h:54-84)
   std::shared_ptr<smplpp::SMPL> smpl_;
   int64_t faceIdx_;
   double posTaskWeight_ = 1.0;
   double normalTaskWeight_ = 1.0;
   double phiLimit_ = 0.04;
   double normalOffset_ = 0.0;
-  std::vector<float> targetPos_{0.f, 0.f, 0.f};
-  std::vector<float> targetNormal_{0.f, 0.f, 1.f};
-  std::vector<float> vertexWeights_{1.f / 3, 1.f / 3, 1.f / 3};
-  std::vector<float> tangents_ = std::vector<float>(6, 0.f); // [3,2]
-  std::vector<float> phi_{0.f, 0.f};
+  Tensor targetPos_ = Tensor({3});
+  Tensor targetNormal_ = Tensor({3});
+  Tensor vertexWeights_ = Tensor({3}, 1.0f / 3.0f);
+  Tensor tangents_ = Tensor({3, 2});
+  Tensor phi_ = Tensor({2});
 
 private:
   void faceVertices(float (&v)[3][3]) const
   {
-    const std::vector<int32_t> fv = smpl_->getFaceIndexRaw(faceIdx_);
-    const Tensor t = smpl_->getVertexRaw(IndexTensor{(int64_t)fv[0] - 1, (int64_t)fv[1] - 1, (int64_t)fv[2] - 1});
+    const Tensor fv = smpl_->getFaceIndexRaw(faceIdx_).to(kCPU) - 1;        // src/IkTask.cpp:35
+    const Tensor t = smpl_->getVertexRaw(fv.to(kInt64)).to(kCPU).clone().detach(); // :37
     for(int i = 0; i < 3; i++)
       for(int x = 0; x < 3; x++) v[i][x] = t.data[(size_t)i * 3 + x];
   }
@@ -167,9 +177,9 @@ public:
         no[i] = t.normalOffset_;
         for(int x = 0; x < 3; x++)
         {
-          vw[i * 3 + x] = t.vertexWeights_[x];
-          tp[i * 3 + x] = t.targetPos_[x];
-          tn[i * 3 + x] = t.targetNormal_[x];
+          vw[i * 3 + x] = (float)t.vertexWeights_.at(x);
+          tp[i * 3 + x] = (float)t.targetPos_.at(x);
+          tn[i * 3 + x] = (float)t.targetNormal_.at(x);
         }
         k++;
       }

@@ -15,6 +15,10 @@ static void dump(const char * key, const std::vector<float> & v)
   for(float x : v) std::printf(" %.9g", (double)x);
   std::printf("\n");
 }
+static void dump(const char * key, const smplpp::Tensor & t)
+{
+  dump(key, t.toVector<float>());
+}
 
 int main(int argc, char ** argv)
 {
@@ -44,7 +48,7 @@ int main(int argc, char ** argv)
     for(auto & kv : tasks)
     {
       kv.second.phiLimit_ = 0.0; // node.cpp:567
-      kv.second.targetPos_ = {0.1f, 0.2f, 0.3f};
+      kv.second.targetPos_ = smplpp::torchlike::tensor({0.1f, 0.2f, 0.3f});
     }
     smplpp::IkSolver solver(smpl, 1, 2);
     solver.setTaskList(tasks);
@@ -74,17 +78,17 @@ int main(int argc, char ** argv)
     smplpp::Tensor th2({1, 25, 3});
     for(int i = 3; i < 75; i++) th2.data[(size_t)i] = 0.05f * std::sin(0.7f * (float)i);
     smpl->launch(beta, th2);
-    smplpp::IkTask task(smpl, 7, {0.1f, 0.0f, 0.2f}, {0.f, 0.f, 1.f});
+    smplpp::IkTask task(smpl, 7, smplpp::torchlike::tensor({0.1f, 0.0f, 0.2f}), smplpp::torchlike::tensor({0.f, 0.f, 1.f}));
     task.normalOffset_ = 0.015;
-    task.phi_ = {0.002f, -0.001f};
+    task.phi_ = smplpp::torchlike::tensor({0.002f, -0.001f});
     task.calcTangents();
     dump("TANGENTS", task.tangents_);
-    const std::vector<int32_t> fv = smpl->getFaceIndexRaw(7);
-    smplpp::Tensor tri = smpl->getVertexRaw(smplpp::IndexTensor{fv[0] - 1, fv[1] - 1, fv[2] - 1});
+    const smplpp::Tensor fv = smpl->getFaceIndexRaw(7).to(smplpp::kCPU) - 1; // node/node.cpp:183
+    smplpp::Tensor tri = smpl->getVertexRaw(fv.to(smplpp::kInt64)).to(smplpp::kCPU).clone().detach(); // :186
     dump("FACEVERTS", tri.data);
-    std::vector<float> centroid(3, 0.f);
+    smplpp::Tensor centroid({3});
     for(int i = 0; i < 3; i++)
-      for(int x = 0; x < 3; x++) centroid[(size_t)x] += tri.data[(size_t)i * 3 + x] * (i == 0 ? 0.5f : 0.25f);
+      for(int x = 0; x < 3; x++) centroid.data[(size_t)x] += tri.data[(size_t)i * 3 + x] * (i == 0 ? 0.5f : 0.25f);
     task.calcVertexWeights(centroid);
     dump("WEIGHTS", task.vertexWeights_);
     dump("ACTUALPOS", task.calcActualPos());
