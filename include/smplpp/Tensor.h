@@ -45,6 +45,8 @@ struct Device
   Device() = default;
   Device(const std::string & t, int i) : type(t), index(i) {}
   Device(DeviceType t, int i) : type(t.id == 0 ? "CPU" : "CUDA"), index(i) {}
+  explicit Device(DeviceType t) : type(t.id == 0 ? "CPU" : "CUDA"), index(-1) {} // node/node.cpp:362-366, followed by set_index(0) (:372)
+  void set_index(int i) { index = i; }
   bool has_index() const { return index >= 0; }
 };
 
@@ -328,6 +330,19 @@ inline Tensor tensor(std::initializer_list<float> v)
   Tensor t({(int64_t)v.size()});
   size_t i = 0;
   for(float x : v) t.data[i++] = x;
+  return t;
+}
+// torch::from_blob(ptr, sizes).clone() (toolbox/TorchEigenUtils.hpp:26-30, toTorchTensor): a copy of caller memory
+inline Tensor from_blob(const float * p, std::initializer_list<int64_t> s)
+{
+  Tensor t{std::vector<int64_t>(s), 0.0f};
+  for(int64_t i = 0; i < t.numel(); i++) t.data[(size_t)i] = p[i];
+  return t;
+}
+inline Tensor from_blob(const double * p, std::initializer_list<int64_t> s)
+{
+  Tensor t(std::vector<int64_t>(s), kFloat64);
+  for(int64_t i = 0; i < t.numel(); i++) t.ddata[(size_t)i] = p[i];
   return t;
 }
 // [m,k] x [k] -> [m] and [m,k] x [k,n] -> [m,n], fp32 (node/node.cpp:958: tangents_ [3,2] x phi [2])

@@ -24,6 +24,15 @@ class VPoserDecoder
 {
 public:
   explicit VPoserDecoder(int device = 0) : device_(device) {}
+  // the reference's VPoserDecoder is a torch module HOLDER: node/node.cpp:425-439 writes `smplpp::VPoserDecoder vposer;
+  // vposer->loadParamsFromJson(path); vposer->eval(); vposer->to(*device);`
+  VPoserDecoder * operator->() { return this; }
+  void eval() {} // (dropout is the identity in this decoder: src/VPoser.cpp:146-155 in eval mode)
+  void to(const Device & device)
+  {
+    if(v_ && device.index != device_) throw Exception("VPoser", "VPoserDecoder::to: move the decoder before its parameters are loaded");
+    device_ = device.index < 0 ? 0 : device.index;
+  }
   ~VPoserDecoder() { smplpp_vposer_destroy(v_); }
   VPoserDecoder(const VPoserDecoder &) = delete;
   VPoserDecoder & operator=(const VPoserDecoder &) = delete;

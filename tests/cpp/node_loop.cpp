@@ -185,10 +185,21 @@ int main(int argc, char ** argv)
   try
   {
     // ---- model setup (node/node.cpp:360-372, :412-415)
-    std::string devStr = "CUDA";
-    torch::Device device(devStr == "CPU" ? torch::kCPU : torch::kCUDA, 0);
+    std::unique_ptr<torch::Device> device;
+    {
+      std::string deviceType = "CUDA";
+      if(deviceType == "CPU")
+      {
+        device = std::make_unique<torch::Device>(torch::kCPU);
+      }
+      else if(deviceType == "CUDA")
+      {
+        device = std::make_unique<torch::Device>(torch::kCUDA);
+      }
+      device->set_index(0);
+    }
     g_smpl = std::make_shared<smplpp::SMPL>();
-    g_smpl->setDevice(device);
+    g_smpl->setDevice(*device);
     g_smpl->setModelPath(argv[1]);
     g_smpl->init();
 
@@ -292,7 +303,7 @@ int main(int argc, char ** argv)
       const int64_t warm = in.i64();
       const std::vector<float> th0 = in.f32(75);
       std::vector<uint8_t> valid(valid64.begin(), valid64.end());
-      for(int i = 0; i < 75; i++) g_theta.data[(size_t)i] = th0[(size_t)i];
+      g_theta = torch::from_blob(th0.data(), {75}).clone().view({smplpp::JOINT_NUM + 1, 3}); // (toTorchTensor<float>(..., true), :390-391)
       for(auto & ikTaskKV : g_ikTaskList) // :553-567
       {
         ikTaskKV.second.normalTaskWeight_ = 0.0;

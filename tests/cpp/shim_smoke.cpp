@@ -98,6 +98,8 @@ int main(int argc, char ** argv)
       // ---- smplpp::VPoserDecoder (include/smplpp/VPoser.h:53-90) and the latent IK layout
       auto vposer = std::make_shared<smplpp::VPoserDecoder>(0);
       vposer->loadParamsFromJson(vposer_json);
+      (*vposer)->eval();                              // node/node.cpp:437-438: the holder's calls
+      (*vposer)->to(smplpp::Device("CUDA", 0));
       smplpp::Tensor z({2, 32});
       for(int i = 0; i < 64; i++) z.data[(size_t)i] = 0.1f * std::cos(0.37f * (float)i);
       smplpp::Tensor jac;
