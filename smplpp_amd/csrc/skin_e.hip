@@ -52,8 +52,11 @@ constexpr int E_RD_AHEAD = SKINE_RD_AHEAD;           // slots between a matrix r
 constexpr int E_ROOT_P = 2;                          // row slot that reads the root translation (first used in slot 9)
 constexpr int E_GCHUNKS = E_G_BYTES / (256 * 16);    // 18 DMAs of 1 KiB per wavefront
 constexpr int E_GDMA0 = 12 * E_SLOTS + E_BAR + 1;    // 223: first slot of the G' DMAs of a run's first item (one per slot)
-constexpr int E_A_PRE = 4;                           // k-steps of A fragments the frame tile set-up loads; a run's first item loads the
-constexpr int E_A_SLOT = 13;                         // fragments of k-step KS + 4 in slot 13 of k-step KS (three plain loads)
+#ifndef SKINE_A_PRE
+#define SKINE_A_PRE 4
+#endif
+constexpr int E_A_PRE = SKINE_A_PRE;                 // k-steps of A fragments the frame tile set-up loads; a run's first item loads the
+constexpr int E_A_SLOT = 13;                         // fragments of k-step KS + E_A_PRE in slot 13 of k-step KS (three plain loads)
 #ifndef SKINE_ABL
 #define SKINE_ABL 0 // timing ablations (development only; results are wrong when non-zero): 1 no epilogue, 2 no ring DMA, 4 no MFMA, 8 no barrier, 16 no fragment reads, 32 no stores, 512 per-workgroup timestamps
 #endif
@@ -163,8 +166,8 @@ static_assert(E_LDS_TOTAL <= 160 * 1024, "LDS plan");
 static_assert(E_ROW_END < 12 * E_SLOTS + E_BAR, "the rows end before the slots a run's first item uses for its G' DMAs");
 static_assert(E_ROW0 + 1 - E_RD_AHEAD > E_BAR, "the first G' read of an item follows the barrier that publishes the tile");
 static_assert(E_GDMA0 + E_GCHUNKS <= E_NSLOT, "the G' DMAs fit the item");
-static_assert(e_barrier_vmcnt(0, true, false) == 5 && e_barrier_vmcnt(1, false, false) == 10 + 3 && e_barrier_vmcnt(3, false, false) == 10 + 9 && e_barrier_vmcnt(3, true, false) == 10 + 3 &&
-                  e_barrier_vmcnt(13, false, false) == 10 + 17 && e_barrier_vmcnt(5, true, false) == 10 + 4 && e_barrier_vmcnt(5, false, false) == 10 + 9,
+static_assert(e_barrier_vmcnt(0, true, false) == 5 && (E_A_PRE != 4 || (e_barrier_vmcnt(1, false, false) == 10 + 3 && e_barrier_vmcnt(3, false, false) == 10 + 9 && e_barrier_vmcnt(5, false, false) == 10 + 9 && e_barrier_vmcnt(13, false, false) == 10 + 17)) &&
+                  e_barrier_vmcnt(3, true, false) == 10 + 3 && e_barrier_vmcnt(5, true, false) == 10 + 4,
               "window bookkeeping");
 
 template<int LGKM, int VM>
@@ -553,27 +556,34 @@ __global__ __launch_bounds__(256, 1) void skin_kernel_e(const uint8_t * __restri
         asm volatile("s_nop 1");
         ESB();
       }
-      float m[3][4];
+      // (no MFMA is in flight here: packed fp32 math, two FMAs per instruction — the same products and sums as the slot stream's)
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      v2f mlo[3], mhi[3];
 #pragma unroll
       for(int g = 0; g < 12; g++)
       {
         const float w = prev.jw[g % 4];
         const v4f gm = gd[R & 1][g];
-        float * mm = m[g / 4];
+        const v2f w2 = {w, w}, glo = {gm.x, gm.y}, ghi = {gm.z, gm.w};
         if(g % 4 == 0)
         {
-          mm[0] = w * gm.x;
-          mm[1] = w * gm.y;
-          mm[2] = w * gm.z;
-          mm[3] = w * gm.w;
+          mlo[g / 4] = w2 * glo;
+          mhi[g / 4] = w2 * ghi;
         }
         else
         {
-          mm[0] = __builtin_fmaf(w, gm.x, mm[0]);
-          mm[1] = __builtin_fmaf(w, gm.y, mm[1]);
-          mm[2] = __builtin_fmaf(w, gm.z, mm[2]);
-          mm[3] = __builtin_fmaf(w, gm.w, mm[3]);
+          mlo[g / 4] = __builtin_elementwise_fma(w2, glo, mlo[g / 4]);
+          mhi[g / 4] = __builtin_elementwise_fma(w2, ghi, mhi[g / 4]);
         }
+      }
+      float m[3][4];
+#pragma unroll
+      for(int c = 0; c < 3; c++)
+      {
+        m[c][0] = mlo[c].x;
+        m[c][1] = mlo[c].y;
+        m[c][2] = mhi[c].x;
+        m[c][3] = mhi[c].y;
       }
       // (the slot stream's operations in the slot stream's order: tools/fk_e_check.py compares the two paths bit for bit)
       float t[3];

@@ -2,7 +2,7 @@
 tools/collect_profiles.sh): HBM bytes per launch of the fused FK kernel = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — FETCH_SIZE
 and WRITE_SIZE are in KB, and on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced streaming reads
 (MI355X_MICROARCH.md, HBM section; this kernel's reads are 16 B-per-lane LDS-DMA and register loads).
-usage: python tools/make_traffic_json.py <pmc_summary.txt> <out.json> [frames] [tag] [kernel_stats.csv]
+usage: python tools/make_traffic_json.py <pmc_summary.txt> <out.json> [frames] [tag] [kernel_stats.csv ...]
 (tag + kernel_stats.csv: the round tag of the collection and the kernel-trace stats of THE SAME collection run — the fused kernel's
 average duration under rocprofv3 is recorded beside the byte counts, so the reader of bench.py's `roofline.traffic` can see which
 run the constant came from: bench.py copies `tag` into `roofline.traffic_source`)"""
@@ -11,7 +11,7 @@ import json, re, sys
 src, dst = sys.argv[1], sys.argv[2]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 tag = sys.argv[4] if len(sys.argv) > 4 else None
-stats = sys.argv[5] if len(sys.argv) > 5 else None
+stats = sys.argv[5:]  # kernel-trace stats of the same collection (one file per form traced)
 cur, vals = None, {}
 for ln in open(src):
     if not ln.startswith(" "):
@@ -39,10 +39,10 @@ out["how"] = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (too
               "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md")
 if tag:
     out["tag"] = tag
-if stats:
-    import csv
+import csv
 
-    for r in csv.DictReader(open(stats)):
+for st in stats:
+    for r in csv.DictReader(open(st)):
         m = re.search(r"skin_kernel_?([a-z])?", r["Name"])
         if m:
             out["skin_kernel_%s_rocprofv3_avg_us_same_run" % (m.group(1) or "v")] = float(r["AverageNs"]) / 1e3
