@@ -104,12 +104,13 @@ constexpr int HB_A_BYTES = 4 * 1024;   // A pieces of one (frame tile, k-step)
 constexpr int HB_IMG = 12 * 1024;      // one slot of B2h = one LDS ring image
 constexpr int HB_G_BYTES = 72 * 1024;  // G2h of one frame tile
 constexpr int HB_CW_OFF = 8 * 1024;    // cw[64] inside slot 14
-// Round 5: the vertex groups of this form are NOT runs of consecutive vertices.  Model creation sorts the vertices by which of the
-// skinning product's two k-steps their weights touch (joints 0..15 | joints 16..23: for SMPL the arms), cuts the sorted list into
-// groups of 64 and deals the groups over the XCD slices with the classes interleaved; slot 14 carries, behind cw, the group's
-// vertex ids (perm[64], -1 = no vertex: the outputs go to the ORIGINAL positions) and one word of flags — bit 0: some vertex of
-// the group has a weight on joints 0..15, bit 1: on joints 16..23.  A group with one bit skips the other k-step's blend MFMAs and
-// G' fragment reads (3 or 2 MFMAs per entry instead of 5); the products it skips are exact zeros, so no bit of the result moves.
+// Round 5: a vertex group is 64 CONSECUTIVE vertices, classified by which of the skinning product's two k-steps its vertices'
+// weights touch (joints 0..15 | joints 16..23: for SMPL the arms).  Model creation deals the groups over the eight XCD slices with the
+// classes interleaved, and interleaves them again inside a slice; slot 14 carries, behind cw, the group's vertex ids (perm[64], -1 =
+// no vertex: the outputs go to the ORIGINAL positions) and one word of flags — bit 0: some vertex of the group has a weight on joints
+// 0..15, bit 1: on joints 16..23.  A group with one bit skips the other k-step's blend MFMAs and G' fragment reads (3 or 2 MFMAs per
+// entry instead of 5); the products it skips are exact zeros, so no bit of the result moves.  (Sorting the VERTICES by class first
+// was measured and rejected: 46 -> 62 us per step, the output rows of a group scattered over ~200 vertex positions.)
 constexpr int HB_PERM_OFF = HB_CW_OFF + 256;   // perm[64] int32
 constexpr int HB_FLAGS_OFF = HB_CW_OFF + 512;  // one int32
 constexpr float HB_SA = 64.0f;         // scale of the A operand (|c| <= 2, |beta| < 1023)

@@ -299,7 +299,7 @@ static char launch_form(const smplpp_model * m, int64_t n, int range_slot)
 // Pose step of a launch of form `form`: joints, relative transforms and the fused kernel's operand images (when `with_ops`) into
 // the model's workspace.
 static int fk_pose_device(smplpp_model * m, char form, int64_t n, const float * beta, const float * theta, float * joints, float * xforms44,
-                          float * poserot, hipStream_t st, int range_slot, bool with_ops)
+                          float * poserot, hipStream_t st, int * range_word, bool with_ops)
 {
   Workspace & ws = m->ws;
   const int64_t n64 = ((n + 63) / 64) * 64;
@@ -309,7 +309,7 @@ static int fk_pose_device(smplpp_model * m, char form, int64_t n, const float * 
     HIP_TRY(ws.A2h.reserve((size_t)(n64 / 64) * HB_KS * HB_A_BYTES));
     HIP_TRY(ws.G2h.reserve((size_t)(n64 / 64) * HB_G_BYTES));
     PoseArgs pa = fk_pose_args(m, n, beta, theta, joints, poserot, xforms44, with_ops);
-    pa.range_flag = m->range_flag + range_slot;
+    pa.range_flag = range_word;
     pose_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(pa);
   }
   else if(form == 'e' || form == 'b')
@@ -382,11 +382,13 @@ static int fk_skin_device(smplpp_model * m, char form, int64_t n, const float * 
   return SMPLPP_OK;
 }
 
+// range_word: where a launch of the fp16x2 form reports an operand outside its range — the model's word of `range_slot`, or the word
+// of the IK solver whose loop the launch belongs to (each solver has its own: one solver's overflow is not another's status bit)
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
-              float * xforms44, float * rest, float * poserot, hipStream_t st, int range_slot)
+              float * xforms44, float * rest, float * poserot, hipStream_t st, int range_slot, int * range_word)
 {
   const char form = launch_form(m, n, range_slot);
-  int rc = fk_pose_device(m, form, n, beta, theta, joints, xforms44, poserot, st, range_slot, verts || rest);
+  int rc = fk_pose_device(m, form, n, beta, theta, joints, xforms44, poserot, st, range_word ? range_word : m->range_flag + range_slot, verts || rest);
   if(rc) return rc;
   return fk_skin_device(m, form, n, theta, verts, rest, st);
 }
@@ -453,7 +455,7 @@ extern "C" int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const 
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   TraceRange tr_fwd("forward SMPL"); // the reference's span around SMPL::launch (node/node.cpp:752-781)
-  if(space == SMPLPP_DEVICE) return fk_device(m, n, beta, theta, verts, joints, xforms, rest, nullptr, st, RANGE_DEVICE);
+  if(space == SMPLPP_DEVICE) return fk_device(m, n, beta, theta, verts, joints, xforms, rest, nullptr, st, RANGE_DEVICE, nullptr);
 
   Workspace & ws = m->ws;
   const size_t nb = sizeof(float) * (size_t)n * NB, nt = sizeof(float) * (size_t)n * (NJ + 1) * 3;
@@ -471,7 +473,7 @@ extern "C" int smplpp_fk(smplpp_model * m, int64_t n, const float * beta, const 
   if(ranged) HIP_TRY(hipMemsetAsync(m->range_flag + RANGE_HOST, 0, sizeof(int), st));
   int rc = fk_device(m, n, ws.beta.as<float>(), ws.theta.as<float>(), verts ? ws.verts.as<float>() : nullptr,
                      joints ? ws.joints.as<float>() : nullptr, xforms ? ws.xf44.as<float>() : nullptr,
-                     rest ? ws.rest.as<float>() : nullptr, nullptr, st, RANGE_HOST);
+                     rest ? ws.rest.as<float>() : nullptr, nullptr, st, RANGE_HOST, nullptr);
   if(rc) return rc;
   if(verts) HIP_TRY(hipMemcpyAsync(verts, ws.verts.p, nv, hipMemcpyDeviceToHost, st));
   if(rest) HIP_TRY(hipMemcpyAsync(rest, ws.rest.p, nv, hipMemcpyDeviceToHost, st));

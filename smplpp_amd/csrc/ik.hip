@@ -30,7 +30,7 @@ struct smplpp_vposer;
 namespace smplpp_hip
 {
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
-              float * xforms44, float * rest, float * poserot, hipStream_t st, int range_slot);
+              float * xforms44, float * rest, float * poserot, hipStream_t st, int range_slot, int * range_word = nullptr);
 int vposer_forward_device(smplpp_vposer * v, int64_t n, const float * z, int64_t z_stride, float * out, int64_t out_stride,
                           float * jac, hipStream_t st, int64_t frame_base, bool value_like_jac = false, unsigned * sig_flag = nullptr,
                           unsigned * sig_counter = nullptr, unsigned sig_tick = 0u);
@@ -3061,6 +3061,7 @@ struct smplpp_ik
   float *verts = nullptr, *rest = nullptr, *joints = nullptr, *poserot = nullptr, *pts = nullptr;
   double *e = nullptr, *J = nullptr, *Jl = nullptr, *e2 = nullptr, *xout = nullptr;
   int *skip = nullptr, *status = nullptr, *sticky = nullptr, *list_cnt = nullptr, *list_f = nullptr;
+  int * range_word = nullptr; // this solver's own "an operand left the fp16x2 form's range" word (status bit 3): its loops' forward passes report here
   int32_t * roles = nullptr; // [DMAX][EVAL_NT] the chain-derivative entries of every thread of ik_eval_kernel (slot u: row u)
   float * list_d = nullptr;
   std::vector<void *> owned;
@@ -3218,7 +3219,8 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
     if((e = getenv("SMPLPP_SCAN_BLOCKS"))) s->scan_blocks = atoll(e);
     if((e = getenv("SMPLPP_SCAN_FORM"))) s->scan_form = atoi(e);
     s->latent_split = vposer != nullptr && n <= 128 && s->dbg_stop == 0;
-    if((e = getenv("SMPLPP_IK_LATENT_SPLIT"))) s->latent_split = vposer != nullptr && e[0] != '0';
+    // (a debug stop ends the solve kernel in front of its "configuration final" flag: never beside the schedule that waits for it)
+    if((e = getenv("SMPLPP_IK_LATENT_SPLIT"))) s->latent_split = vposer != nullptr && e[0] != '0' && s->dbg_stop == 0;
   }
   const size_t nk = (size_t)n * K;
   const size_t Dmax = TD75 + 2 * K + NB;
@@ -3266,6 +3268,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   A_(skip, (size_t)n);
   A_(status, (size_t)n);
   A_(sticky, (size_t)n);
+  A_(range_word, 1);
   s->ta.flags = s->sticky;
   if(vposer)
   {
@@ -3304,6 +3307,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   S_TRY(hipMemset(s->list_cnt, 0, sizeof(int) * nk));
   S_TRY(hipMemset(s->status, 0, sizeof(int) * n));
   S_TRY(hipMemset(s->sticky, 0, sizeof(int) * n));
+  S_TRY(hipMemset(s->range_word, 0, sizeof(int)));
   s->verts = s->vbuf[0];
   // (default priority: a lowest-priority side stream — tried against the scan being dispatched ahead of the solve — halved the
   // latent-IK leg of bench.py, where several solvers' streams exist; what fixes that order is the solve kernel's own "all my
@@ -3397,7 +3401,7 @@ extern "C" int smplpp_ik_set_config(smplpp_ik * s, const float * beta, const flo
   s->jac_ahead = false; // (a Jacobian made ahead belongs to the configuration it was made for)
   HIP_TRY(hipMemset(s->status, 0, sizeof(int) * s->n));
   HIP_TRY(hipMemset(s->sticky, 0, sizeof(int) * s->n));
-  if(s->m->range_flag) HIP_TRY(hipMemset(s->m->range_flag + RANGE_INTERNAL, 0, sizeof(int))); // (status bit 3: same lifetime)
+  if(s->range_word) HIP_TRY(hipMemset(s->range_word, 0, sizeof(int))); // (status bit 3: same lifetime; this solver's own word)
   if(theta && s->vp) // latent layout: the entries that pass through to theta25 (the decoder fills the rest at every evaluation)
   {
     ik_splice_kernel<<<dim3((unsigned)((s->n * 75 + 255) / 256)), 256>>>(s->theta, nullptr, s->theta25, s->n);
@@ -3475,7 +3479,7 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
     }
     s->vcur ^= 1;
     s->verts = s->vbuf[s->vcur];
-    int rc = fk_device(m, n, s->beta, th25, s->verts, s->joints, nullptr, s->rest, s->poserot, st, RANGE_INTERNAL); // node.cpp:777
+    int rc = fk_device(m, n, s->beta, th25, s->verts, s->joints, nullptr, s->rest, s->poserot, st, RANGE_INTERNAL, s->range_word); // node.cpp:777
     if(rc) return rc;
   }
   TraceRange tr_eval("calculate IK matrices"); // node.cpp:796-881
@@ -3907,11 +3911,11 @@ extern "C" int smplpp_ik_get_status(smplpp_ik * s, int32_t * flags, int space, v
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipMemcpy(a.data(), s->status, sizeof(int) * s->n, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(b.data(), s->sticky, sizeof(int) * s->n, hipMemcpyDeviceToHost));
-  // bit 3: a forward pass INSIDE the loops of a solver on this model met an operand outside the fp16x2 form's range since the last
-  // set_config (one word per model — which frame is not recorded, so every frame of the batch carries it; such a frame's vertices
-  // are not finite and its solve then fails on its own)
+  // bit 3: a forward pass INSIDE this solver's loops met an operand outside the fp16x2 form's range since the last set_config
+  // (one word per solver — which frame is not recorded, so every frame of the batch carries it; such a frame's vertices are not
+  // finite and its solve then fails on its own)
   int internal = 0;
-  if(s->m->range_flag && s->m->form_ik == 'h') HIP_TRY(hipMemcpy(&internal, s->m->range_flag + RANGE_INTERNAL, sizeof(int), hipMemcpyDeviceToHost));
+  if(s->range_word && s->m->form_ik == 'h') HIP_TRY(hipMemcpy(&internal, s->range_word, sizeof(int), hipMemcpyDeviceToHost));
   std::vector<int32_t> h((size_t)s->n);
   for(int64_t f = 0; f < s->n; f++)
     h[(size_t)f] = (a[(size_t)f] == 1 ? 1 : 0) | ((b[(size_t)f] & 1) ? 2 : 0) | (b[(size_t)f] & 4) | ((internal & 1) ? 8 : 0);

@@ -499,13 +499,11 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
           if(W[v * NJ + j] != 0.0f) (j < 16 ? lo : hi) = true;
         vcls[(size_t)v] = hi ? (lo ? 1 : 2) : 0;
       }
-      std::vector<int32_t> order((size_t)V);
-      for(int64_t v = 0; v < V; v++) order[(size_t)v] = (int32_t)v;
       std::vector<int> tflags((size_t)nvg, 0);
       for(int64_t t = 0; t < nvg; t++)
         for(int i = 0; i < 64 && t * 64 + i < V; i++)
         {
-          const int c = vcls[(size_t)order[(size_t)(t * 64 + i)]];
+          const int c = vcls[(size_t)(t * 64 + i)];
           tflags[(size_t)t] |= (c == 0 ? 1 : (c == 1 ? 3 : 2));
         }
       // (2) + (3): per XCD slice the sorted groups it is dealt, then their order inside the slice
@@ -535,7 +533,7 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
         for(auto & kt : keyed)
         {
           const int64_t t = kt.second;
-          for(int i = 0; i < 64 && t * 64 + i < V; i++) hperm[(size_t)(g * 64 + i)] = order[(size_t)(t * 64 + i)];
+          for(int i = 0; i < 64 && t * 64 + i < V; i++) hperm[(size_t)(g * 64 + i)] = (int32_t)(t * 64 + i);
           gflags[(size_t)g] = tflags[(size_t)t] ? tflags[(size_t)t] : 1;
           g++;
         }

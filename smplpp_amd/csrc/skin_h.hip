@@ -22,9 +22,9 @@
 // (buffer_load_dwordx4 ... lds) seven slots ahead; slot 14 of an item carries the group's skinning weights.
 // One raw s_barrier per slot publishes the next image (counted vmcnt: DMAs stay in flight across it).
 // XCD x owns an eighth of the vertex groups (its slice of B2h, 2.4 MB, lives in that XCD's L2 and is read from HBM once).
-// Round 5: a vertex group is 64 vertices of ONE skinning class where the model allows it (common.h, HB_PERM_OFF: the groups are cut
-// from the vertices sorted by which k-step of the skinning product their weights touch; slot 14 carries the group's vertex ids and
-// its flags).  A group whose weights live in one k-step runs the skinning phase in the instantiation that issues only that k-step's
+// Round 5: a vertex group is 64 CONSECUTIVE vertices with a skinning class (common.h, HB_PERM_OFF: which k-steps of the skinning
+// product its vertices' weights touch; the groups are dealt over and inside the XCD slices with the classes interleaved; slot 14
+// carries the group's vertex ids and its flags).  A group whose weights live in one k-step runs the skinning phase in the instantiation that issues only that k-step's
 // MFMAs and G' fragment reads — 3 (joints 0..15 only) or 2 (joints 16..23 only) MFMAs per entry instead of 5; exact zeros skipped.
 #include "common.h"
 

@@ -6,7 +6,7 @@
 namespace smplpp_hip
 {
 int fk_device(smplpp_model * m, int64_t n, const float * beta, const float * theta, float * verts, float * joints,
-              float * xforms44, float * rest, float * poserot, hipStream_t st, int range_slot);
+              float * xforms44, float * rest, float * poserot, hipStream_t st, int range_slot, int * range_word = nullptr);
 __device__ void rodrigues_dev_stage(float t0, float t1, float t2, float * R);
 
 __device__ void rodrigues_dev_stage(float t0, float t1, float t2, float * R)

@@ -59,6 +59,21 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
+class _CountingWriter:
+    """forwards to a stream and counts what went through (launch_ranks: has rank 0 said anything yet?)"""
+
+    def __init__(self, dst):
+        self.dst, self.count = dst, 0
+
+    def write(self, text):
+        self.count += len(text)
+        return self.dst.write(text)
+
+    def flush(self):
+        return self.dst.flush()
+
+
+RENDEZVOUS_SECONDS = 30.0  # a bind failure later than this is not the rendezvous
 TAIL_LINES = 40  # of a failed rank's stderr, repeated under a header once the job has stopped
 PORT_RETRIES = 3
 
@@ -81,12 +96,20 @@ def launch_ranks(argv: Sequence[str], world: int, extra_env: Optional[dict] = No
     stdout = sys.stdout if stdout is None else stdout
     stderr = sys.stderr if stderr is None else stderr
     rc = 0
+    t_all = time.monotonic()
     for attempt in range(PORT_RETRIES):
-        rc, tails = _launch_once(argv, world, extra_env, timeout, stdout, stderr)
+        left = None if timeout is None else max(1.0, timeout - (time.monotonic() - t_all))  # `timeout` covers ALL attempts
+        counted = _CountingWriter(stdout)
+        t0 = time.monotonic()
+        rc, tails = _launch_once(argv, world, extra_env, left, counted, stderr)
         if rc == 0:
             return 0
-        text = "".join("".join(t) for t in tails.values())
-        if attempt + 1 < PORT_RETRIES and ("EADDRINUSE" in text or "Address already in use" in text or "address already in use" in text):
+        # only a failure of the RENDEZVOUS is retried: the bind error in rank 0's tail, within seconds of the start, and nothing of
+        # rank 0's stdout forwarded yet (a bind error minutes into a job is someone else's socket; a second run would repeat output)
+        text = "".join(tails.get(0, ()))
+        early = time.monotonic() - t0 < RENDEZVOUS_SECONDS and counted.count == 0
+        bind = ("EADDRINUSE" in text or "Address already in use" in text or "address already in use" in text)
+        if attempt + 1 < PORT_RETRIES and early and bind:
             stderr.write("launch_ranks: the rendezvous port was taken by someone else; starting the ranks again on another port\n")
             continue
         return rc

@@ -387,3 +387,53 @@ def test_value_only_instantiation_decodes_the_jacobian_kernels_bits(decoders):
         val = np.full((n, 21, 3), np.nan, np.float32)
         assert L.smplpp_debug_vposer_value(gpu._h, n, base, z.ctypes.data_as(C.c_void_p), val.ctypes.data_as(C.c_void_p)) == 0, L.smplpp_last_error()
         assert np.array_equal(val, out), (n, base, float(np.abs(val - out).max()))
+
+
+def test_decoder_jacobian_is_finite_at_the_axis_angle_branch_points():
+    """tests/src/TestVPoser.cpp:36-43 on the GPU path: the reference checks that the gradient of convertRotMatToAxisAngle has no NaN
+    at the identity (angle 0: the Taylor branch, src/VPoser.cpp:105-111) and at a rotation by pi (the sqrt-diagonal branch, :53-103,
+    kept finite by the (1 - eps) shrink inside acos and the eps under the sqrt, :41, :60).  Here the decoder's last layer is
+    biased so that, at z = 0, its 21 joints decode EXACTLY to those rotations — identity, pi about x / y / z and about oblique axes,
+    and rotations 1e-4 rad and 1e-3 rad from either branch point — with small random weights in front, so that d(out)/dz is the
+    derivative of the axis-angle conversion times a non-zero matrix: values and Jacobian must be finite, the decoded rotations
+    must be the intended ones, and both must agree with the torch restatement (whose backward() is the reference's own formula)."""
+    from scipy.spatial.transform import Rotation
+    from oracle import vposer_torch as VT
+    from smplpp_amd.ik import VPoserDecoder
+
+    rng = np.random.default_rng(12)
+    axes = [np.array(a, np.float64) / np.linalg.norm(a) for a in
+            ([1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [1, -2, 3], [0.3, 0.5, -0.8], [-1, 0.2, 0.1])]
+    rots = [np.eye(3)]
+    rots += [Rotation.from_rotvec(np.pi * a).as_matrix() for a in axes]                      # exactly pi
+    rots += [Rotation.from_rotvec((np.pi - d) * a).as_matrix() for a in axes[:3] for d in (1e-4, 1e-3)]  # just below pi
+    rots += [Rotation.from_rotvec(d * a).as_matrix() for a in axes[3:6] for d in (1e-4, 1e-3)]          # just above 0
+    rots += [Rotation.from_rotvec(0.7 * axes[4]).as_matrix()]                                # a generic one
+    assert len(rots) == 21
+    R = np.stack(rots)
+    params = VPoserDecoder.synthetic_params(seed=8)
+    params["decoder_net.5.weight"] = (params["decoder_net.5.weight"] * np.float32(0.05)).astype(np.float32)
+    # 6D representation: the rotation's first two columns, stored [3, 2] per joint (src/VPoser.cpp:129-141); the bias is the whole
+    # output at z = 0 once the hidden layers' contribution is taken off: solve for it with the torch restatement
+    target = R[:, :, :2].reshape(-1).astype(np.float32)
+    params["decoder_net.5.bias"] = np.zeros(126, np.float32)
+    hidden0 = VT.VPoserDecoder(params).net(torch.zeros(1, 32)).detach().numpy()[0]
+    params["decoder_net.5.bias"] = (target - hidden0).astype(np.float32)
+    gpu, ref = VPoserDecoder(params), VT.VPoserDecoder(params)
+    z = np.zeros((3, 32), np.float32)
+    z[1] = rng.normal(0, 1e-3, 32)  # a hair off the branch points
+    z[2] = rng.normal(0, 0.3, 32)
+    out, jac = gpu.forward(z, want_jac=True)
+    assert np.isfinite(out).all() and np.isfinite(jac).all()
+    got = Rotation.from_rotvec(out[0].astype(np.float64)).as_matrix()
+    assert np.abs(got - R).max() < 2e-3  # (fp32 through acos / sqrt at pi: the angle itself is exact to ~4e-4 there)
+    rout, rjac = ref.forward_with_jacobian(z)
+    assert np.isfinite(rjac).all()
+    # away from pi the two fp32 evaluations agree tightly; at pi the axis may flip sign (both are the same rotation)
+    same = np.abs(Rotation.from_rotvec(out.reshape(-1, 3).astype(np.float64)).as_matrix()
+                  - Rotation.from_rotvec(rout.reshape(-1, 3).astype(np.float64)).as_matrix()).max()
+    assert same < 2e-3
+    near0 = [0] + list(range(14, 21))
+    assert np.abs(out[:, near0] - rout[:, near0]).max() < 5e-6
+    rows = np.concatenate([np.arange(3 * j, 3 * j + 3) for j in near0])
+    assert np.abs(jac[:, rows] - rjac[:, rows]).max() < 2e-4 * max(1.0, np.abs(rjac[:, rows]).max())
