@@ -425,13 +425,18 @@ def test_decoder_jacobian_is_finite_at_the_axis_angle_branch_points():
     z[2] = rng.normal(0, 0.3, 32)
     out, jac = gpu.forward(z, want_jac=True)
     assert np.isfinite(out).all() and np.isfinite(jac).all()
+    # Exactly pi about an axis with components of BOTH signs (joints 5, 6, 7) is where the reference's own sign fixes
+    # (src/VPoser.cpp:62-103) return the axis-angle of a DIFFERENT rotation (the torch restatement, run on the CPU: 0.4-1.0 off the
+    # intended matrix) and where one fp32 ulp decides which fix fires: there only finiteness is asserted.  Everywhere else the
+    # decoded rotation is the intended one (7e-4 at pi: acos((1 - eps) x) and sqrt(s + eps) bound the angle away from pi) and the
+    # engine agrees with the restatement.
+    ok = np.array([j for j in range(21) if j not in (5, 6, 7)])
     got = Rotation.from_rotvec(out[0].astype(np.float64)).as_matrix()
-    assert np.abs(got - R).max() < 2e-3  # (fp32 through acos / sqrt at pi: the angle itself is exact to ~4e-4 there)
+    assert np.abs(got[ok] - R[ok]).max() < 2e-3
     rout, rjac = ref.forward_with_jacobian(z)
     assert np.isfinite(rjac).all()
-    # away from pi the two fp32 evaluations agree tightly; at pi the axis may flip sign (both are the same rotation)
-    same = np.abs(Rotation.from_rotvec(out.reshape(-1, 3).astype(np.float64)).as_matrix()
-                  - Rotation.from_rotvec(rout.reshape(-1, 3).astype(np.float64)).as_matrix()).max()
+    same = np.abs(Rotation.from_rotvec(out[:, ok].reshape(-1, 3).astype(np.float64)).as_matrix()
+                  - Rotation.from_rotvec(rout[:, ok].reshape(-1, 3).astype(np.float64)).as_matrix()).max()
     assert same < 2e-3
     near0 = [0] + list(range(14, 21))
     assert np.abs(out[:, near0] - rout[:, near0]).max() < 5e-6
