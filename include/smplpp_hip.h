@@ -195,8 +195,9 @@ int smplpp_ik_get_vertices(smplpp_ik * s, float * verts, int space, void * strea
 /* Outcome of the solves so far, per frame: bit 0 = the LAST solve failed with the reference's "LLT has numerical issue!"
  * (node/node.cpp:934-937; that frame's update was skipped), bit 1 = some solve failed since the configuration was set /
  * the sequence started, bit 2 = an evaluation since the tasks were last set met a task WITH A NORMAL TERM (normal weight or normal
- * offset) on a vertex of more than 12 adjacent faces: the analytic Jacobian differentiates vertex normals through tables of 12 faces
- * per vertex (src/SMPL.cpp:527-535 puts no bound on it), so those rows are unsupported — the solve SKIPS the update of such a frame
+ * offset) on a vertex of more than 16 adjacent faces: the analytic Jacobian differentiates vertex normals through per-face tables
+ * whose width smplpp_model_create takes from the topology — 12 faces per vertex, 16 when some vertex has more (SMPL's own mesh:
+ * at most 9; src/SMPL.cpp:527-535 puts no bound on it) — so beyond 16 those rows are unsupported — the solve SKIPS the update of such a frame
  * (no caller moves on a truncated Jacobian) and smplpp_ik_set_tasks clears the bit (it belongs to the tasks; the next evaluation
  * raises it again where it still applies); position-only tasks are unaffected and any model gets its solver.  Bit 3 = a forward
  * pass inside a loop on this model met an operand outside the fp16x2 form's range since the last smplpp_ik_set_config (one word per

@@ -34,7 +34,8 @@ constexpr int TREE_ANC = 0, TREE_LVL = SMPLPP_JOINT_NUM, TREE_LVLJ = TREE_LVL + 
 // slots of smplpp_model::range_flag: enqueue-only user launches (read by smplpp_fk_status), host-space user launches (each reads
 // its own), launches from inside the IK / VPoser loops (intermediate iterates; the solve's own status reports what matters there)
 constexpr int RANGE_DEVICE = 0, RANGE_HOST = 1, RANGE_INTERNAL = 2, RANGE_SLOTS = 4;
-constexpr int MAXADJ = 12;                    // adjacent faces per vertex the IK normal Jacobian differentiates through
+constexpr int MAXADJ = 12;                    // adjacent faces per vertex the IK normal Jacobian's tables hold by default (SMPL's mesh: at most 9)
+constexpr int MAXADJ_WIDE = 16;               // ... for a topology with a vertex of 13..16 faces (smplpp_model::madj; its own instantiation of the evaluation)
 constexpr int MAXRING = 3 * (MAXADJ + 1) + 1; // distinct vertices an IK task can touch: its face's and those of the faces around them
 // Column layout of the B operand: vertex group g = v / 32 owns columns [96 g, 96 g + 96): 32 x, then 32 y, 32 z.
 constexpr int VG = 32;
@@ -237,9 +238,10 @@ struct smplpp_model
   int32_t * faces = nullptr;   // [F][3] 0-based
   int32_t * adjOff = nullptr;  // [V+1]
   int32_t * adjFace = nullptr; // [adjOff[V]] ascending face id per vertex
-  uint16_t * faceRing = nullptr; // [F][MAXRING + 1] IK ring of a task on face f: count, the face's three vertices, then the distinct
+  int madj = smplpp_hip::MAXADJ;  // width of the IK ring tables below: MAXADJ, or MAXADJ_WIDE when some vertex has more than MAXADJ adjacent faces
+  uint16_t * faceRing = nullptr; // [F][3 (madj + 1) + 2] IK ring of a task on face f: count, the face's three vertices, then the distinct
                                  // vertices of the faces adjacent to them in (vertex, adjacent face, corner) order (V <= 65535)
-  uint8_t * faceMap = nullptr;   // [F][3 MAXADJ 3] (vertex of the face, adjacent face, corner) -> slot in that ring
+  uint8_t * faceMap = nullptr;   // [F][3 madj 3] (vertex of the face, adjacent face, corner) -> slot in that ring
   int32_t * anc = nullptr;       // [TREE_SIZE] tree tables of the IK evaluation (TREE_* above)
   float * Wdense = nullptr;    // [V][24] original weights (stage entry points / IK)
   float * Pvm = nullptr;       // [V][3][207] posedirs, vertex-major (IK Jacobian: pose-corrective term of a few vertices)

@@ -76,8 +76,8 @@ struct ModelView
   const float * Pvm;
   const float * Svm;
   const float * JS;
-  const uint16_t * faceRing; // [F][MAXRING + 1] per face: ring size, then the ring (common.h)
-  const uint8_t * faceMap;   // [F][3 MAXADJ 3] (vertex of the face, adjacent face, corner) -> ring slot
+  const uint16_t * faceRing; // [F][3 (madj + 1) + 2] per face: ring size, then the ring (common.h; madj = the model's table width: 12 or 16)
+  const uint8_t * faceMap;   // [F][3 madj 3] (vertex of the face, adjacent face, corner) -> ring slot
   const int32_t * anc;       // [TREE_SIZE] tree tables (common.h): ancestor masks, joints by level
   int nlev;
   int64_t V;
@@ -294,7 +294,7 @@ __device__ unsigned long long g_solve_stamps[64 * 16];
 // so a workgroup only has to wait for its own stores: a device-scope release fence per workgroup would write back the whole
 // L2 of its XCD 256 times per kernel — including the lines of the kernel running beside it (the fused FK kernel went from 17
 // to 28 us that way).
-template<int DMAX, int RCAP, int NGN>
+template<int DMAX, int RCAP, int NGN, int MADJ>
 __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArrays & ta, const float * __restrict__ theta25,
                                              const float * __restrict__ verts_all, const float * __restrict__ rest_all,
                                              const float * __restrict__ Gp, const float * __restrict__ joints,
@@ -305,6 +305,9 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
                                              const float * __restrict__ vjac, double * __restrict__ Jl_out)
 {
   typedef EvalPlan<DMAX, RCAP, NGN> Plan;
+  // MADJ: adjacent faces per vertex the normal Jacobian's tables hold (the model's: 12, or 16 for a topology with a vertex of
+  // 13..16 faces — smplpp_model::madj; the per-face tables faceRing / faceMap are built with the same strides)
+  constexpr int MRING = 3 * (MADJ + 1) + 1; // distinct vertices a task can touch
   constexpr int CS = Plan::CS, L_DBB = Plan::L_DBB, L_RV = Plan::L_RV, L_DP = Plan::L_DP, L_VN = Plan::L_VN, L_END = Plan::L_END;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_tree[TREE_SIZE];
@@ -339,8 +342,8 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   // dependent pair face id -> ring list (two round trips) then runs beside the set-up and the chain-derivative steps instead
   // of in front of phase A.  (The re-projection that wrote faces, weights and targets has been waited for by the stream.)
   const int ntask = (k_end > k_begin) ? k_end - k_begin : 0; // (a part beyond the last task — more parts than tasks — has none)
-  const bool a0_live = tid < ntask * (MAXRING + 1); // A0's first pass: one (task, ring-list word) per thread
-  const int a0_t = a0_live ? tid / (MAXRING + 1) : 0, a0_q = a0_live ? tid % (MAXRING + 1) : 0;
+  const bool a0_live = tid < ntask * (MRING + 1); // A0's first pass: one (task, ring-list word) per thread
+  const int a0_t = a0_live ? tid / (MRING + 1) : 0, a0_q = a0_live ? tid % (MRING + 1) : 0;
   // (a workgroup whose share of the tasks is empty — more parts than tasks — or a thread without an item reads task 0 of its
   // frame: every address requested here lies inside the task arrays)
   const int64_t a0_k = a0_live ? tb + k_begin + a0_t : tb;
@@ -352,7 +355,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   const float a3_w[3] = {ta.vw[a3_k * 3], ta.vw[a3_k * 3 + 1], ta.vw[a3_k * 3 + 2]};
   const float a3_tp[3] = {ta.tpos[a3_k * 3], ta.tpos[a3_k * 3 + 1], ta.tpos[a3_k * 3 + 2]};
   const float a3_tn[3] = {ta.tnrm[a3_k * 3], ta.tnrm[a3_k * 3 + 1], ta.tnrm[a3_k * 3 + 2]};
-  const uint16_t a0_e = mv.faceRing[(int64_t)a0_face * (MAXRING + 1) + a0_q];
+  const uint16_t a0_e = mv.faceRing[(int64_t)a0_face * (MRING + 1) + a0_q];
 
   // ---- set-up: every global load first (one round trip), then the frame constants into LDS
   static_assert(EVAL_NT >= NJ * 12 && IK_MAXK <= 64, "one element of each frame constant per thread; validity by one ballot");
@@ -531,24 +534,24 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   //   A2  one thread per (task, triangle vertex): vertex normal from those positions (tasks with a normal offset / term)
   //   A3  one thread per task: tangents, weight refresh, residual rows (node.cpp:803-820)
   __shared__ float s_vn[IK_MAXK][9];
-  __shared__ uint16_t s_ringb[IK_MAXK][MAXRING + 1]; // (vertex ids fit 16 bits: smplpp_ik_create checks V)
+  __shared__ uint16_t s_ringb[IK_MAXK][MRING + 1]; // (vertex ids fit 16 bits: smplpp_ik_create checks V)
   __shared__ uint8_t s_usen[IK_MAXK];               // the task differentiates a normal (normal term or normal offset)
   __shared__ int s_facel[IK_MAXK];                  // the task's face
   __shared__ uint8_t s_acnt[IK_MAXK][4];            // faces around each of its three vertices (<= 255: a larger count takes the general routine either way)
-  // posed positions of the ring vertices of every task of this workgroup: [task][MAXRING][3], in the dp buffer of phase B
+  // posed positions of the ring vertices of every task of this workgroup: [task][MRING][3], in the dp buffer of phase B
   // (free until then)
-  static_assert(IK_MAXK * MAXRING * 3 <= RCAP * 3 * NQ, "s_rpos must fit the L_DP region");
-  float(*s_rpos)[MAXRING][3] = reinterpret_cast<float(*)[MAXRING][3]>(lds + L_DP);
+  static_assert(IK_MAXK * MRING * 3 <= RCAP * 3 * NQ, "s_rpos must fit the L_DP region");
+  float(*s_rpos)[MRING][3] = reinterpret_cast<float(*)[MRING][3]>(lds + L_DP);
   // A0: ring lists from the per-face tables built with the model (topology only); the first pass from the words requested at
   // the kernel's start
-  for(int item = tid; item < ntask * (MAXRING + 1); item += EVAL_NT)
+  for(int item = tid; item < ntask * (MRING + 1); item += EVAL_NT)
   {
-    const int t = item / (MAXRING + 1), q = item % (MAXRING + 1);
+    const int t = item / (MRING + 1), q = item % (MRING + 1);
     const int k = k_begin + t;
     const bool first = item < EVAL_NT; // (item == tid)
     const bool use_normal = first ? ((a0_noff > 0.0f) || (a0_nrmw > 0.0f)) : ((ta.noff[tb + k] > 0.0f) || (ta.nrmw[tb + k] > 0.0f));
     const int face = first ? a0_face : ta.face[tb + k];
-    const uint16_t e = first ? a0_e : mv.faceRing[(int64_t)face * (MAXRING + 1) + q];
+    const uint16_t e = first ? a0_e : mv.faceRing[(int64_t)face * (MRING + 1) + q];
     // slots 0..2 = the face's own vertices; with a normal term / offset also the distinct vertices of the faces around them
     s_ringb[t][q] = (q == 0 && !use_normal) ? (uint16_t)3 : e;
     if(q == 0)
@@ -601,9 +604,9 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   }
   EVAL_STAMP(3);
   if(dbg_stop == 23) return;
-  for(int item = tid; item < ntask * MAXRING; item += EVAL_NT) // A1
+  for(int item = tid; item < ntask * MRING; item += EVAL_NT) // A1
   {
-    const int t = item / MAXRING, q = item % MAXRING;
+    const int t = item / MRING, q = item % MRING;
     if(q < s_ringb[t][0])
     {
       const int v = s_ringb[t][1 + q];
@@ -618,20 +621,20 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   // A2: SMPL::calcVertexNormal (src/SMPL.cpp:527-535) with the adjacent faces' corners taken by ring slot — the unit normals
   // of the adjacent faces one thread per (task, triangle vertex, adjacent face), then the uniform sum per vertex in the
   // reference's order
-  static_assert((IK_MAXK * MAXRING * 3 + IK_MAXK * 3 * MAXADJ * 3) <= RCAP * 3 * NQ, "s_rpos + s_fn must fit the L_DP region");
-  float(*s_fn)[3 * MAXADJ][3] = reinterpret_cast<float(*)[3 * MAXADJ][3]>(lds + L_DP + IK_MAXK * MAXRING * 3);
-  for(int item = tid; item < ntask * 3 * MAXADJ; item += EVAL_NT)
+  static_assert((IK_MAXK * MRING * 3 + IK_MAXK * 3 * MADJ * 3) <= RCAP * 3 * NQ, "s_rpos + s_fn must fit the L_DP region");
+  float(*s_fn)[3 * MADJ][3] = reinterpret_cast<float(*)[3 * MADJ][3]>(lds + L_DP + IK_MAXK * MRING * 3);
+  for(int item = tid; item < ntask * 3 * MADJ; item += EVAL_NT)
   {
-    const int t = item / (3 * MAXADJ), ia = item % (3 * MAXADJ), i = ia / MAXADJ, a2 = ia % MAXADJ;
+    const int t = item / (3 * MADJ), ia = item % (3 * MADJ), i = ia / MADJ, a2 = ia % MADJ;
     if(s_usen[t])
     {
       const int u = s_ringb[t][1 + i];
       // (count and map entry in ONE round trip: the entry exists whether or not the vertex has that many faces)
-      const uint8_t * mp = mv.faceMap + (int64_t)s_facel[t] * (3 * MAXADJ * 3) + ia * 3;
+      const uint8_t * mp = mv.faceMap + (int64_t)s_facel[t] * (3 * MADJ * 3) + ia * 3;
       const int m0 = mp[0], m1 = mp[1], m2 = mp[2];
       const int cnt = mv.adjOff[u + 1] - mv.adjOff[u];
-      if(a2 == 0) s_acnt[t][i] = (uint8_t)(cnt < 255 ? cnt : 255); // (the sum below starts from LDS, not from a second round trip; smplpp_ik_create admits at most MAXADJ)
-      if(a2 < cnt && cnt <= MAXADJ) face_normal_pts(s_rpos[t][m0], s_rpos[t][m1], s_rpos[t][m2], s_fn[t][ia]);
+      if(a2 == 0) s_acnt[t][i] = (uint8_t)(cnt < 255 ? cnt : 255); // (the sum below starts from LDS, not from a second round trip; smplpp_ik_create admits at most MADJ)
+      if(a2 < cnt && cnt <= MADJ) face_normal_pts(s_rpos[t][m0], s_rpos[t][m1], s_rpos[t][m2], s_fn[t][ia]);
     }
   }
   __syncthreads();
@@ -643,8 +646,8 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
       const int u = s_ringb[t][1 + i];
       const int cnt = s_acnt[t][i];
       float vn[3];
-      if(cnt > MAXADJ) // more faces than the ring map covers: the general routine for the VALUE; the derivative tables of phase
-      {                // B hold MAXADJ faces per vertex, so the frame is flagged and host-space callers get an error
+      if(cnt > MADJ) // more faces than the ring map covers: the general routine for the VALUE; the derivative tables of phase
+      {                // B hold MADJ faces per vertex, so the frame is flagged and host-space callers get an error
         vertex_normal_dev(verts, mv.faces, mv.adjOff, mv.adjFace, u, vn);
         atomicOr(&ta.flags[f], 4);
       }
@@ -656,7 +659,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         float acc[3] = {0.f, 0.f, 0.f};
         for(int a2 = 0; a2 < cnt; a2++)
         {
-          const float * fn = s_fn[t][i * MAXADJ + a2];
+          const float * fn = s_fn[t][i * MADJ + a2];
           acc[0] += w * fn[0];
           acc[1] += w * fn[1];
           acc[2] += w * fn[2];
@@ -739,15 +742,15 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   if(dbg_stop == 22) return;
   // ---- phase B: Jacobian rows (node.cpp:823-873).  Tasks are taken in GROUPS whose ring vertices fit the LDS buffers
   // together (a position-only task touches 3 vertices, so a 6-target solve is one group; a task with a normal term
-  // touches up to MAXRING and forms a group of its own): each barrier-separated step then serves the whole group, and the
+  // touches up to MRING and forms a group of its own): each barrier-separated step then serves the whole group, and the
   // global-memory latencies of the tasks overlap instead of queueing.
   __shared__ int s_roff[IK_MAXK + 1]; // ring offset of task k inside its group's buffers
   __shared__ int s_rvert[RCAP];         // ring slot -> vertex
-  __shared__ uint8_t s_map[NGN][3 * MAXADJ * 3]; // (vertex of the face, adjacent face, corner) -> slot in the task's ring, per normal task
+  __shared__ uint8_t s_map[NGN][3 * MADJ * 3]; // (vertex of the face, adjacent face, corner) -> slot in the task's ring, per normal task
   __shared__ int s_cnt[NGN][3];         // adjacent-face count of the face's three vertices
   __shared__ float s_dvn[NGN][NQ * 3 * 3]; // per (column, triangle vertex): derivative of the vertex normal (the normal itself, the same for every column: L_VN)
-  __shared__ __attribute__((aligned(16))) float s_geo[NGN][3 * MAXADJ][12]; // per adjacent face of a triangle vertex: unit normal, |cross|, edges e1, e2
-  constexpr int MAPN = 3 * MAXADJ * 3; // ring-slot map entries per normal task
+  __shared__ __attribute__((aligned(16))) float s_geo[NGN][3 * MADJ][12]; // per adjacent face of a triangle vertex: unit normal, |cross|, edges e1, e2
+  constexpr int MAPN = 3 * MADJ * 3; // ring-slot map entries per normal task
   static_assert(RCAP + NGN * 3 <= 96 && 96 + NGN * MAPN <= EVAL_NT, "B1 hands the count / map loads to thread ranges beyond the ring threads");
   for(int g = 0; g < s_ng; g++)
   {
@@ -760,9 +763,9 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     {
       // ring tables of the group: offsets from the cumulated sizes, one thread per (task, ring slot)
       const int gbase = s_rcum[k_lo - k_begin];
-      for(int item = tid; item < (k_hi - k_lo) * MAXRING; item += EVAL_NT)
+      for(int item = tid; item < (k_hi - k_lo) * MRING; item += EVAL_NT)
       {
-        const int kk = k_lo + item / MAXRING, i = item % MAXRING;
+        const int kk = k_lo + item / MRING, i = item % MRING;
         const uint16_t * rg = s_ringb[kk - k_begin];
         const int off0 = s_rcum[kk - k_begin] - gbase;
         if(i == 0) s_roff[kk] = off0;
@@ -957,11 +960,11 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
     }
     // the column-independent half of B3n, once per adjacent face instead of once per (face, column): edges, unit normal and
     // |cross| of every face around the three vertices of each normal task (positions staged by B1)
-    if((int)tid < ngn * 3 * MAXADJ)
+    if((int)tid < ngn * 3 * MADJ)
     {
-      const int gi = tid / (3 * MAXADJ), ia = tid % (3 * MAXADJ), i = ia / MAXADJ, a = ia % MAXADJ;
+      const int gi = tid / (3 * MADJ), ia = tid % (3 * MADJ), i = ia / MADJ, a = ia % MADJ;
       int cnt = s_cnt[gi][i];
-      if(cnt > MAXADJ) cnt = MAXADJ;
+      if(cnt > MADJ) cnt = MADJ;
       if(a < cnt)
       {
         const float * rvb = lds + L_RV + s_roff[k_lo + gi] * RVS;
@@ -1027,7 +1030,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         float sum = 0.f;
         for(int a = 0; a < cnt; a++) sum += 1.0f;
         const float aw = 1.0f / sum;
-        if(cnt > MAXADJ) cnt = MAXADJ;
+        if(cnt > MADJ) cnt = MADJ;
         float mu[3] = {0.f, 0.f, 0.f}, dmu[3] = {0.f, 0.f, 0.f};
         const float * dv = dp + (i * 3) * NQ + q; // triangle vertex i (ring slot i): the first corner of every face around it
         const float dv0 = dv[0], dv1 = dv[NQ], dv2 = dv[2 * NQ];
@@ -1035,7 +1038,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
         {
           // the adjacent face's geometry from s_geo (the same values every column used to recompute); its corners' ring slots
           // ride in the record's last word (three byte reads of the map per face and column otherwise)
-          const float4 * ge = reinterpret_cast<const float4 *>(s_geo[gi][i * MAXADJ + a]);
+          const float4 * ge = reinterpret_cast<const float4 *>(s_geo[gi][i * MADJ + a]);
           const float4 g0 = ge[0], g1 = ge[1], g2 = ge[2];
           const int mpw = __float_as_int(g2.w);
           const int mp[3] = {mpw & 255, (mpw >> 8) & 255, mpw >> 16};
@@ -1263,7 +1266,7 @@ __device__ __forceinline__ void ik_eval_body(const ModelView & mv, const TaskArr
   EVAL_STAMP(7);
 }
 
-template<int DMAX, int RCAP, int NGN>
+template<int DMAX, int RCAP, int NGN, int MADJ = MAXADJ>
 __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArrays ta, const float * __restrict__ theta25,
                                                       const float * __restrict__ verts_all, const float * __restrict__ rest_all,
                                                       const float * __restrict__ Gp, const float * __restrict__ joints,
@@ -1274,7 +1277,7 @@ __global__ __launch_bounds__(EVAL_NT) void ik_eval_kernel(ModelView mv, TaskArra
                                                       const float * __restrict__ vjac, double * __restrict__ Jl_out)
 {
   // (the side stream's fork is not raised here but by the solve kernel that follows, once its workgroups run: ik_solve_kernel)
-  ik_eval_body<DMAX, RCAP, NGN>(mv, ta, theta25, verts_all, rest_all, Gp, joints, poserot, K, optimize_beta, phi_live, min_valid, pos804, e_out,
+  ik_eval_body<DMAX, RCAP, NGN, MADJ>(mv, ta, theta25, verts_all, rest_all, Gp, joints, poserot, K, optimize_beta, phi_live, min_valid, pos804, e_out,
                                 J_out, skip, dbg_stop, tsplit, roles, vjac, Jl_out);
 }
 
@@ -3194,7 +3197,7 @@ extern "C" int smplpp_ik_create(smplpp_model * m, int64_t n, int64_t K, smplpp_v
   if(K > PROJ_MAXK) return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: at most 48 tasks per frame are supported");
   if(TD75 + 2 * K + NB > MAXD)
     return fail(SMPLPP_ERR_INVALID, "smplpp_ik_create: too many tasks for the in-LDS solver (75 + 2K + 10 must be <= 181)");
-  // (a vertex with more than MAXADJ = 12 adjacent faces does not stop the solver from being created: position-only tasks anywhere and
+  // (a vertex with more than 16 adjacent faces — the widest table the evaluation is instantiated for — does not stop the solver from being created: position-only tasks anywhere and
   // normal-term tasks away from such a vertex are unaffected; a normal-term task that touches one is reported when it is evaluated)
   HIP_TRY(hipSetDevice(m->device));
   smplpp_ik * s = new smplpp_ik();
@@ -3492,25 +3495,32 @@ static int ik_forward_eval(smplpp_ik * s, int optimize_beta, int phi_live, int64
     s->side_pending = false;
   }
   s->jac_ahead = false; // (consumed by the evaluation below: the join above covers the Jacobian kernel, which raised it)
-  const bool deep = m->nlev > 9; // (ik_eval_kernel's two instantiations: see EvalPlan)
-  const size_t shmem = sizeof(float) * (deep ? EvalPlan<DMAX, 64, 3>::L_END : EvalPlan<9, 76, 6>::L_END) + L_ANC_BYTES;
-  static PerDeviceOnce once_eval[2];
-  const void * kfn = deep ? reinterpret_cast<const void *>(&ik_eval_kernel<DMAX, 64, 3>) : reinterpret_cast<const void *>(&ik_eval_kernel<9, 76, 6>);
-  HIP_TRY(lds_opt_in(once_eval[deep ? 1 : 0], m->device, kfn, (int)shmem));
+  const bool deep = m->nlev > 9; // (ik_eval_kernel's instantiations: see EvalPlan)
+  const bool wide = m->madj > MAXADJ; // a topology with a vertex of 13..16 faces: 16-face tables, fewer normal tasks per group
+  const size_t shmem = sizeof(float) * (deep ? (wide ? EvalPlan<DMAX, 64, 3>::L_END : EvalPlan<DMAX, 64, 3>::L_END)
+                                             : (wide ? EvalPlan<9, 76, 4>::L_END : EvalPlan<9, 76, 6>::L_END)) + L_ANC_BYTES;
+  static PerDeviceOnce once_eval[4];
+  const void * kfn = deep ? (wide ? reinterpret_cast<const void *>(&ik_eval_kernel<DMAX, 64, 3, MAXADJ_WIDE>) : reinterpret_cast<const void *>(&ik_eval_kernel<DMAX, 64, 3>))
+                          : (wide ? reinterpret_cast<const void *>(&ik_eval_kernel<9, 76, 4, MAXADJ_WIDE>) : reinterpret_cast<const void *>(&ik_eval_kernel<9, 76, 6>));
+  HIP_TRY(lds_opt_in(once_eval[(deep ? 1 : 0) + (wide ? 2 : 0)], m->device, kfn, (int)shmem));
   int tsplit = (n < 256) ? (int)(256 / n) : 1; // one round of workgroups (one per CU: its LDS is the evaluation's)
   if(tsplit > K) tsplit = K;
   if(tsplit < 1) tsplit = 1;
   if(s->use_flags) eval_done = nullptr; // (flags mode: the fork is the solve kernel's start flag; the evaluation's end is signalled in events mode only)
-#define EVAL_(DM, RC, NG)                                                                                                                  \
-  hipExtLaunchKernelGGL((ik_eval_kernel<DM, RC, NG>), dim3((unsigned)(n * tsplit)), dim3(EVAL_NT), shmem, st, nullptr, eval_done, 0,     \
+#define EVAL_(DM, RC, NG, MA)                                                                                                              \
+  hipExtLaunchKernelGGL((ik_eval_kernel<DM, RC, NG, MA>), dim3((unsigned)(n * tsplit)), dim3(EVAL_NT), shmem, st, nullptr, eval_done, 0,     \
                         view_of(m), s->ta, th25, (const float *)s->verts, (const float *)s->rest, (const float *)m->ws.Gp.as<float>(),     \
                         (const float *)s->joints, (const float *)s->poserot, K, optimize_beta, phi_live, (int)min_valid, s->pts, s->e,     \
                         s->J, s->skip, s->dbg_stop, tsplit, s->roles, s->vp ? (const float *)s->vjac : (const float *)nullptr,             \
                         s->vp ? s->Jl : (double *)nullptr)
-  if(deep)
-    EVAL_(DMAX, 64, 3);
+  if(deep && wide)
+    EVAL_(DMAX, 64, 3, MAXADJ_WIDE);
+  else if(deep)
+    EVAL_(DMAX, 64, 3, MAXADJ);
+  else if(wide)
+    EVAL_(9, 76, 4, MAXADJ_WIDE);
   else
-    EVAL_(9, 76, 6);
+    EVAL_(9, 76, 6, MAXADJ);
 #undef EVAL_
   HIP_TRY(hipGetLastError());
   s->have_eval = true;

@@ -660,19 +660,25 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
   {
     // IK ring tables (topology only): what a task on face f touches when it differentiates a normal — the face's vertices
     // (slots 0..2), then the distinct vertices of the faces around them, first occurrence first; the map gives every
-    // (vertex of the face, adjacent face, corner) its slot.  At most MAXADJ faces per vertex and MAXRING vertices are kept.
-    std::vector<uint16_t> ring((size_t)F * (MAXRING + 1), 0);
-    std::vector<uint8_t> map((size_t)F * 3 * MAXADJ * 3, 0);
+    // (vertex of the face, adjacent face, corner) its slot.  The tables hold `madj` faces per vertex: 12, or 16 when some vertex of
+    // this topology has more (the evaluation then runs its 16-face instantiation; beyond 16 a task with a normal term on such a
+    // vertex is reported, smplpp_ik_get_status bit 2) — and 3 (madj + 1) + 1 ring vertices.
+    int maxval = 0;
+    for(int64_t v = 0; v < V; v++) maxval = std::max<int>(maxval, m->h_adjOff[v + 1] - m->h_adjOff[v]);
+    m->madj = maxval > MAXADJ ? MAXADJ_WIDE : MAXADJ;
+    const int MADJ_ = m->madj, MRING_ = 3 * (MADJ_ + 1) + 1;
+    std::vector<uint16_t> ring((size_t)F * (MRING_ + 1), 0);
+    std::vector<uint8_t> map((size_t)F * 3 * MADJ_ * 3, 0);
     for(int64_t f = 0; f < F; f++)
     {
-      uint16_t * rg = ring.data() + f * (MAXRING + 1);
-      uint8_t * mp = map.data() + f * (3 * MAXADJ * 3);
+      uint16_t * rg = ring.data() + f * (MRING_ + 1);
+      uint8_t * mp = map.data() + f * (3 * MADJ_ * 3);
       int nr = 0;
       for(int i = 0; i < 3; i++) rg[1 + nr++] = (uint16_t)m->h_faces[f * 3 + i];
       for(int i = 0; i < 3; i++)
       {
         const int32_t u = m->h_faces[f * 3 + i], b0 = m->h_adjOff[u];
-        const int cnt = std::min<int>(m->h_adjOff[u + 1] - b0, MAXADJ);
+        const int cnt = std::min<int>(m->h_adjOff[u + 1] - b0, MADJ_);
         for(int a = 0; a < cnt; a++)
           for(int cc = 0; cc < 3; cc++)
           {
@@ -680,12 +686,12 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
             int slot = -1;
             for(int q = 0; q < nr; q++)
               if(rg[1 + q] == (uint16_t)v) slot = q;
-            if(slot < 0 && nr < MAXRING)
+            if(slot < 0 && nr < MRING_)
             {
               slot = nr;
               rg[1 + nr++] = (uint16_t)v;
             }
-            mp[(i * MAXADJ + a) * 3 + cc] = (uint8_t)(slot < 0 ? 0 : slot);
+            mp[(i * MADJ_ + a) * 3 + cc] = (uint8_t)(slot < 0 ? 0 : slot);
           }
       }
       rg[0] = (uint16_t)nr;

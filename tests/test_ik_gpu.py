@@ -558,11 +558,14 @@ def _double_fan_model(N):
     return md
 
 
-def test_ik_vertex_valence_limit():
-    """The normal-term Jacobian differentiates through every face around a task's vertices, in tables of MAXADJ = 12 faces per
-    vertex (src/SMPL.cpp:527-535, 620-640 put no bound on it).  At the bound (a 12-face fan) the evaluation matches the
-    oracle, normal rows included.  Beyond it (14) the model still gets its solver (round 4: a real topology with ONE such vertex
-    must not lose IK altogether): position-only tasks on the fan match the oracle, a task with a normal term on it is REPORTED —
+@pytest.mark.parametrize("deep", [False, True])
+def test_ik_vertex_valence_limit(deep):
+    """The normal-term Jacobian differentiates through every face around a task's vertices (src/SMPL.cpp:527-535, 620-640 put no
+    bound on it), in tables whose width is a property of the MODEL: 12 faces per vertex, or 16 when the topology has a vertex of
+    13..16 faces (smplpp_model_create measures it; the evaluation then runs its 16-face instantiation — round 6).  A 12-face fan
+    and a 16-face fan both match the oracle, normal rows included (`deep`: on a 12-level kinematic tree too, the evaluation's other
+    pair of instantiations).  Beyond 16 (18) the model still gets its solver (round 4: a real topology with ONE such vertex must
+    not lose IK altogether): position-only tasks on the fan match the oracle, a task with a normal term on it is REPORTED —
     host-space eval / iterate raise, smplpp_ik_get_status carries bit 2 — instead of silently dropping faces from the derivative,
     and the same solver works again once its normal-term tasks sit elsewhere."""
     from oracle import cpu
@@ -572,8 +575,12 @@ def test_ik_vertex_valence_limit():
     from smplpp_amd.smpl import SMPL
 
     rng = np.random.default_rng(4)
-    for N in (12, 14):
+    for N in (12, 16, 18):
         md = _double_fan_model(N)
+        if deep:
+            kt = md["kinematic_tree"].copy()
+            kt[0] = np.array([-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 0, 12, 13, 14, 0, 16, 17, 18, 3, 20, 21, 22], np.int64)
+            md["kinematic_tree"] = kt
         s = SMPL()
         s.setDevice("cuda:0")
         s.init(md)
@@ -589,7 +596,7 @@ def test_ik_vertex_valence_limit():
         tn = rng.normal(0, 1, (2, K, 3)).astype(np.float32)
         tn /= np.linalg.norm(tn, axis=2, keepdims=True)
         sol = IkSolver(s, 2, K)
-        if N > 12:
+        if N > 16:
             # position-only tasks: nothing differentiates through a vertex normal
             sol.setTasks(face_idx=faces, target_pos=tp, target_normal=tn, phi_limit=np.zeros(K), normal_task_weight=np.zeros(K))
             sol.setConfig(beta, theta)
