@@ -81,3 +81,51 @@ def test_result_writers(tmp_path):
     beta, n2, faces, w = mocap.read_mocap_body_yaml(y)
     assert n2 == names and faces.tolist() == [6842, 7324] and np.allclose(beta, np.linspace(-1, 1, 10), atol=1e-6)
     assert np.allclose(w, [[0.2, 0.3, 0.5], [1 / 3, 1 / 3, 1 / 3]], atol=1e-6)
+
+
+def test_cpp_side_of_the_formats_reads_what_python_reads(tmp_path):
+    """include/smplpp/Mocap.h (the C++ side of the capture path's on-disk formats: what node.cpp takes from ezc3d at :580-594 /
+    :667-690, /tmp/MocapBody.yaml of :1418-1441 / :509-534, the motion text of scripts/convertRosbagToText.py) against the Python
+    side on the same files: a float C3D with missing markers and prefixed labels (and, when the reference tree is present, the
+    reference's own data/sample_walk.c3d), frame by frame; the yaml the C++ writer makes is read by the Python reader and by the
+    C++ reader; the motion text by numpy."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mocap_formats")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "mocap_formats.cpp"), "-o", exe])
+    rng = np.random.default_rng(3)
+    names = sorted(mocap.BASELINE41)
+    labels = ["Skeleton0:" + n for n in names] + ["Unlabeled_1", "Unlabeled_2"]
+    pts = rng.normal(0, 1, (23, len(labels), 3)).astype(np.float32)
+    valid = rng.random((23, len(labels))) > 0.15
+    valid[5] = False  # a frame without any marker
+    p = str(tmp_path / "t.c3d")
+    mocap.write_c3d(p, labels, pts, valid, rate=120.0)
+    files = [p] + (["/root/reference/data/sample_walk.c3d"] if os.path.exists("/root/reference/data/sample_walk.c3d") else [])
+    for path in files:
+        dump, yml, txt = str(tmp_path / "dump.txt"), str(tmp_path / "body.yaml"), str(tmp_path / "motion.txt")
+        r = subprocess.run([exe, path, dump, yml, txt], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+        assert r.returncode == 0 and "OK" in r.stdout, r.stdout
+        c = mocap.read_c3d(path)
+        lines = open(dump).read().splitlines()
+        head = lines[0].split()
+        assert float(head[1]) == c["rate"] and int(head[3]) == c["points"].shape[0] and int(head[5]) == c["points"].shape[1]
+        assert [ln[6:] for ln in lines if ln.startswith("label ")] == c["labels"]
+        fr = [ln.split() for ln in lines if ln.startswith("frame ")]
+        assert len(fr) == c["points"].shape[0]
+        w = np.array([1.0, 2.0, 3.0])
+        for t, (_, ti, nv, sm) in enumerate(fr):
+            v = c["valid"][t]
+            assert int(ti) == t and int(nv) == int(v.sum())
+            assert abs(float(sm) - float((c["points"][t][v].astype(np.float64) @ w).sum())) < 1e-6 * max(1.0, abs(float(sm)))
+        got = {ln.split()[1]: int(ln.split()[2]) for ln in lines if ln.startswith("match ")}
+        assert [got[n] for n in names] == mocap.match_markers(c["labels"], names)
+        assert "yaml_roundtrip 1" in lines
+        beta, ynames, faces, weights = mocap.read_mocap_body_yaml(yml)  # the Python reader on the C++ writer's file
+        assert ynames == names and [int(f) for f in faces] == [mocap.BASELINE41[n] for n in names]
+        assert np.abs(beta - (0.1 * (np.arange(10) - 4) + 1e-7 * np.arange(10)).astype(np.float32)).max() < 1e-7
+        assert np.abs(weights.sum(axis=1) - 1).max() < 1e-6
+        th = np.loadtxt(txt)
+        assert th.shape == (3, 75) and np.abs(th - (0.01 * np.arange(225, dtype=np.float32) + np.float32(1e-6)).reshape(3, 75)).max() < 1e-7
