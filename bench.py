@@ -108,7 +108,7 @@ def roofline_object(form, n, skin_ms, launches, traffic):
             "useful": {"achieved": ALG_FLOPS_PER_FRAME * n / t_k / 1e12 if t_k > 0 else 0.0, "unit": "TFLOP/s",
                        "note": "algorithmic fp32 FLOPs of the whole FK (15.5 MFLOP per frame, SURVEY.md 8d) / kernel time"},
             "note": "frac = SURVEY 8(d): algorithmic bytes (19,347,120 + 83,020 N) / kernel time / 8 TB/s.  The kernel is bound by instruction "
-                    "issue and the matrix pipe, not by bytes: `traffic` (PMC) is within 1.35x of the algorithmic bytes, and the chip holds "
+                    "issue and the matrix pipe, not by bytes: `traffic` (PMC) is within 1.37x of the algorithmic bytes, and the chip holds "
                     "~1.7 GHz of its 2.4 GHz under it (power-limited; in-kernel stamps, DESIGN.md 3.2)",
         })
     else:
