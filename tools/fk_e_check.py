@@ -1,6 +1,6 @@
 """Development aid: the exact form (skin_e.hip) against round 1's bf16x3 kernel (skin_b.hip) — same piece products in the same
 order, same fp32 skinning: the outputs must agree bit for bit — at ragged batch sizes, with and without `rest`, then step times.
-usage (GPU box): python3 tools/fk_e_check.py [sizes...]"""
+usage (GPU box): [FK_CHECK_FORM=x] python3 tools/fk_e_check.py [sizes...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,16 +10,17 @@ from smplpp_amd.smpl import SMPL
 sizes = [int(a) for a in sys.argv[1:]] or [1, 63, 64, 65, 200, 1024, 1100]
 md = model_io.synthetic_model()
 eng = {}
-for form in ("e", "b"):
+FE = os.environ.get("FK_CHECK_FORM", "e")  # "x": the exact form on two wavefronts per SIMD (skin_x.hip)
+for form in (FE, "b"):
     os.environ["SMPLPP_SKIN"] = form
     s = SMPL(); s.setDevice("cuda:0"); s.init(md)
     eng[form] = s
 bad = 0
 for n in sizes:
     b, t = model_io.synthetic_inputs(n, seed=5 + n)
-    oe = eng["e"].launch(b, t)
+    oe = eng[FE].launch(b, t)
     ob = eng["b"].launch(b, t)
-    oe2 = eng["e"].launch(b, t, want=("verts",))
+    oe2 = eng[FE].launch(b, t, want=("verts",))
     dv, dr = np.abs(oe["verts"] - ob["verts"]).max(), np.abs(oe["rest"] - ob["rest"]).max()
     d2 = np.abs(oe2["verts"] - ob["verts"]).max()
     fin = np.isfinite(oe["verts"]).all()
@@ -27,7 +28,7 @@ for n in sizes:
     bad += (dv != 0) or (dr != 0) or (d2 != 0) or not fin
 bt, tt = model_io.synthetic_inputs(1024)
 btd, ttd = torch.from_numpy(bt).cuda(), torch.from_numpy(tt).cuda()
-for form in ("e", "b", "e"):
+for form in (FE, "b", FE):
     s = eng[form]
     out = {"verts": torch.empty((1024, 6890, 3), dtype=torch.float32, device="cuda")}
     for _ in range(600): s.launch(btd, ttd, want=("verts",), out=out)
