@@ -14,7 +14,7 @@ ARCH = "gfx950"
 # skin_h.hip: accumulators in arch VGPRs (its VALU epilogue reads them; the A operand takes the AGPRs).
 # skin_p.hip places its VALU work by hand in MFMA shadows: SLP-packing adjacent f32 FMAs into v_pk_fma_f32 (+ the v_mov
 # shuffles that feeds them) is an anti-lever beside MFMAs (cdna_hip_programming.md, per-instruction constants).
-PER_FILE_FLAGS = {"skin_p.hip": ["-fno-slp-vectorize"], "skin_b.hip": ["-fno-slp-vectorize"], "skin_e.hip": ["-fno-slp-vectorize"], "skin_x.hip": ["-fno-slp-vectorize"], "skin_h.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"], "fk.hip": ["-fno-slp-vectorize"], "ik.hip": ["-fno-slp-vectorize"]}
+PER_FILE_FLAGS = {"skin_p.hip": ["-fno-slp-vectorize"], "skin_b.hip": ["-fno-slp-vectorize"], "skin_e.hip": ["-fno-slp-vectorize"], "skin_h.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"], "fk.hip": ["-fno-slp-vectorize"], "ik.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

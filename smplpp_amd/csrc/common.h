@@ -224,7 +224,6 @@ struct smplpp_model
   int * range_flag = nullptr;  // device words [RANGE_SLOTS]: bit 0 = a launch of the fp16x2 form met an operand outside fp16's range
   uint8_t * B3e = nullptr;     // bases + skinning tables of the exact form, one 20 KiB image per (vertex group, k-step) (layout above, EB_*)
   char form = 'e';             // fused-kernel form of smplpp_fk (SMPLPP_SKIN, read once at model creation): e | h | b | p | v
-  bool split = false;          // form e through skin_kernel_x (SMPLPP_SKIN=x)
   char form_ik = 'h';          // ... of the IK / VPoser loops' internal launches (h unless SMPLPP_SKIN chose one form for everything)
   uint8_t * wIdx = nullptr;    // [VGn*32][maxw]
   float * wVal = nullptr;      // [VGn*32][maxw]

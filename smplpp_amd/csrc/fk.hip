@@ -245,7 +245,6 @@ hipError_t launch_skin_persistent(const smplpp_model * m, int64_t n, const float
 hipError_t launch_skin_bf16x3(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st); // skin_b.hip
 hipError_t launch_skin_f16x2(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st);  // skin_h.hip
 hipError_t launch_skin_exact(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st);  // skin_e.hip
-hipError_t launch_skin_split(const smplpp_model * m, int64_t n, const float * theta, float * verts, float * rest, hipStream_t st);  // skin_x.hip
 
 // Device-pointer FK (enqueue only).  Used by smplpp_fk and by the IK solver.
 // The pose step's arguments for the model's workspace (form h: with_ops adds the fused kernel's operand images; the other forms
@@ -367,7 +366,7 @@ static int fk_skin_device(smplpp_model * m, char form, int64_t n, const float * 
       HIP_TRY(hipEventRecord(e0, st));
     }
     if(form == 'e')
-      HIP_TRY(m->split ? launch_skin_split(m, n, theta, verts, rest, st) : launch_skin_exact(m, n, theta, verts, rest, st));
+      HIP_TRY(launch_skin_exact(m, n, theta, verts, rest, st));
     else if(form == 'h')
       HIP_TRY(launch_skin_f16x2(m, n, theta, verts, rest, st));
     else if(form == 'b')

@@ -348,12 +348,6 @@ extern "C" int smplpp_model_create(int64_t V, int64_t F, const float * vt, const
     const char f = form_env ? form_env[0] : 0;
     if(f == 'e' || f == 'h' || f == 'b' || f == 'p' || f == 'v')
       m->form = m->form_ik = f;
-    else if(f == 'x') // e's arithmetic and layouts on skin_kernel_x (two wavefronts per SIMD: skin_x.hip), smplpp_fk only
-    {
-      m->form = 'e';
-      m->form_ik = 'h';
-      m->split = true;
-    }
     else
     {
       m->form = 'e';

@@ -10,7 +10,7 @@ from smplpp_amd.smpl import SMPL
 sizes = [int(a) for a in sys.argv[1:]] or [1, 63, 64, 65, 200, 1024, 1100]
 md = model_io.synthetic_model()
 eng = {}
-FE = os.environ.get("FK_CHECK_FORM", "e")  # "x": the exact form on two wavefronts per SIMD (skin_x.hip)
+FE = os.environ.get("FK_CHECK_FORM", "e")  # (another form whose bits must equal b's: development builds)
 for form in (FE, "b"):
     os.environ["SMPLPP_SKIN"] = form
     s = SMPL(); s.setDevice("cuda:0"); s.init(md)
